@@ -1,0 +1,247 @@
+"""ctypes wrapper around the CPU oracle (oracle/libavp_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg. The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+
+
+class OrcCtx(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("S", C.c_int32), ("Sy", C.c_int32),
+                ("b", C.c_double * 4), ("dx", C.c_double), ("dy", C.c_double),
+                ("X", C.c_void_p), ("Y", C.c_void_p), ("occ", C.c_void_p),
+                ("P", C.c_int32), ("ox", C.c_void_p), ("oy", C.c_void_p),
+                ("lw", C.c_double), ("lf", C.c_double), ("lr", C.c_double), ("lb", C.c_double),
+                ("max_v", C.c_double), ("max_steer", C.c_double), ("min_radius", C.c_double),
+                ("safe_side", C.c_double), ("safe_fr", C.c_double),
+                ("n_steer", C.c_int32), ("steer", C.c_double * 16), ("steer_tan", C.c_double * 16),
+                ("dt", C.c_double), ("ddt", C.c_double), ("flag_radius", C.c_double),
+                ("cost_gear", C.c_double), ("cost_heading", C.c_double), ("cost_scale", C.c_double),
+                ("extended_num", C.c_int32), ("checker_kind", C.c_int32), ("max_pops", C.c_int64)]
+
+
+class OrcPlanOut(C.Structure):
+    _fields_ = [("status", C.c_int32), ("in_radius_last", C.c_int32), ("rs_valid", C.c_int32),
+                ("rs_collision", C.c_int32),
+                ("n_pops", C.c_int64), ("n_closed", C.c_int64), ("n_open", C.c_int64), ("global_index", C.c_int64),
+                ("n_checks", C.c_int64), ("n_rs", C.c_int64), ("n_dij_calls", C.c_int64), ("n_dij_closed", C.c_int64),
+                ("n_closed_hit", C.c_int64), ("n_open_hit", C.c_int64), ("n_improved", C.c_int64),
+                ("n_collided", C.c_int64), ("n_pushed", C.c_int64),
+                ("n_astar", C.c_int32), ("n_rs_pts", C.c_int32), ("n_final", C.c_int32),
+                ("rs_n", C.c_int32), ("rs_types", C.c_int8 * 8), ("rs_lengths", C.c_double * 5), ("rs_L", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libavp_oracle.so")
+    src = os.path.join(_HERE, "avp_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libavp_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        assert L.orc_sizeof_ctx() == C.sizeof(OrcCtx), (L.orc_sizeof_ctx(), C.sizeof(OrcCtx))
+        assert L.orc_sizeof_plan_out() == C.sizeof(OrcPlanOut), (L.orc_sizeof_plan_out(), C.sizeof(OrcPlanOut))
+        L.orc_pi_2_pi.restype = C.c_double
+        L.orc_pi_2_pi.argtypes = [C.c_double]
+        L.orc_M.restype = C.c_double
+        L.orc_M.argtypes = [C.c_double]
+        L.orc_py_hypot.restype = C.c_double
+        L.orc_py_hypot.argtypes = [C.c_double, C.c_double]
+        L.orc_pos_to_index.restype = C.c_int64
+        L.orc_pos_to_index.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_is_obstacle.restype = C.c_int32
+        L.orc_is_obstacle.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_dij_create.restype = C.c_void_p
+        L.orc_dij_create.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_dij_destroy.argtypes = [C.c_void_p]
+        L.orc_dij_compute_path.restype = C.c_int64
+        L.orc_dij_compute_path.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_dij_lookup.restype = C.c_int64
+        L.orc_dij_lookup.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_dij_nclosed.restype = C.c_int64
+        L.orc_dij_nclosed.argtypes = [C.c_void_p]
+        L.orc_dij_dump.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orc_plan.restype = C.c_int32
+        L.orc_split_path.restype = C.c_int32
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """CPU oracle bound to one map + vehicle + config (all reference semantics)."""
+
+    def __init__(self, park_map, vehicle, config: dict, max_pops: int = 0):
+        self.L = lib()
+        pk = park_map.pack()
+        self._keep = pk
+        ctx = OrcCtx()
+        ctx.nx, ctx.ny, ctx.S, ctx.Sy = pk["nx"], pk["ny"], pk["S"], pk["Sy"]
+        for i in range(4):
+            ctx.b[i] = float(pk["boundary"][i])
+        ctx.dx, ctx.dy = pk["dx"], pk["dy"]
+        ctx.X, ctx.Y, ctx.occ = _p(pk["xs"]), _p(pk["ys"]), _p(pk["occ"])
+        ctx.P = len(pk["obs_x"])
+        ctx.ox, ctx.oy = _p(pk["obs_x"]), _p(pk["obs_y"])
+        v = vehicle
+        ctx.lw, ctx.lf, ctx.lr, ctx.lb = v.lw, v.lf, v.lr, v.lb
+        ctx.max_v, ctx.max_steer, ctx.min_radius = v.max_v, v.max_steering_angle, float(v.min_radius_turn)
+        ctx.safe_side, ctx.safe_fr = config["safe_side_dis"], config["safe_fr_dis"]
+        n = int(config["steering_angle_num"])
+        steer = np.linspace(-v.max_steering_angle, v.max_steering_angle, n)
+        ctx.n_steer = n
+        for i in range(n):
+            ctx.steer[i] = float(steer[i])
+            ctx.steer_tan[i] = float(np.tan(steer[i]))
+        ctx.dt, ctx.ddt, ctx.flag_radius = config["dt"], config["trajectory_dt"], float(config["flag_radius"])
+        ctx.cost_gear, ctx.cost_heading, ctx.cost_scale = config["cost_gear"], config["cost_heading_change"], config["cost_scale"]
+        ctx.extended_num = int(config["extended_num"])
+        ctx.checker_kind = 1 if config["collision_check"] == "circle" else 0
+        ctx.max_pops = max_pops
+        self.ctx = ctx
+        self.maxc = 1 / float(v.min_radius_turn)
+        self.P = ctx.P
+
+    @property
+    def ref(self):
+        return C.byref(self.ctx)
+
+    # -- index maths -------------------------------------------------------------------------
+    def pos_to_index(self, x, y):
+        return int(self.L.orc_pos_to_index(self.ref, float(x), float(y)))
+
+    def is_obstacle(self, x, y):
+        return int(self.L.orc_is_obstacle(self.ref, float(x), float(y)))
+
+    def corners(self, x, y, th):
+        out = np.zeros(8)
+        self.L.orc_corners(self.ref, C.c_double(x), C.c_double(y), C.c_double(th), _p(out))
+        return out.reshape(4, 2)
+
+    # -- collision ---------------------------------------------------------------------------
+    def check_batch(self, poses, kind=0, want_near=False):
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        x, y, th = [np.ascontiguousarray(poses[:, i]) for i in range(3)]
+        out = np.zeros(len(x), np.uint8)
+        near = np.zeros(len(x), np.int32)
+        self.L.orc_check_batch(self.ref, C.c_int32(kind), _p(x), _p(y), _p(th), C.c_int64(len(x)), _p(out), _p(near))
+        return (out, near) if want_near else out
+
+    # -- Reeds-Shepp -------------------------------------------------------------------------
+    def rs_candidates(self, q0, q1, maxc=None):
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        q1 = np.ascontiguousarray(q1, dtype=np.float64)
+        n = len(q0)
+        nc = np.zeros(n, np.int32)
+        ty = np.zeros((n, 12, 5), np.int8)
+        le = np.zeros((n, 12, 5))
+        self.L.orc_rs_candidates(_p(q0), _p(q1), C.c_double(maxc or self.maxc), C.c_int64(n), _p(nc), _p(ty), _p(le))
+        return nc, ty, le
+
+    def rs_optimal(self, q0, q1, maxc=None, maxpts=128):
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        q1 = np.ascontiguousarray(q1, dtype=np.float64)
+        n = len(q0)
+        st = np.zeros(n, np.int32)
+        L = np.zeros(n)
+        ty = np.zeros((n, 5), np.int8)
+        le = np.zeros((n, 5))
+        npts = np.zeros(n, np.int32)
+        pts = np.zeros((n, maxpts, 3))
+        dr = np.zeros((n, maxpts), np.int8)
+        self.L.orc_rs_optimal_batch(_p(q0), _p(q1), C.c_double(maxc or self.maxc), C.c_int64(n), C.c_int32(maxpts),
+                                    _p(st), _p(L), _p(ty), _p(le), _p(npts), _p(pts), _p(dr))
+        return dict(status=st, L=L, types=ty, lens=le, npts=npts, pts=pts, dirs=dr)
+
+    # -- heuristic field ---------------------------------------------------------------------
+    def dijkstra(self, gx, gy):
+        return OracleDijkstra(self, gx, gy)
+
+    # -- full plan ---------------------------------------------------------------------------
+    def plan(self, start, goal, max_trace=20000, max_path=1024, want_h=False):
+        start = np.ascontiguousarray(start, dtype=np.float64)
+        goal = np.ascontiguousarray(goal, dtype=np.float64)
+        out = OrcPlanOut()
+        trace = np.zeros((max_trace, 11))
+        ap = np.zeros((max_path, 3))
+        rp = np.zeros((max_path, 3))
+        rd = np.zeros(max_path, np.int8)
+        fp = np.zeros((max_path, 3))
+        max_h = 1 << 20 if want_h else 0
+        hid = np.zeros(max(max_h, 1), np.int64)
+        hd = np.zeros(max(max_h, 1), np.int64)
+        self.L.orc_plan(self.ref, _p(start), _p(goal), C.byref(out), _p(trace), C.c_int64(max_trace), _p(ap), _p(rp),
+                        _p(rd), _p(fp), C.c_int32(max_path), _p(hid) if want_h else None, _p(hd) if want_h else None,
+                        C.c_int64(max_h))
+        np_ = min(out.n_pops, max_trace)
+        res = dict(status=out.status, n_pops=out.n_pops, trace=trace[:np_].copy(), astar_path=ap[:out.n_astar].copy(),
+                   rs_xyyaw=rp[:out.n_rs_pts].copy(), rs_dir=rd[:out.n_rs_pts].copy(), final_path=fp[:out.n_final].copy(),
+                   rs_types=np.array(out.rs_types[:out.rs_n], dtype=np.int8), rs_lengths=np.array(out.rs_lengths[:out.rs_n]),
+                   rs_L=out.rs_L, rs_valid=out.rs_valid, rs_collision=out.rs_collision, in_radius_last=out.in_radius_last)
+        for k in ("n_closed", "n_open", "global_index", "n_checks", "n_rs", "n_dij_calls", "n_dij_closed", "n_closed_hit",
+                  "n_open_hit", "n_improved", "n_collided", "n_pushed"):
+            res[k] = getattr(out, k)
+        if want_h:
+            res["h_closed_id"] = hid[:out.n_dij_closed].copy()
+            res["h_closed_dist"] = hd[:out.n_dij_closed].copy()
+        return res
+
+    def split_path(self, final_path, max_pts=4096, max_seg=256):
+        fp = np.ascontiguousarray(final_path, dtype=np.float64)
+        pts = np.zeros((max_pts, 3))
+        seg = np.zeros(max_seg, np.int32)
+        nseg = C.c_int32(0)
+        cg = C.c_int32(0)
+        r = self.L.orc_split_path(self.ref, _p(fp), C.c_int32(len(fp)), _p(pts), C.c_int32(max_pts), _p(seg),
+                                  C.c_int32(max_seg), C.byref(nseg), C.byref(cg))
+        if r == -2:
+            raise IndexError("list index out of range")
+        if r < 0:
+            raise RuntimeError("split_path capacity")
+        return pts[:r].copy(), seg[:nseg.value].copy(), cg.value
+
+
+class OracleDijkstra:
+    def __init__(self, orc: Oracle, gx, gy):
+        self.o = orc
+        self.h = orc.L.orc_dij_create(orc.ref, C.c_double(gx), C.c_double(gy))
+
+    def compute_path(self, x, y):
+        return int(self.o.L.orc_dij_compute_path(self.h, C.c_double(x), C.c_double(y)))
+
+    def lookup(self, gid):
+        return int(self.o.L.orc_dij_lookup(self.h, C.c_int64(gid)))
+
+    def dump(self):
+        n = int(self.o.L.orc_dij_nclosed(self.h))
+        ids = np.zeros(n, np.int64)
+        d = np.zeros(n, np.int64)
+        x = np.zeros(n)
+        y = np.zeros(n)
+        self.o.L.orc_dij_dump(self.h, _p(ids), _p(d), _p(x), _p(y))
+        return ids, d, x, y
+
+    def __del__(self):
+        try:
+            self.o.L.orc_dij_destroy(self.h)
+        except Exception:
+            pass
