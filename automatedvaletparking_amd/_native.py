@@ -1,0 +1,207 @@
+"""ctypes binding of libavp_hip.so (C-ABI in include/avp.h) + device buffer plumbing.
+
+PyTorch-ROCm is used for exactly two things: owning device buffers (tensors whose data_ptr() is
+handed to the C-ABI) and naming the stream the kernels are queued on. There is NO CPU fallback:
+if the shared library or a GPU is missing, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libavp_hip.so")
+HOSTMATH_PATH = os.path.join(_PKG, "libavp_hostmath.so")
+AVP_MAX_STEER = 16
+
+EXPORTS = [
+    "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
+    "avp_check_batch", "avp_trig_batch", "avp_ieee_batch",
+]
+
+
+class AvpParams(C.Structure):
+    _fields_ = [
+        ("lw", C.c_double), ("lf", C.c_double), ("lr", C.c_double), ("lb", C.c_double),
+        ("max_v", C.c_double), ("max_steer", C.c_double), ("min_radius", C.c_double),
+        ("fp_xr", C.c_double), ("fp_xf", C.c_double), ("fp_yr", C.c_double), ("fp_yl", C.c_double),
+        ("circ_rd", C.c_double), ("circ_cf", C.c_double), ("circ_cr", C.c_double),
+        ("n_steer", C.c_int32), ("n_sub", C.c_int32),
+        ("steer", C.c_double * AVP_MAX_STEER), ("dth_dt", C.c_double * AVP_MAX_STEER),
+        ("dth_ddt", (C.c_double * 4) * AVP_MAX_STEER),
+        ("travel_dt", C.c_double), ("travel_ddt", C.c_double * 4),
+        ("flag_radius", C.c_double),
+        ("cost_gear", C.c_double), ("cost_heading", C.c_double), ("cost_scale", C.c_double),
+        ("maxc", C.c_double),
+        ("extended_num", C.c_int32), ("checker_kind", C.c_int32), ("max_pops", C.c_int64),
+    ]
+
+
+def make_params(config: dict, vehicle, max_pops: int = 0) -> AvpParams:
+    """Pack config + Vehicle into avp_params. Every constant is evaluated here with the reference's
+    own expression order and numpy/Python functions (np.tan, np.sqrt, float **), see the file:line
+    notes in include/avp.h."""
+    v = vehicle
+    p = AvpParams()
+    p.lw, p.lf, p.lr, p.lb = v.lw, v.lf, v.lr, v.lb
+    p.max_v, p.max_steer, p.min_radius = v.max_v, v.max_steering_angle, float(v.min_radius_turn)
+    side, fr = config['safe_side_dis'], config['safe_fr_dis']
+    p.fp_xr = -v.lr - fr                      # map/costmap.py:97
+    p.fp_xf = v.lw + v.lf + fr                # :99
+    p.fp_yr = -v.lb / 2 - side                # :97
+    p.fp_yl = v.lb / 2 + side                 # :100
+    p.circ_rd = float(0.5 * np.sqrt(((v.lr + v.lw + v.lf) / 2) ** 2 + (v.lb ** 2)))   # collision_check.py:92
+    p.circ_cf = 1 / 4 * (3 * v.lw + 3 * v.lf - v.lr)                                     # :94
+    p.circ_cr = 1 / 4 * (v.lw + v.lf - 3 * v.lr)                                         # :96
+    n = int(config['steering_angle_num'])
+    if not (1 <= n <= AVP_MAX_STEER):
+        raise ValueError("steering_angle_num must be in 1..16")
+    steer = np.linspace(-v.max_steering_angle, v.max_steering_angle, n)                  # hybrid_a_star.py:81-83
+    dt, ddt = config['dt'], config['trajectory_dt']
+    n_sub = math.ceil(dt / ddt)                                                         # :185
+    if not (1 <= n_sub <= 4):
+        raise ValueError("ceil(dt/trajectory_dt) must be in 1..4")
+    p.n_steer, p.n_sub = n, n_sub
+    for i in range(n):
+        p.steer[i] = float(steer[i])
+        p.dth_dt[i] = float((v.max_v * np.tan(steer[i])) / v.lw * dt)                    # :146-148
+        for j in range(n_sub):
+            p.dth_ddt[i][j] = float((v.max_v * np.tan(steer[i])) / v.lw * ddt * (j + 1))  # :189-191
+    p.travel_dt = v.max_v * dt                                                          # :145
+    for j in range(n_sub):
+        p.travel_ddt[j] = v.max_v * ddt * (j + 1)                                       # :188
+    p.flag_radius = float(config['flag_radius'])
+    p.cost_gear, p.cost_heading, p.cost_scale = config['cost_gear'], config['cost_heading_change'], config['cost_scale']
+    p.maxc = 1 / float(v.min_radius_turn)                                               # :285
+    p.extended_num = int(config['extended_num'])
+    p.checker_kind = 1 if config['collision_check'] == 'circle' else 0
+    p.max_pops = int(max_pops)
+    return p
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library. Raises if the extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the hot path)")
+        L = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(L, name).restype = C.c_int32
+        if hasattr(L, "avp_plan_workspace_bytes"):
+            L.avp_plan_workspace_bytes.restype = C.c_int64
+        if L.avp_sizeof_params() != C.sizeof(AvpParams):
+            raise RuntimeError("avp_params layout mismatch between include/avp.h and _native.AvpParams")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().avp_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def chk(status: int, what: str = ""):
+    if status != 0:
+        raise RuntimeError(f"{what or 'libavp_hip'}: status {status}: {last_error()}")
+
+
+def torch_cuda():
+    """torch with a visible GPU, or a loud failure."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no ROCm GPU visible: the hybrid-A* hot path has no CPU fallback "
+                           "(the CPU restatement under oracle/ is test infrastructure only)")
+    return torch
+
+
+def _vp(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceMap:
+    """One costmap resident in HBM on one device (avp_map handle)."""
+
+    def __init__(self, park_map, vehicle, config: dict, device: Optional[int] = None, max_pops: int = 0):
+        torch = torch_cuda()
+        self.torch = torch
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.params = make_params(config, vehicle, max_pops)
+        pk = park_map.pack()
+        self.pack = pk
+        self.P = len(pk["obs_ix"])
+        h = C.c_void_p()
+        bnd = np.ascontiguousarray(pk["boundary"], dtype=np.float64)
+        chk(lib().avp_map_create(C.byref(self.params), _vp(pk["occ"]), C.c_int32(pk["nx"]), C.c_int32(pk["ny"]),
+                                 _vp(pk["xs"]), _vp(pk["ys"]), _vp(bnd), _vp(pk["obs_ix"]), _vp(pk["obs_iy"]),
+                                 C.c_int32(self.P), C.c_int32(self.device), C.byref(h)), "avp_map_create")
+        self.h = h
+        self.use_current_stream()
+
+    def use_current_stream(self):
+        """Queue kernels on torch's current stream of this device (so torch.cuda.Event timing sees them)."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        chk(lib().avp_map_set_stream(self.h, C.c_void_p(s)), "avp_map_set_stream")
+
+    def sync(self):
+        chk(lib().avp_sync(self.h), "avp_sync")
+
+    def dev_tensor(self, arr, dtype=None):
+        t = self.torch.as_tensor(np.ascontiguousarray(arr), device=f"cuda:{self.device}")
+        return t if dtype is None else t.to(dtype)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+
+    def zeros(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=dtype, device=f"cuda:{self.device}")
+
+    # ---- collision -----------------------------------------------------------------------------
+    def check_batch_dev(self, x, y, th, out=None, kind: int = 0, variant: int = 0):
+        """x, y, th: float64 CUDA tensors (SoA). Returns a uint8 CUDA tensor (asynchronous)."""
+        torch = self.torch
+        n = x.numel()
+        if out is None:
+            out = torch.empty(n, dtype=torch.uint8, device=x.device)
+        chk(lib().avp_check_batch(self.h, C.c_int32(kind), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                  C.c_void_p(th.data_ptr()), C.c_int64(n), C.c_void_p(out.data_ptr()), C.c_int32(variant)),
+            "avp_check_batch")
+        return out
+
+    def check_batch(self, poses, kind: int = 0, variant: int = 0) -> np.ndarray:
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
+        if len(poses) == 0:
+            return np.zeros(0, np.uint8)
+        soa = self.dev_tensor(poses.T.copy())
+        out = self.check_batch_dev(soa[0], soa[1], soa[2], kind=kind, variant=variant)
+        return out.cpu().numpy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().avp_map_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def device_map(park_map, vehicle, config, device: Optional[int] = None) -> DeviceMap:
+    """DeviceMap cached on the Map object per (device, config identity)."""
+    torch = torch_cuda()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    cache = park_map.__dict__.setdefault("_avp_device_maps", {})
+    key = (dev, id(config), tuple(sorted((k, repr(v)) for k, v in config.items())))
+    dm = cache.get(key)
+    if dm is None:
+        dm = DeviceMap(park_map, vehicle, config, dev)
+        cache[key] = dm
+    return dm

@@ -1,0 +1,217 @@
+// avp_capi.hip -- the C-ABI of libavp_hip.so (see include/avp.h). Single translation unit:
+// every kernel header is included here and compiled for gfx950 with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../include/avp.h"
+#include "avp_device.h"
+#include "avp_check_kernels.h"
+#include "avp_rs_kernels.h"
+#include "avp_plan_kernels.h"
+
+static thread_local char g_err[512] = "";
+static int32_t set_err(int32_t code, const char* fmt, const char* a = "", const char* b = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return set_err(AVP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct avp_map {
+    avp_params params;
+    DevMap dev;
+    int32_t device;
+    hipStream_t stream;
+    void* blob;          // one device allocation holding every table
+    size_t blob_bytes;
+    int32_t n_cu;
+    // planner scratch owned by the handle (problem queue counter etc.)
+    void* counters;
+};
+
+extern "C" {
+#define AVP_EXPORT __attribute__((visibility("default")))
+
+AVP_EXPORT int32_t avp_version(void) { return AVP_VERSION; }
+AVP_EXPORT int32_t avp_sizeof_params(void) { return (int32_t)sizeof(avp_params); }
+
+AVP_EXPORT int32_t avp_last_error(char* buf, int32_t n)
+{
+    if (!buf || n <= 0) return AVP_ERR_ARG;
+    strncpy(buf, g_err, (size_t)n - 1);
+    buf[n - 1] = 0;
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, int32_t nx, int32_t ny, const double* xs,
+                       const double* ys, const double boundary[4], const int32_t* obs_ix, const int32_t* obs_iy,
+                       int32_t P, int32_t device, avp_map** out)
+{
+    if (!params || !occ || !xs || !ys || !boundary || !out || nx < 2 || ny < 2 || nx > 8191 || ny > 8191 || P < 0 ||
+        (P > 0 && (!obs_ix || !obs_iy)))
+        return set_err(AVP_ERR_ARG, "avp_map_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(AVP_ERR_NOGPU, "no HIP device visible");
+    if (device < 0 || device >= ndev) return set_err(AVP_ERR_ARG, "avp_map_create: device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+
+    avp_map* m = new avp_map();
+    memset(m, 0, sizeof(*m));
+    m->params = *params;
+    m->device = device;
+    m->stream = nullptr;
+    m->n_cu = prop.multiProcessorCount;
+    DevMap& d = m->dev;
+    d.nx = nx; d.ny = ny; d.P = P;
+    d.b0 = boundary[0]; d.b1 = boundary[1]; d.b2 = boundary[2]; d.b3 = boundary[3];
+    d.dx = xs[1] - xs[0];                       // map/costmap.py:190-191
+    d.dy = ys[1] - ys[0];
+    d.S = (int32_t)((d.b1 - d.b0) / d.dx);      // map/costmap.py:328
+    d.Sy = (int32_t)((d.b3 - d.b2) / d.dy);     // compute_h.py:245-246
+    d.wpc = (ny + 63) / 64;
+
+    // host-side tables
+    std::vector<double> ox((size_t)P), oy((size_t)P);
+    std::vector<int32_t> colStart((size_t)nx + 1, 0);
+    std::vector<uint64_t> bits((size_t)nx * d.wpc, 0);
+    for (int32_t q = 0; q < P; q++) {
+        const int32_t ix = obs_ix[q], iy = obs_iy[q];
+        if (ix < 0 || ix >= nx || iy < 0 || iy >= ny || occ[(size_t)ix * ny + iy] != 255 ||
+            (q > 0 && (ix < obs_ix[q - 1] || (ix == obs_ix[q - 1] && iy <= obs_iy[q - 1])))) {
+            delete m;
+            return set_err(AVP_ERR_ARG, "avp_map_create: obstacle cells must be the np.where(cost_map==255) list");
+        }
+        ox[q] = xs[ix]; oy[q] = ys[iy];
+        colStart[(size_t)ix + 1]++;
+        bits[(size_t)ix * d.wpc + (iy >> 6)] |= 1ull << (iy & 63);
+    }
+    for (int32_t i = 0; i < nx; i++) colStart[(size_t)i + 1] += colStart[i];
+
+    // one blob: [X][Y][ox][oy][bits][colStart][occ]
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t oX = off; off = al(off + (size_t)nx * 8);
+    const size_t oY = off; off = al(off + (size_t)ny * 8);
+    const size_t oOx = off; off = al(off + (size_t)(P > 0 ? P : 1) * 8);
+    const size_t oOy = off; off = al(off + (size_t)(P > 0 ? P : 1) * 8);
+    const size_t oB = off; off = al(off + bits.size() * 8);
+    const size_t oC = off; off = al(off + colStart.size() * 4);
+    const size_t oOcc = off; off = al(off + (size_t)nx * ny);
+    const size_t oCnt = off; off = al(off + 256);
+    m->blob_bytes = off;
+    if (hipMalloc(&m->blob, off) != hipSuccess) { delete m; return set_err(AVP_ERR_HIP, "hipMalloc of the map blob failed"); }
+    char* base = (char*)m->blob;
+    std::vector<char> host(off, 0);
+    memcpy(host.data() + oX, xs, (size_t)nx * 8);
+    memcpy(host.data() + oY, ys, (size_t)ny * 8);
+    if (P > 0) { memcpy(host.data() + oOx, ox.data(), (size_t)P * 8); memcpy(host.data() + oOy, oy.data(), (size_t)P * 8); }
+    memcpy(host.data() + oB, bits.data(), bits.size() * 8);
+    memcpy(host.data() + oC, colStart.data(), colStart.size() * 4);
+    memcpy(host.data() + oOcc, occ, (size_t)nx * ny);
+    if (hipMemcpy(base, host.data(), off, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(m->blob); delete m;
+        return set_err(AVP_ERR_HIP, "hipMemcpy of the map blob failed");
+    }
+    d.X = (const double*)(base + oX); d.Y = (const double*)(base + oY);
+    d.ox = (const double*)(base + oOx); d.oy = (const double*)(base + oOy);
+    d.colBits = (const uint64_t*)(base + oB); d.colStart = (const int32_t*)(base + oC);
+    d.occ = (const uint8_t*)(base + oOcc);
+    m->counters = base + oCnt;
+    *out = m;
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_map_destroy(avp_map* map)
+{
+    if (!map) return AVP_OK;
+    hipSetDevice(map->device);
+    if (map->blob) hipFree(map->blob);
+    delete map;
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_map_set_stream(avp_map* map, void* hip_stream)
+{
+    if (!map) return set_err(AVP_ERR_ARG, "null map");
+    map->stream = (hipStream_t)hip_stream;
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_sync(avp_map* map)
+{
+    if (!map) return set_err(AVP_ERR_ARG, "null map");
+    HIPCHK(hipSetDevice(map->device));
+    HIPCHK(hipStreamSynchronize(map->stream));
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, const double* y, const double* th, int64_t n,
+                        uint8_t* out, int32_t variant)
+{
+    if (!map || n < 0 || (n > 0 && (!x || !y || !th || !out))) return set_err(AVP_ERR_ARG, "avp_check_batch: bad argument");
+    if (n == 0) return AVP_OK;
+    HIPCHK(hipSetDevice(map->device));
+    const DevMap& d = map->dev;
+    if (kind == 1) {
+        const int64_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(check_circle_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
+    } else if (kind == 0) {
+        // the production kernel assumes the footprint AABB spans at most two 64-row bitmap words
+        const double diag = sqrt((map->params.fp_xf - map->params.fp_xr) * (map->params.fp_xf - map->params.fp_xr) +
+                                 (map->params.fp_yl - map->params.fp_yr) * (map->params.fp_yl - map->params.fp_yr));
+        const bool rows_ok = diag / d.dy + 3.0 < 64.0;
+        if (variant == 1 || !rows_ok) {
+            const int64_t blocks = (n + 255) / 256;
+            hipLaunchKernelGGL(check_distance_naive_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
+        } else {
+            const size_t lds_full = check_distance_lds_bytes(d, true);
+            const bool stage = lds_full <= 160 * 1024;
+            const size_t lds = stage ? lds_full : check_distance_lds_bytes(d, false);
+            const int64_t tiles = (n + 63) / 64;
+            int64_t blocks = (tiles + CHK_WAVES - 1) / CHK_WAVES;
+            const int64_t cap = (int64_t)map->n_cu * (stage ? 1 : 2);
+            if (blocks > cap) blocks = cap;
+            if (stage) {
+                HIPCHK(hipFuncSetAttribute((const void*)check_distance_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(check_distance_kernel<true>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, x, y, th, n, out);
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void*)check_distance_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(check_distance_kernel<false>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, x, y, th, n, out);
+            }
+        }
+    } else
+        return set_err(AVP_ERR_ARG, "avp_check_batch: kind must be 0 (distance) or 1 (circle)");
+    HIPCHK(hipGetLastError());
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos)
+{
+    if (!map || n <= 0 || !x || !out_sin || !out_cos) return set_err(AVP_ERR_ARG, "avp_trig_batch: bad argument");
+    HIPCHK(hipSetDevice(map->device));
+    hipLaunchKernelGGL(trig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, map->stream, x, n, out_sin, out_cos);
+    HIPCHK(hipGetLastError());
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_ieee_batch(avp_map* map, const double* a, const double* b, int64_t n, double* q, double* r, double* h)
+{
+    if (!map || n <= 0 || !a || !b || !q || !r || !h) return set_err(AVP_ERR_ARG, "avp_ieee_batch: bad argument");
+    HIPCHK(hipSetDevice(map->device));
+    hipLaunchKernelGGL(ieee_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, map->stream, a, b, n, q, r, h);
+    HIPCHK(hipGetLastError());
+    return AVP_OK;
+}
+
+#include "avp_capi_rs.inc"
+#include "avp_capi_plan.inc"
+
+}  // extern "C"

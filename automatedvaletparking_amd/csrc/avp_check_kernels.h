@@ -1,0 +1,224 @@
+// avp_check_kernels.h -- batched vehicle-footprint collision kernels (gfx950, wave64).
+//
+// Replaces the per-pose Python calls distance_checker.check / two_circle_checker.check
+// (collision_check/collision_check.py:144-240, 88-137). Results are bit-identical booleans.
+//
+// Production kernel (check_distance_kernel): one lane = one pose, one wave = 64 poses, four
+// independent waves per workgroup, persistent over pose tiles.
+//   1. The per-column occupancy bitmaps and the node coordinate tables of the map are staged once
+//      per workgroup into LDS (Case1: 9.3 KB + 4.3 KB; Case19: 25 KB + 7.3 KB).
+//   2. Each lane builds its footprint record (corners, 4 edge lines, thresholds) and parks it in LDS.
+//   3. Broad phase: the lane walks the <= 54 map columns under its AABB; per column the bitmap
+//      word(s) are masked to the AABB rows. The surviving bits are exactly the reference's
+//      "near obstacle" points, in the same (ix, iy) order.
+//   4. The (pose, ix, iy) candidates of all 64 lanes are compacted into one per-wave LDS queue
+//      with a wave prefix sum, so that the expensive exact test (16 fp64 divisions per point)
+//      runs on full waves regardless of how unevenly the candidates are spread over poses.
+//   5. Narrow phase: one lane = one candidate; the pose's footprint record is gathered from LDS.
+// No MFMA: there is no contraction. fp64 VALU + LDS bound; obstacle data never leaves the CU.
+#pragma once
+#include "avp_device.h"
+
+// ---- variant 1: straightforward all-points kernel (cross-check) -------------------------------
+__global__ __launch_bounds__(256) void check_distance_naive_kernel(DevMap m, avp_params p, const double* __restrict__ x,
+                                                                   const double* __restrict__ y,
+                                                                   const double* __restrict__ th, int64_t n,
+                                                                   uint8_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Footprint f;
+    avp_footprint_setup(p, x[i], y[i], th[i], f);
+    double xmin, xmax, ymin, ymax;
+    avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
+    bool hit = false;
+    for (int q = 0; q < m.P && !hit; q++) {
+        const double px = m.ox[q], py = m.oy[q];
+        if (px >= xmin && px <= xmax && py >= ymin && py <= ymax) hit = avp_footprint_point_hit(f, px, py);
+    }
+    out[i] = hit ? 1 : 0;
+}
+
+// ---- production kernel ------------------------------------------------------------------------
+#define CHK_WAVES 4
+#define CHK_QCAP 4096          // queue entries per wave (u32)
+#define CHK_QDRAIN 512         // drain threshold: CHK_QCAP - 64 lanes * 56 rows
+#define CHK_FPW (sizeof(Footprint) / 8)
+
+__device__ __forceinline__ int wave_prefix_excl(int v, int lane, int& total)
+{
+    // exclusive prefix sum over the 64 lanes of a wave
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(s, d, 64);
+        if (lane >= d) s += t;
+    }
+    total = __shfl(s, 63, 64);
+    return s - v;
+}
+
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+template <bool STAGE>
+__global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m, avp_params p,
+                                                                        const double* __restrict__ x,
+                                                                        const double* __restrict__ y,
+                                                                        const double* __restrict__ th, int64_t n,
+                                                                        uint8_t* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve: [bitmap words][X][Y][per-wave: footprints 64*24 doubles | queue | hit flags]
+    // STAGE: map tables live in LDS; otherwise (map too large for 160 KB) they are read through L1/L2
+    uint64_t* lBits = (uint64_t*)smem;
+    double* lX = (double*)(lBits + (STAGE ? (size_t)m.nx * m.wpc : 0));
+    double* lY = lX + (STAGE ? m.nx : 0);
+    double* sWave = lY + (STAGE ? m.ny : 0);
+    const uint64_t* sBits = STAGE ? lBits : m.colBits;
+    const double* sX = STAGE ? lX : m.X;
+    const double* sY = STAGE ? lY : m.Y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t perWave = 64 * CHK_FPW + CHK_QCAP / 2 + 8;   // in doubles
+    double* sFp = sWave + (size_t)wave * perWave;
+    uint32_t* sQ = (uint32_t*)(sFp + 64 * CHK_FPW);
+    volatile uint8_t* sHit = (volatile uint8_t*)(sQ + CHK_QCAP);
+
+    if (STAGE) {
+        for (int i = threadIdx.x; i < m.nx * m.wpc; i += blockDim.x) lBits[i] = m.colBits[i];
+        for (int i = threadIdx.x; i < m.nx; i += blockDim.x) lX[i] = m.X[i];
+        for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
+        __syncthreads();
+    }
+
+    const int64_t tiles = (n + 63) / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * CHK_WAVES + wave; tile < tiles; tile += (int64_t)gridDim.x * CHK_WAVES) {
+        const int64_t i = tile * 64 + lane;
+        const bool valid = i < n;
+        int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
+        {
+            Footprint f;
+            avp_footprint_setup(p, valid ? x[i] : 0.0, valid ? y[i] : 0.0, valid ? th[i] : 0.0, f);
+            double xmin, xmax, ymin, ymax;
+            avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
+            if (valid) {
+                ixlo = avp_first_ge(sX, m.nx, m.b0, m.dx, xmin);
+                ixhi = avp_last_le(sX, m.nx, m.b0, m.dx, xmax);
+                iylo = avp_first_ge(sY, m.ny, m.b2, m.dy, ymin);
+                iyhi = avp_last_le(sY, m.ny, m.b2, m.dy, ymax);
+                if (iylo > iyhi) ixhi = ixlo - 1;
+            }
+            const double* src = (const double*)&f;
+            double* dst = sFp + (size_t)lane * CHK_FPW;
+#pragma unroll
+            for (int k = 0; k < (int)CHK_FPW; k++) dst[k] = src[k];
+        }
+        sHit[lane] = 0;
+        wave_sync();
+        int ncol = ixhi - ixlo + 1;
+        if (ncol < 0) ncol = 0;
+        int maxcol = ncol;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) maxcol = max(maxcol, __shfl_xor(maxcol, d, 64));
+        int qtail = 0;
+        const int w0 = iylo >> 6, w1 = iyhi >> 6;   // at most 2 words: AABB height <= 5.4 m / 0.1 m < 64 rows
+
+        auto drain = [&]() {
+            wave_sync();
+            for (int base = 0; base < qtail; base += 64) {
+                const int e = base + lane;
+                if (e < qtail) {
+                    const uint32_t ent = sQ[e];
+                    const int pl = ent >> 26, ix = (ent >> 13) & 0x1fff, iy = ent & 0x1fff;
+                    if (!sHit[pl]) {
+                        const Footprint* f = (const Footprint*)(sFp + (size_t)pl * CHK_FPW);
+                        if (avp_footprint_point_hit(*f, sX[ix], sY[iy])) sHit[pl] = 1;
+                    }
+                }
+            }
+            qtail = 0;
+            wave_sync();
+        };
+
+        for (int c = 0; c < maxcol; c++) {
+            uint64_t bits0 = 0, bits1 = 0;
+            const int ix = ixlo + c;
+            if (c < ncol && !sHit[lane]) {
+                const uint64_t* col = sBits + (size_t)ix * m.wpc;
+                bits0 = col[w0];
+                // mask rows below iylo and above iyhi
+                bits0 &= ~0ull << (iylo & 63);
+                if (w1 == w0) bits0 &= ~0ull >> (63 - (iyhi & 63));
+                else { bits1 = col[w1] & (~0ull >> (63 - (iyhi & 63))); }
+            }
+            const int cnt = __popcll(bits0) + __popcll(bits1);
+            int total;
+            int off = qtail + wave_prefix_excl(cnt, lane, total);
+            if (total == 0) continue;
+            const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)ix << 13);
+            while (bits0) { const int bpos = __ffsll((unsigned long long)bits0) - 1; bits0 &= bits0 - 1; sQ[off++] = tag | (uint32_t)((w0 << 6) + bpos); }
+            while (bits1) { const int bpos = __ffsll((unsigned long long)bits1) - 1; bits1 &= bits1 - 1; sQ[off++] = tag | (uint32_t)((w1 << 6) + bpos); }
+            qtail += total;
+            if (qtail > CHK_QDRAIN) drain();
+        }
+        drain();
+        if (valid) out[i] = sHit[lane];
+    }
+}
+
+static inline size_t check_distance_lds_bytes(const DevMap& m, bool stage)
+{
+    const size_t perWave = 64 * CHK_FPW + CHK_QCAP / 2 + 8;
+    return ((stage ? (size_t)m.nx * m.wpc + m.nx + m.ny : 0) + CHK_WAVES * perWave) * 8;
+}
+
+// ---- two-circle checker (collision_check.py:88-137): lane per pose, bitmap walk ---------------
+__global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params p, const double* __restrict__ x,
+                                                           const double* __restrict__ y, const double* __restrict__ th,
+                                                           int64_t n, uint8_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double cs = avp_cos(th[i]), sn = avp_sin(th[i]);
+    const double Rd = p.circ_rd;
+    const double fx = x[i] + p.circ_cf * cs, fy = y[i] + p.circ_cf * sn;
+    const double rx = x[i] + p.circ_cr * cs, ry = y[i] + p.circ_cr * sn;
+    double right, left, upper, down;
+    if (fx >= rx) { right = fx + Rd; left = rx - Rd; } else { right = rx + Rd; left = fx - Rd; }
+    if (fy >= ry) { upper = fy + Rd; down = ry - Rd; } else { upper = ry + Rd; down = fy - Rd; }
+    const int ixlo = avp_first_gt(m.X, m.nx, m.b0, m.dx, left), ixhi = avp_last_lt(m.X, m.nx, m.b0, m.dx, right);
+    const int iylo = avp_first_gt(m.Y, m.ny, m.b2, m.dy, down), iyhi = avp_last_lt(m.Y, m.ny, m.b2, m.dy, upper);
+    bool hit = false;
+    if (iylo <= iyhi) {
+        for (int ix = ixlo; ix <= ixhi && !hit; ix++) {
+            const double px = m.X[ix];
+            for (int w = iylo >> 6; w <= (iyhi >> 6) && !hit; w++) {
+                uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+                if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
+                if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
+                while (bits && !hit) {
+                    const int bpos = __ffsll((unsigned long long)bits) - 1;
+                    bits &= bits - 1;
+                    const double py = m.Y[(w << 6) + bpos];
+                    // the reference squares with libm pow(v, 2.0); v*v is its correctly rounded value
+                    const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
+                    if (sqrt(d0x * d0x + d0y * d0y) <= Rd) hit = true;
+                    else if (sqrt(d1x * d1x + d1y * d1y) <= Rd) hit = true;
+                }
+            }
+        }
+    }
+    out[i] = hit ? 1 : 0;
+}
+
+// ---- test hooks -------------------------------------------------------------------------------
+__global__ void trig_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ s, double* __restrict__ c)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { s[i] = avp_sin(x[i]); c[i] = avp_cos(x[i]); }
+}
+__global__ void ieee_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ q,
+                            double* __restrict__ r, double* __restrict__ h)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { q[i] = a[i] / b[i]; r[i] = sqrt(fabs(a[i])); h[i] = avp_hypot(a[i], b[i]); }
+}

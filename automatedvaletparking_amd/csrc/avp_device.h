@@ -1,0 +1,136 @@
+// avp_device.h -- device-side views of the map / parameters and the exact footprint test.
+// Included by every kernel file of libavp_hip.so (single translation unit build).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/avp.h"
+#include "avp_math.h"
+
+// Costmap resident in HBM. Column-major occupancy in two forms:
+//  - obstacle points in np.where(cost_map == 255) order (sorted by ix, then iy): ox/oy + colStart
+//  - per-column bitmaps: colBits[ix*wpc + (iy >> 6)] bit (iy & 63)
+struct DevMap {
+    int32_t nx, ny, S, Sy, P, wpc;
+    double b0, b1, b2, b3, dx, dy;
+    const double* X;          // nx node x coordinates (map_position[0])
+    const double* Y;          // ny
+    const uint8_t* occ;       // nx*ny, 255 = obstacle
+    const double* ox;         // P
+    const double* oy;         // P
+    const int32_t* colStart;  // nx + 1
+    const uint64_t* colBits;  // nx * wpc
+};
+
+// Inflated vehicle rectangle prepared for distance_checker.check (collision_check.py:144-195).
+// 24 doubles = 192 bytes (one LDS record).
+struct Footprint {
+    double cx[4], cy[4];      // rr, rf, lf, lr (map/costmap.py:106-113)
+    double k[4], b[4], den[4];
+    double wthr, lthr;        // v_lb - 0.01, v_length - 0.01
+    double pad0, pad1;
+};
+
+// Footprint corners: world = R(theta).local + (x, y), the 2x2 product rounded the way the
+// reference's BLAS call rounds it: acc = a0*b0; acc = fma(a1, b1, acc)  (numerics).
+AVP_HD void avp_footprint_setup(const avp_params& p, double x, double y, double th, Footprint& f)
+{
+    const double cs = avp_cos(th), sn = avp_sin(th);
+    const double lx[4] = { p.fp_xr, p.fp_xf, p.fp_xf, p.fp_xr };
+    const double ly[4] = { p.fp_yr, p.fp_yr, p.fp_yl, p.fp_yl };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f.cx[i] = AVP_FMA(-sn, ly[i], cs * lx[i]) + x;
+        f.cy[i] = AVP_FMA(cs, ly[i], sn * lx[i]) + y;
+    }
+    double t0 = f.cx[0] - f.cx[3], t1 = f.cy[0] - f.cy[3];
+    f.wthr = sqrt(t0 * t0 + t1 * t1) - 0.01;
+    t0 = f.cx[3] - f.cx[2]; t1 = f.cy[3] - f.cy[2];
+    f.lthr = sqrt(t0 * t0 + t1 * t1) - 0.01;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = (i + 1) & 3;
+        f.k[i] = (f.cy[j] - f.cy[i]) / (f.cx[j] - f.cx[i]);   // +-inf / NaN when axis aligned, as numpy
+        f.b[i] = f.cy[i] - f.k[i] * f.cx[i];
+        f.den[i] = sqrt(1 + f.k[i] * f.k[i]);
+    }
+    f.pad0 = f.pad1 = 0.0;
+}
+
+// AABB of the 4 corners (collision_check.py:49-52)
+AVP_HD void avp_footprint_aabb(const Footprint& f, double& xmin, double& xmax, double& ymin, double& ymax)
+{
+    xmin = xmax = f.cx[0]; ymin = ymax = f.cy[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        if (f.cx[i] > xmax) xmax = f.cx[i];
+        if (f.cx[i] < xmin) xmin = f.cx[i];
+        if (f.cy[i] > ymax) ymax = f.cy[i];
+        if (f.cy[i] < ymin) ymin = f.cy[i];
+    }
+}
+
+// One obstacle point against the rectangle (collision_check.py:197-238): inside test by
+// point-line distances, exact corner test, exact edge-slope test.
+AVP_HD bool avp_footprint_point_hit(const Footprint& f, double px, double py)
+{
+    double d[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = fabs(f.k[i] * px + f.b[i] - py) / f.den[i];
+    const bool c1 = fabs(d[0] - d[2]) < f.wthr;
+    const bool c2 = fabs(d[1] - d[3]) < f.lthr;
+    if (c1 && c2) return true;
+    bool on_x = false, on_y = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { on_x |= (px == f.cx[i]); on_y |= (py == f.cy[i]); }
+    if (on_x && on_y) return true;
+    bool edge = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double k1 = (f.cy[i] - py) / (f.cx[i] - px);
+        edge |= (k1 == f.k[i]);
+    }
+    return edge;
+}
+
+// First node index i with A[i] >= v (A ascending, n entries): exact against the table, any v.
+AVP_HD int avp_first_ge(const double* A, int n, double a0, double pitch, double v)
+{
+    double g = floor((v - a0) / pitch);
+    int i = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);
+    while (i > 0 && A[i - 1] >= v) --i;
+    while (i < n && A[i] < v) ++i;
+    return i;
+}
+// Last node index i with A[i] <= v, or -1.
+AVP_HD int avp_last_le(const double* A, int n, double a0, double pitch, double v)
+{
+    double g = floor((v - a0) / pitch);
+    int i = !(g >= 0.0) ? -1 : (g >= (double)n ? n - 1 : (int)g);
+    while (i + 1 < n && A[i + 1] <= v) ++i;
+    while (i >= 0 && A[i] > v) --i;
+    return i;
+}
+// strict versions for the two-circle checker's exclusive filter (collision_check.py:119-127)
+AVP_HD int avp_first_gt(const double* A, int n, double a0, double pitch, double v)
+{
+    double g = floor((v - a0) / pitch);
+    int i = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);
+    while (i > 0 && A[i - 1] > v) --i;
+    while (i < n && !(A[i] > v)) ++i;
+    return i;
+}
+AVP_HD int avp_last_lt(const double* A, int n, double a0, double pitch, double v)
+{
+    double g = floor((v - a0) / pitch);
+    int i = !(g >= 0.0) ? -1 : (g >= (double)n ? n - 1 : (int)g);
+    while (i + 1 < n && A[i + 1] < v) ++i;
+    while (i >= 0 && !(A[i] < v)) --i;
+    return i;
+}
+
+// map/costmap.py:319-329
+AVP_HD int64_t avp_pos_to_index(const DevMap& m, double gx, double gy)
+{
+    const int64_t c = (int64_t)floor((gx - m.b0) / m.dx);
+    const int64_t r = (int64_t)floor((m.b3 - gy) / m.dy);
+    return c + r * (int64_t)m.S;
+}

@@ -1,0 +1,208 @@
+// avp_math.h -- scalar fp64 maths shared by every kernel of the hybrid-A* hot path.
+//
+// The reference evaluates the bicycle-model expansion and the footprint corners with numpy /
+// CPython floats, i.e. with glibc 2.35 libm on x86-64 (FMA ifunc variant). Closed/open-list
+// membership in the reference is exact float equality (path_plan/hybrid_a_star.py:156,170), so the
+// expansion trig must agree with that libm to the last bit. avp_sin/avp_cos below restate glibc's
+// published algorithm for |x| < 105414350 (IBM Accurate Mathematical Library lineage: 1/128-step
+// double-double table + short polynomials, 3-part pi/2 reduction) with the FMA contractions of the
+// x86-64 FMA build written out explicitly; the table is regenerated from first principles by
+// gen_sincos_table.py. tests/test_math_host.py checks bit equality against this host's libm.
+//
+// Everything here compiles for the device (hipcc, gfx950) and for the host (gcc, used only by
+// the CPU-side unit tests of this header). Build with -ffp-contract=off: every fused operation
+// is spelled AVP_FMA.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define AVP_HD __host__ __device__ __forceinline__
+#define AVP_D __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AVP_TAB_QUAL static __device__ const
+#else
+#define AVP_TAB_QUAL static const
+#endif
+#else
+#define AVP_HD static inline
+#define AVP_D static inline
+#define AVP_TAB_QUAL static const
+#endif
+
+#include "avp_sincos_tab.h"
+
+#define AVP_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define AVP_PI 3.141592653589793
+
+AVP_HD uint64_t avp_d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+AVP_HD double avp_u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+
+// ---- glibc 2.35 s_sin.c restated -------------------------------------------------------------
+namespace avp_trig {
+constexpr double sn3 = -1.66666666666664880952546298448555E-01;
+constexpr double sn5 = 8.33333214285722277379541354343671E-03;
+constexpr double cs2 = 4.99999999999999999999950396842453E-01;
+constexpr double cs4 = -4.16666666666664434524222570944589E-02;
+constexpr double cs6 = 1.38888874007937613028114285595617E-03;
+constexpr double s1 = -0x1.5555555555555p-3;
+constexpr double s2 = 0x1.1111111110ECEp-7;
+constexpr double s3 = -0x1.A01A019DB08B8p-13;
+constexpr double s4 = 0x1.71DE27B9A7ED9p-19;
+constexpr double s5 = -0x1.ADDFFC2FCDF59p-26;
+constexpr double big = 0x1.8p45;
+constexpr double hp0 = 0x1.921fb54442d18p+0;    // pi/2 high
+constexpr double hp1 = 0x1.1a62633145c07p-54;   // pi/2 low
+constexpr double mp1 = 0x1.921FB58000000p+0;    // pi/2 in 27-bit pieces
+constexpr double mp2 = -0x1.dde973c000000p-27;
+constexpr double pp3 = -0x1.cb3b398000000p-55;
+constexpr double pp4 = -0x1.d747f23e32ed7p-83;
+constexpr double hpinv = 0x1.45f306dc9c883p-1;  // 2/pi
+constexpr double toint = 0x1.8p52;
+
+AVP_HD double taylor_sin(double xx, double x, double dx)
+{
+    double p = AVP_FMA(s5, xx, s4);
+    p = AVP_FMA(p, xx, s3);
+    p = AVP_FMA(p, xx, s2);
+    p = AVP_FMA(p, xx, s1);
+    double t = AVP_FMA(p, x, -(0.5 * dx));
+    t = AVP_FMA(t, xx, dx);
+    return x + t;
+}
+
+AVP_HD double do_sin(double x, double dx)
+{
+    const double xold = x;
+    if (fabs(x) < 0.126) return taylor_sin(x * x, x, dx);
+    if (x <= 0) dx = -dx;
+    const double ux = big + fabs(x);
+    const int k = (int)(avp_d2u(ux) & 0xffffffffu);
+    x = fabs(x) - (ux - big);
+    const double xx = x * x;
+    const double s = x + AVP_FMA(x * xx, AVP_FMA(xx, sn5, sn3), dx);
+    const double c = AVP_FMA(x, dx, xx * AVP_FMA(xx, AVP_FMA(xx, cs6, cs4), cs2));
+    const double sn = AVP_SINCOS_TAB[k][0], ssn = AVP_SINCOS_TAB[k][1];
+    const double cs = AVP_SINCOS_TAB[k][2], ccs = AVP_SINCOS_TAB[k][3];
+    const double cor = AVP_FMA(cs, s, AVP_FMA(-sn, c, AVP_FMA(s, ccs, ssn)));
+    return copysign(sn + cor, xold);
+}
+
+AVP_HD double do_cos(double x, double dx)
+{
+    if (x < 0) dx = -dx;
+    const double ux = big + fabs(x);
+    const int k = (int)(avp_d2u(ux) & 0xffffffffu);
+    x = fabs(x) - (ux - big) + dx;
+    const double xx = x * x;
+    const double s = AVP_FMA(x * xx, AVP_FMA(xx, sn5, sn3), x);
+    const double c = xx * AVP_FMA(xx, AVP_FMA(xx, cs6, cs4), cs2);
+    const double sn = AVP_SINCOS_TAB[k][0], ssn = AVP_SINCOS_TAB[k][1];
+    const double cs = AVP_SINCOS_TAB[k][2], ccs = AVP_SINCOS_TAB[k][3];
+    const double cor = AVP_FMA(-sn, s, AVP_FMA(-cs, c, AVP_FMA(-s, ssn, ccs)));
+    return cs + cor;
+}
+
+AVP_HD int reduce_sincos(double x, double* a, double* da)
+{
+    const double t = AVP_FMA(x, hpinv, toint);
+    const double xn = t - toint;
+    const double y = AVP_FMA(-xn, mp2, AVP_FMA(-xn, mp1, x));
+    const int n = (int)(avp_d2u(t) & 3);
+    const double t2 = AVP_FMA(-xn, pp3, y);
+    double db = AVP_FMA(-xn, pp3, (y - t2));
+    const double b = AVP_FMA(-xn, pp4, t2);
+    db += AVP_FMA(-xn, pp4, (t2 - b));
+    *a = b;
+    *da = db;
+    return n;
+}
+
+AVP_HD double do_sincos(double a, double da, int n)
+{
+    const double r = (n & 1) ? do_cos(a, da) : do_sin(a, da);
+    return (n & 2) ? -r : r;
+}
+}  // namespace avp_trig
+
+// sin / cos bit-identical to glibc 2.35 (x86-64 FMA variant) for |x| < 105414350; NaN beyond.
+AVP_HD double avp_sin(double x)
+{
+    using namespace avp_trig;
+    const int32_t k = 0x7fffffff & (int32_t)(avp_d2u(x) >> 32);
+    if (k < 0x3e500000) return x;
+    if (k < 0x3feb6000) return do_sin(x, 0);
+    if (k < 0x400368fd) { const double t = hp0 - fabs(x); return copysign(do_cos(t, hp1), x); }
+    if (k < 0x419921FB) { double a, da; const int n = reduce_sincos(x, &a, &da); return do_sincos(a, da, n); }
+    return NAN;
+}
+
+AVP_HD double avp_cos(double x)
+{
+    using namespace avp_trig;
+    const int32_t k = 0x7fffffff & (int32_t)(avp_d2u(x) >> 32);
+    if (k < 0x3e400000) return 1.0;
+    if (k < 0x3feb6000) return do_cos(x, 0);
+    if (k < 0x400368fd) { const double y = hp0 - fabs(x); const double a = y + hp1; const double da = (y - a) + hp1; return do_sin(a, da); }
+    if (k < 0x419921FB) { double a, da; const int n = reduce_sincos(x, &a, &da); return do_sincos(a, da, n + 1); }
+    return NAN;
+}
+
+// ---- Python float semantics ------------------------------------------------------------------
+// CPython float %: result takes the sign of the divisor (Objects/floatobject.c float_rem)
+AVP_HD double avp_pymod(double vx, double wx)
+{
+    double mod = fmod(vx, wx);
+    if (mod != 0.0) { if ((wx < 0) != (mod < 0)) mod += wx; }
+    else mod = copysign(0.0, wx);
+    return mod;
+}
+
+// path_plan/rs_curve.py:649-656
+AVP_HD double avp_pi_2_pi(double theta)
+{
+    while (theta > AVP_PI) theta -= 2.0 * AVP_PI;
+    while (theta < -AVP_PI) theta += 2.0 * AVP_PI;
+    return theta;
+}
+
+// path_plan/rs_curve.py:669-680
+AVP_HD double avp_M(double theta)
+{
+    double phi = avp_pymod(theta, 2.0 * AVP_PI);
+    if (phi < -AVP_PI) phi += 2.0 * AVP_PI;
+    if (phi > AVP_PI) phi -= 2.0 * AVP_PI;
+    return phi;
+}
+
+// CPython 3.10 math.hypot(a, b) (Modules/mathmodule.c vector_norm, n = 2): scaled, split-accumulated
+// sum of squares with one differential correction. Pure IEEE arithmetic, no libm dependence.
+AVP_HD double avp_hypot(double a, double b)
+{
+    const double T27 = 134217729.0;
+    double v0 = fabs(a), v1 = fabs(b);
+    double mx = v0 > v1 ? v0 : v1;
+    if (isinf(v0) || isinf(v1)) return INFINITY;
+    if (v0 != v0 || v1 != v1) return NAN;
+    if (mx == 0.0) return mx;
+    int max_e;
+    (void)frexp(mx, &max_e);
+    if (max_e < -1023) return sqrt(a * a + b * b);
+    const double scale = ldexp(1.0, -max_e);
+    double csum = 1.0, frac1 = 0.0, frac2 = 0.0, frac3 = 0.0, x, t, hi, lo, oldcsum;
+    for (int i = 0; i < 2; i++) {
+        x = (i == 0 ? v0 : v1) * scale;
+        t = x * T27; hi = t - (t - x); lo = x - hi;
+        x = hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
+        x = 2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
+        frac3 += lo * lo;
+    }
+    const double h = sqrt(csum - 1.0 + (frac1 + frac2 + frac3));
+    x = h; t = x * T27; hi = t - (t - x); lo = x - hi;
+    x = -hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
+    x = -2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
+    x = -lo * lo; oldcsum = csum; csum += x; frac3 += (oldcsum - csum) + x;
+    x = csum - 1.0 + (frac1 + frac2 + frac3);
+    return (h + x / (2.0 * h)) / scale;
+}

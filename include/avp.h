@@ -1,0 +1,114 @@
+/*
+ * avp.h -- C-ABI of libavp_hip.so, the MI355X-native hybrid-A* hot path.
+ *
+ * The reference (wenqing-2021/AutomatedValetParking) is pure Python and has no FFI; the boundary
+ * is its class API. Each entry point below replaces the reference
+ * interface cited next to it; automatedvaletparking_amd/ binds them with ctypes and re-exposes
+ * the reference's own classes (PathPlanner, distance_checker, two_circle_checker, rs_curve.PATH,
+ * costmap.Map/Vehicle/Case). INTEGRATION.md shows the binding a maintainer of the reference adds.
+ *
+ * Conventions: every function returns int32 status (0 = OK, < 0 = error, text via avp_last_error);
+ * no exception crosses; the caller owns every buffer; pointers documented "device" are raw HIP
+ * device pointers (e.g. torch.Tensor.data_ptr()); launches are asynchronous on the handle's stream
+ * (avp_map_set_stream, default = the NULL stream) unless noted. A handle is not thread-safe;
+ * distinct handles are independent. All arithmetic is IEEE fp64, ids/distances are integers.
+ */
+#ifndef AVP_H
+#define AVP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVP_VERSION 100
+#define AVP_MAX_STEER 16
+#define AVP_RS_MAXSEG 5
+
+/* status codes of the library calls */
+enum {
+    AVP_OK = 0,
+    AVP_ERR_ARG = -1,       /* bad argument                                   */
+    AVP_ERR_HIP = -2,       /* HIP runtime error (text in avp_last_error)     */
+    AVP_ERR_NOGPU = -3,     /* no usable gfx950 device                         */
+    AVP_ERR_CAPACITY = -4   /* a caller-provided buffer is too small           */
+};
+
+/* per-problem status written by avp_plan_batch (the reference signals these by exceptions/hangs) */
+enum {
+    AVP_PLAN_OK = 0,            /* goal reached by a collision-free Reeds-Shepp shot            */
+    AVP_PLAN_NO_PATH = 1,       /* open list exhausted: AttributeError at path_planner.py:104   */
+    AVP_PLAN_H_UNREACHABLE = 2, /* heuristic query unreachable: the reference blocks forever in
+                                   PriorityQueue.get(), compute_h.py:77                          */
+    AVP_PLAN_RS_ERROR = 3,      /* start == goal: AssertionError rs_curve.py:153                */
+    AVP_PLAN_ITER_LIMIT = 4,    /* params.max_pops reached (the reference has no cap)           */
+    AVP_PLAN_CAPACITY = 5       /* node arena / path buffer exhausted                           */
+};
+
+/*
+ * Planner parameters: the hot-path keys of config/config.yaml + Vehicle constants
+ * (map/costmap.py:52-63), with every per-config constant that the reference computes through
+ * numpy/libm evaluated ON THE HOST in the reference's expression order and passed in, so that the
+ * device never has to reproduce numpy's tan / pow (hard part 1).
+ */
+typedef struct avp_params {
+    /* vehicle */
+    double lw, lf, lr, lb, max_v, max_steer, min_radius;
+    /* inflated footprint in the vehicle frame: rear/front x, right/left y (map/costmap.py:97-101) */
+    double fp_xr, fp_xf, fp_yr, fp_yl;
+    /* two-circle model (collision_check.py:92-98): radius, front/rear centre offsets */
+    double circ_rd, circ_cf, circ_cr;
+    /* hybrid A* (hybrid_a_star.py:81-83,145-151,188-194) */
+    int32_t n_steer;
+    int32_t n_sub;                       /* ceil(dt / trajectory_dt)                                */
+    double steer[AVP_MAX_STEER];         /* np.linspace(-max_steer, max_steer, n)                   */
+    double dth_dt[AVP_MAX_STEER];        /* (max_v*np.tan(steer))/lw*dt                             */
+    double dth_ddt[AVP_MAX_STEER][4];    /* (max_v*np.tan(steer))/lw*ddt*(j+1), j < n_sub <= 4      */
+    double travel_dt;                    /* max_v*dt (sign applied per gear)                        */
+    double travel_ddt[4];                /* max_v*ddt*(j+1)                                         */
+    double flag_radius;
+    double cost_gear, cost_heading, cost_scale;
+    double maxc;                         /* 1 / min_radius                                          */
+    int32_t extended_num;
+    int32_t checker_kind;                /* 0 = distance_checker, 1 = two_circle_checker            */
+    int64_t max_pops;                    /* per-problem pop cap, 0 = library default                */
+} avp_params;
+
+typedef struct avp_map avp_map;          /* opaque: one costmap resident in HBM + its stream        */
+
+int32_t avp_version(void);
+int32_t avp_sizeof_params(void);            /* sizeof(avp_params): binding self-check */
+int32_t avp_last_error(char* buf, int32_t n);
+
+/*
+ * Replaces: Map (map/costmap.py:159-195) as consumed by the checkers and the heuristic.
+ * Host pointers; copied to the device once. occ: nx*ny bytes, [ix*ny + iy], 255 = obstacle edge
+ * cell (cost_map == 255). xs/ys: map_position. boundary[4] = Map.boundary. obs_ix/obs_iy: the P
+ * obstacle cells in np.where(cost_map == 255) order (row-major). device = HIP ordinal.
+ */
+int32_t avp_map_create(const avp_params* params, const uint8_t* occ, int32_t nx, int32_t ny,
+                       const double* xs, const double* ys, const double boundary[4],
+                       const int32_t* obs_ix, const int32_t* obs_iy, int32_t P,
+                       int32_t device, avp_map** out);
+int32_t avp_map_destroy(avp_map* map);
+int32_t avp_map_set_stream(avp_map* map, void* hip_stream);
+int32_t avp_sync(avp_map* map);
+
+/*
+ * Replaces: distance_checker.check / two_circle_checker.check (collision_check.py:144-240, 88-137),
+ * one call per pose in the reference. x, y, th, out: device, n elements; out[i] in {0,1}.
+ * kind: 0 distance, 1 circle. variant: 0 = production kernel, 1 = straightforward all-points kernel
+ * (kept for cross-checking the production kernel on the GPU).
+ */
+int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, const double* y, const double* th,
+                        int64_t n, uint8_t* out, int32_t variant);
+
+/* Device evaluation of the shared scalar maths (test hook): out_sin/out_cos = avp_sin/avp_cos(x). */
+int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos);
+/* Device IEEE check hook: q = a / b, r = sqrt(|a|), h = hypot(a, b) as the kernels compute them. */
+int32_t avp_ieee_batch(avp_map* map, const double* a, const double* b, int64_t n, double* q, double* r, double* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVP_H */

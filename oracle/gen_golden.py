@@ -237,7 +237,7 @@ def save(name, d):
 
 
 # ----------------------------------------------------------------------------------------------
-def gen_micro():
+def gen_micro(groups=(1, 2, 3, 4)):
     cfg = config()
     veh = ref_costmap.Vehicle()
     rng = np.random.default_rng(20260927)
@@ -253,7 +253,17 @@ def gen_micro():
         g1[f"c{k}_obs_xy"] = np.concatenate(m.case.obs, 0)
     g1["vehicle"] = np.array([veh.lw, veh.lf, veh.lr, veh.lb, veh.max_steering_angle, veh.max_v, veh.min_radius_turn])
     g1["steer_tan"] = np.tan(np.linspace(-veh.max_steering_angle, veh.max_steering_angle, cfg["steering_angle_num"]))
-    save("g1_costmaps.npz", g1)
+    if 1 in groups:
+        save("g1_costmaps.npz", g1)
+    if 2 in groups:
+        gen_micro_g2(maps, rng)
+    if 3 in groups:
+        gen_micro_g3(maps, rng, cfg, veh)
+    if 4 in groups:
+        gen_micro_g4(np.random.default_rng(44), veh)
+
+
+def gen_micro_g2(maps, rng):
 
     # G2: index maths on 3 cases
     g2 = {}
@@ -271,6 +281,8 @@ def gen_micro():
         g2.update({f"c{k}_x": xs, f"c{k}_y": ys, f"c{k}_id": ids, f"c{k}_xo": xo, f"c{k}_yo": yo, f"c{k}_obst": ob})
     save("g2_index.npz", g2)
 
+
+def gen_micro_g3(maps, rng, cfg, veh):
     # G3: collision booleans
     g3 = {}
     for k in (1, 4, 5, 13, 19, 20):
@@ -307,6 +319,8 @@ def gen_micro():
     g3["corners"] = np.array([veh.create_anticlockpoint(x, y, t, cfg).reshape(5, 2) for x, y, t in pp])
     save("g3_collision.npz", g3)
 
+
+def gen_micro_g4(rng, veh):
     # G4: Reeds-Shepp
     maxc = 1 / veh.min_radius_turn
     n = 20000
@@ -314,7 +328,7 @@ def gen_micro():
     q1 = np.stack([rng.uniform(-25, 25, n), rng.uniform(-25, 25, n), rng.uniform(-np.pi, np.pi, n)], 1)
     # structured: close poses (short paths, many CCC/CCCC winners)
     q1[n // 2:, :2] = q0[n // 2:, :2] + rng.uniform(-6, 6, (n - n // 2, 2))
-    MAXP = 96
+    MAXP = 320
     L = np.zeros(n)
     types = np.full((n, 5), -1, np.int8)
     lens = np.zeros((n, 5))
@@ -464,7 +478,7 @@ def gen_synth():
 if __name__ == "__main__":
     what = sys.argv[1]
     if what == "micro":
-        gen_micro()
+        gen_micro(tuple(int(a) for a in sys.argv[2:]) or (1, 2, 3, 4))
     elif what == "hfield":
         gen_hfield(tuple(int(a) for a in sys.argv[2:]) or (1, 4))
     elif what == "trace":

@@ -1,0 +1,104 @@
+"""HIP footprint-collision kernels vs the CPU oracle and the reference's golden vectors (bit exact)."""
+import numpy as np
+import pytest
+
+from conftest import gold, case_map_from_gold
+
+pytestmark = pytest.mark.gpu
+
+
+def _dm(m, vehicle, cfg):
+    from automatedvaletparking_amd import _native
+    return _native.DeviceMap(m, vehicle, cfg)
+
+
+def test_device_trig_bit_equal_host_libm(vehicle, cfg):
+    import ctypes as C
+    from automatedvaletparking_amd import _native
+    dm = _dm(case_map_from_gold(1), vehicle, cfg)
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-np.pi, np.pi, 2_000_000), rng.uniform(-50, 50, 500_000), rng.uniform(-1e8, 1e8, 100_000),
+                         np.linspace(-np.pi, np.pi, 200_001), np.array([0.0, -0.0, np.pi, -np.pi, 0.85546875, 2.426265])])
+    x = dm.dev_tensor(xs)
+    s = dm.empty(len(xs), dm.torch.float64)
+    c = dm.empty(len(xs), dm.torch.float64)
+    _native.chk(_native.lib().avp_trig_batch(dm.h, C.c_void_p(x.data_ptr()), C.c_int64(len(xs)), C.c_void_p(s.data_ptr()), C.c_void_p(c.data_ptr())))
+    assert np.array_equal(s.cpu().numpy(), np.sin(xs))
+    assert np.array_equal(c.cpu().numpy(), np.cos(xs))
+
+
+def test_device_div_sqrt_hypot_ieee(vehicle, cfg):
+    import ctypes as C
+    import math
+    from automatedvaletparking_amd import _native
+    dm = _dm(case_map_from_gold(1), vehicle, cfg)
+    rng = np.random.default_rng(12)
+    n = 1_000_000
+    a = rng.uniform(-100, 100, n) * 10.0 ** rng.integers(-8, 8, n)
+    b = rng.uniform(-100, 100, n) * 10.0 ** rng.integers(-8, 8, n)
+    a[:4] = [1.0, 0.0, -1.0, 5.0]
+    b[:4] = [0.0, 0.0, 0.0, -0.0]
+    ta, tb = dm.dev_tensor(a), dm.dev_tensor(b)
+    q, r, h = [dm.empty(n, dm.torch.float64) for _ in range(3)]
+    _native.chk(_native.lib().avp_ieee_batch(dm.h, C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()), C.c_int64(n),
+                                             C.c_void_p(q.data_ptr()), C.c_void_p(r.data_ptr()), C.c_void_p(h.data_ptr())))
+    with np.errstate(all="ignore"):
+        assert np.array_equal(q.cpu().numpy(), a / b, equal_nan=True)
+        assert np.array_equal(r.cpu().numpy(), np.sqrt(np.abs(a)))
+    hh = h.cpu().numpy()
+    sub = slice(0, 200_000)
+    assert np.array_equal(hh[sub], np.array([math.hypot(x, y) for x, y in zip(a[sub], b[sub])]))
+
+
+@pytest.mark.parametrize("k", [1, 4, 5, 13, 19, 20])
+def test_golden_collision_vectors(k, vehicle, cfg):
+    g3 = gold("g3_collision.npz")
+    dm = _dm(case_map_from_gold(k), vehicle, cfg)
+    poses = g3[f"c{k}_poses"]
+    assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), g3[f"c{k}_dist"])
+    assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), g3[f"c{k}_dist"])
+    assert np.array_equal(dm.check_batch(poses, kind=1), g3[f"c{k}_circ"])
+
+
+@pytest.mark.parametrize("k", [1, 19])
+def test_random_poses_vs_oracle(k, vehicle, cfg):
+    from oracle import oracle
+    m = case_map_from_gold(k)
+    dm = _dm(m, vehicle, cfg)
+    o = oracle.Oracle(m, vehicle, cfg)
+    rng = np.random.default_rng(100 + k)
+    b = m.boundary
+    n = 200_000 if k == 1 else 60_000
+    poses = np.stack([rng.uniform(b[0] - 1, b[1] + 1, n), rng.uniform(b[2] - 1, b[3] + 1, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    poses[:2000, 2] = rng.choice([0.0, np.pi / 2, -np.pi / 2, np.pi, -np.pi], 2000)      # axis aligned: inf / NaN lines
+    want = o.check_batch(poses, kind=0)
+    assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), want)
+    assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), want)
+    assert np.array_equal(dm.check_batch(poses, kind=1), o.check_batch(poses, kind=1))
+
+
+def test_edge_inputs(vehicle, cfg):
+    m = case_map_from_gold(1)
+    dm = _dm(m, vehicle, cfg)
+    assert len(dm.check_batch(np.zeros((0, 3)))) == 0
+    odd = np.array([[np.nan, 0.0, 0.0], [0.0, np.inf, 0.0], [1e9, 1e9, 0.3], [m.boundary[0], m.boundary[2], 0.1]])
+    from oracle import oracle
+    o = oracle.Oracle(m, vehicle, cfg)
+    for n in (1, 63, 64, 65, 257):
+        p = np.resize(odd, (n, 3))
+        assert np.array_equal(dm.check_batch(p, kind=0), o.check_batch(p, kind=0))
+
+
+def test_reference_class_api(vehicle, cfg):
+    from automatedvaletparking_amd import collision_check
+    g3 = gold("g3_collision.npz")
+    m = case_map_from_gold(1)
+    dc = collision_check.distance_checker(map=m, vehicle=vehicle, config=cfg)
+    tc = collision_check.two_circle_checker(map=m, vehicle=vehicle, config=cfg)
+    poses = g3["c1_poses"]
+    for i in range(0, 40):
+        x, y, t = poses[i]
+        assert dc.check(node_x=x, node_y=y, theta=t) == bool(g3["c1_dist"][i])
+        assert tc.check(x, y, t) == bool(g3["c1_circ"][i])
+        near, vb = dc.get_near_obstacles(x, y, t)
+        assert len(near[0]) == int(g3["c1_near"][i]) and vb.shape == (5, 2, 1)
