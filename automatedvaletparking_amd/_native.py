@@ -20,7 +20,8 @@ AVP_MAX_STEER = 16
 
 EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
-    "avp_check_batch", "avp_trig_batch", "avp_ieee_batch",
+    "avp_check_batch", "avp_trig_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
+    "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch",
 ]
 
 
@@ -184,6 +185,29 @@ class DeviceMap:
         soa = self.dev_tensor(poses.T.copy())
         out = self.check_batch_dev(soa[0], soa[1], soa[2], kind=kind, variant=variant)
         return out.cpu().numpy()
+
+    # ---- Reeds-Shepp ---------------------------------------------------------------------------
+    def rs_optimal_batch(self, q0, q1, maxc=None, maxpts: int = 128) -> dict:
+        torch = self.torch
+        q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(-1, 3)
+        q1 = np.ascontiguousarray(q1, dtype=np.float64).reshape(-1, 3)
+        n = len(q0)
+        maxc = float(self.params.maxc if maxc is None else maxc)
+        t0, t1 = self.dev_tensor(q0), self.dev_tensor(q1)
+        st = self.empty(n, torch.int32)
+        L = self.empty(n, torch.float64)
+        ty = self.empty((n, 5), torch.int8)
+        le = self.empty((n, 5), torch.float64)
+        npts = self.empty(n, torch.int32)
+        pts = self.zeros((n, max(maxpts, 1), 3), torch.float64)
+        dr = self.zeros((n, max(maxpts, 1)), torch.int8)
+        chk(lib().avp_rs_optimal_batch(self.h, C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()), C.c_double(maxc),
+                                       C.c_int64(n), C.c_int32(maxpts), C.c_void_p(st.data_ptr()), C.c_void_p(L.data_ptr()),
+                                       C.c_void_p(ty.data_ptr()), C.c_void_p(le.data_ptr()), C.c_void_p(npts.data_ptr()),
+                                       C.c_void_p(pts.data_ptr()) if maxpts > 0 else None,
+                                       C.c_void_p(dr.data_ptr()) if maxpts > 0 else None), "avp_rs_optimal_batch")
+        return dict(status=st.cpu().numpy(), L=L.cpu().numpy(), types=ty.cpu().numpy(), lens=le.cpu().numpy(),
+                    npts=npts.cpu().numpy(), pts=pts.cpu().numpy(), dirs=dr.cpu().numpy())
 
     def __del__(self):
         try:

@@ -1,1 +1,749 @@
+// avp_plan_kernels.h -- batched hybrid-A* planner: one workgroup = one (start, goal) problem,
+// persistent workgroups pull problems from a global counter.
+//
+// Replaces, per problem, PathPlanner.a_star_plan (path_plan/path_planner.py:58-110) with
+// hybrid_a_star.{__init__, expand_node, calc_node_cost, calc_node_heuristic, try_reach_goal,
+// try_rs_curve, finish_path} (path_plan/hybrid_a_star.py:72-389) and the Dijkstra heuristic
+// (path_plan/compute_h.py). The pop order (heap layout, ties, in-place key updates) follows
+// CPython's heapq exactly; closed/open membership is exact fp64 equality through a hash table.
+//
+// Heuristic field ("holonomic with obstacles"): the reference runs a resumable 8-connected integer
+// Dijkstra (10/14) from the goal over the goal-anchored lattice, keyed by the aliasing grid id of
+// map/costmap.py:319-329, stopping at every queried cell and never expanding the cells it stopped
+// at. Here the same field is produced by a workgroup-parallel bucketed sweep (buckets of 10 cost
+// units = the minimum edge weight, so a whole bucket is final at once), extended lazily by each
+// query that misses, with the reference's two order-dependent effects reproduced exactly:
+//   * terminator cells (queries that were not yet closed) are flagged and never relax neighbours;
+//   * hit/miss of a query is decided against the key (distance, id) of the last miss, which is the
+//     reference's closed set, so the set of terminators is the same;
+//   * ids alias between the last map column and the first column of the next row; the owner of an
+//     aliased id (the lattice cell whose position is stored in the reference's Grid) is the first
+//     discoverer in (distance, id, neighbour) order, resolved with a 64-bit atomicMin key.
+// See DESIGN.md for the equivalence argument and the measured agreement with the heapq-exact oracle.
 #pragma once
+#include "avp_device.h"
+#include "avp_rs_kernels.h"
+
+#define PL_THREADS 256
+#define PL_QCAP 32768                 // entries per rotating bucket queue
+#define PL_NQ 4                       // rotating bucket queues
+#define PL_MAXCHILD 32
+#define PL_RSQ 10                     // RS queries evaluated per pass (46 words each)
+#define PL_RS_CAP 1024                // samples of one RS shot
+#define PL_UNSEEN 0x7fffffffu
+#define PL_TRACE_W 11
+#define PL_FLAG_T 1
+
+struct PlNode {
+    double x, y, th, g, h, f;
+    int32_t index, parent_index, parent_pos, heap_pos;
+    int8_t forward, steer_i, state, pad0;   // state: 1 open, 2 closed, 3 popped (being expanded)
+    int32_t pad1;
+};
+
+struct avp_plan_result_dev {          // mirrors avp_plan_result in include/avp.h
+    int32_t status, n_pops, n_astar, n_rs_pts, n_final, rs_n, in_radius_last, rs_collision;
+    int64_t n_checks, n_rs, n_closed, n_open, h_cells, h_misses, global_index, n_nodes;
+    int8_t rs_types[8];
+    double rs_lengths[5];
+    double rs_L;
+    double rs_start[3];               // RS sample 0 (the popped node's pose)
+    int32_t rs_dir0, pad;
+};
+
+struct PlanWs {                       // per-slot workspace carve (device pointers)
+    uint32_t* dist;                   // [idCap]
+    uint8_t* flags;                   // [idCap]
+    unsigned long long* aliasKey;     // [rowCap]
+    unsigned long long* queue;        // [PL_NQ][PL_QCAP]  (dist << 32 | id)
+    PlNode* nodes;                    // [maxNodes]
+    uint32_t* heap;                   // [maxNodes]
+    uint32_t* hash;                   // [hashCap] node position + 1, 0 = empty
+    double* rsbuf;                    // [PL_RS_CAP * 3]
+    int8_t* rsdir;                    // [PL_RS_CAP]
+};
+
+struct PlanDims { int64_t idCap, rowCap, maxNodes, hashCap; size_t bytes; };
+
+static inline __host__ __device__ size_t pl_al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static inline __host__ __device__ PlanDims plan_dims(int32_t S, int32_t Sy, int32_t maxNodes)
+{
+    PlanDims d;
+    d.idCap = (int64_t)S * (Sy + 3) + 16;
+    d.rowCap = Sy + 4;
+    d.maxNodes = maxNodes;
+    int64_t h = 1;
+    while (h < 2 * (int64_t)maxNodes) h <<= 1;
+    d.hashCap = h;
+    size_t b = 0;
+    b += pl_al((size_t)d.idCap * 4);
+    b += pl_al((size_t)d.idCap);
+    b += pl_al((size_t)d.rowCap * 8);
+    b += pl_al((size_t)PL_NQ * PL_QCAP * 8);
+    b += pl_al((size_t)maxNodes * sizeof(PlNode));
+    b += pl_al((size_t)maxNodes * 4);
+    b += pl_al((size_t)d.hashCap * 4);
+    b += pl_al((size_t)PL_RS_CAP * 3 * 8);
+    b += pl_al((size_t)PL_RS_CAP);
+    d.bytes = b;
+    return d;
+}
+
+static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
+{
+    PlanWs w;
+    size_t o = 0;
+    w.dist = (uint32_t*)(base + o); o += pl_al((size_t)d.idCap * 4);
+    w.flags = (uint8_t*)(base + o); o += pl_al((size_t)d.idCap);
+    w.aliasKey = (unsigned long long*)(base + o); o += pl_al((size_t)d.rowCap * 8);
+    w.queue = (unsigned long long*)(base + o); o += pl_al((size_t)PL_NQ * PL_QCAP * 8);
+    w.nodes = (PlNode*)(base + o); o += pl_al((size_t)d.maxNodes * sizeof(PlNode));
+    w.heap = (uint32_t*)(base + o); o += pl_al((size_t)d.maxNodes * 4);
+    w.hash = (uint32_t*)(base + o); o += pl_al((size_t)d.hashCap * 4);
+    w.rsbuf = (double*)(base + o); o += pl_al((size_t)PL_RS_CAP * 3 * 8);
+    w.rsdir = (int8_t*)(base + o);
+    return w;
+}
+
+// ---- lane-per-pose collision test through the column bitmaps (reads L1/L2-resident tables) -----
+__device__ __noinline__ bool pl_check_pose(const DevMap& m, const avp_params& p, double x, double y, double th)
+{
+    if (p.checker_kind == 1) {
+        const double cs = avp_cos(th), sn = avp_sin(th);
+        const double Rd = p.circ_rd;
+        const double fx = x + p.circ_cf * cs, fy = y + p.circ_cf * sn;
+        const double rx = x + p.circ_cr * cs, ry = y + p.circ_cr * sn;
+        double right, left, upper, down;
+        if (fx >= rx) { right = fx + Rd; left = rx - Rd; } else { right = rx + Rd; left = fx - Rd; }
+        if (fy >= ry) { upper = fy + Rd; down = ry - Rd; } else { upper = ry + Rd; down = fy - Rd; }
+        const int ixlo = avp_first_gt(m.X, m.nx, m.b0, m.dx, left), ixhi = avp_last_lt(m.X, m.nx, m.b0, m.dx, right);
+        const int iylo = avp_first_gt(m.Y, m.ny, m.b2, m.dy, down), iyhi = avp_last_lt(m.Y, m.ny, m.b2, m.dy, upper);
+        if (iylo > iyhi) return false;
+        for (int ix = ixlo; ix <= ixhi; ix++) {
+            const double px = m.X[ix];
+            for (int w = iylo >> 6; w <= (iyhi >> 6); w++) {
+                uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+                if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
+                if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
+                while (bits) {
+                    const int bpos = __ffsll((unsigned long long)bits) - 1;
+                    bits &= bits - 1;
+                    const double py = m.Y[(w << 6) + bpos];
+                    const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
+                    if (sqrt(d0x * d0x + d0y * d0y) <= Rd) return true;
+                    if (sqrt(d1x * d1x + d1y * d1y) <= Rd) return true;
+                }
+            }
+        }
+        return false;
+    }
+    Footprint f;
+    avp_footprint_setup(p, x, y, th, f);
+    double xmin, xmax, ymin, ymax;
+    avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
+    const int ixlo = avp_first_ge(m.X, m.nx, m.b0, m.dx, xmin), ixhi = avp_last_le(m.X, m.nx, m.b0, m.dx, xmax);
+    const int iylo = avp_first_ge(m.Y, m.ny, m.b2, m.dy, ymin), iyhi = avp_last_le(m.Y, m.ny, m.b2, m.dy, ymax);
+    if (iylo > iyhi) return false;
+    for (int ix = ixlo; ix <= ixhi; ix++) {
+        const double px = m.X[ix];
+        for (int w = iylo >> 6; w <= (iyhi >> 6); w++) {
+            uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+            if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
+            if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
+            while (bits) {
+                const int bpos = __ffsll((unsigned long long)bits) - 1;
+                bits &= bits - 1;
+                if (avp_footprint_point_hit(f, px, m.Y[(w << 6) + bpos])) return true;
+            }
+        }
+    }
+    return false;
+}
+
+// ---- shared (LDS) state of one problem ----------------------------------------------------------
+struct PlChild {
+    double x, y, th;                  // child pose
+    double L;                         // RS length to the goal [m]
+    int64_t id;                       // grid id of (x, y)
+    int32_t found;                    // node position of an equal open/closed node, -1 none
+    int32_t first_coll;               // first colliding sub-step, -1 none
+    int8_t found_state, oob, rs_err, pad;
+};
+
+struct PlShared {
+    // lattice / id space (compute_h.py lattice anchored at the goal)
+    int32_t col0, row0, colMin, colMax, rowMin, rowMax, orow0, alias;   // alias: a lattice column has col == S
+    int64_t goal_id;
+    int32_t regular;
+    // sweep
+    int32_t E;                        // buckets [0, E) are expanded
+    uint32_t qcount[PL_NQ];
+    int32_t qover;
+    uint32_t dF; int64_t idF;         // key of the last miss (closed frontier), dF = 0xffffffff before the first
+    int32_t hasF;
+    int64_t h_cells, h_misses;
+    // A*
+    int32_t nnodes, nheap, nclosed, closed_nonempty;
+    int64_t global_index;
+    int32_t cur;                      // node position being expanded
+    int32_t status, done;
+    double goal[3];
+    int32_t pid;
+    // per pop scratch
+    int32_t rs_status, rs_npts, rs_first_coll, in_radius, collision;
+    RsPath rs;                        // normalised winner of the shot
+    int64_t n_checks, n_rs;
+    uint32_t hq_d;                    // result of the collective query
+    int32_t hq_flag;
+    PlChild child[PL_MAXCHILD];
+    // RS word results: [query][word] ok + 5 lengths
+    uint8_t w_ok[PL_RSQ * 46];
+    double w_l[PL_RSQ * 46][5];
+};
+
+AVP_D int32_t pl_bucket(uint32_t d) { return (int32_t)(d / 10u); }
+
+AVP_D uint64_t pl_mix(uint64_t z) { z ^= z >> 33; z *= 0xff51afd7ed558ccdULL; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL; z ^= z >> 33; return z; }
+AVP_D uint64_t pl_pose_hash(double x, double y, double th)
+{
+    const double zx = x == 0.0 ? 0.0 : x, zy = y == 0.0 ? 0.0 : y, zt = th == 0.0 ? 0.0 : th;
+    return pl_mix(avp_d2u(zx) * 0x9E3779B97F4A7C15ULL ^ pl_mix(avp_d2u(zy) + 0x632BE59BD9B4E019ULL) ^ pl_mix(avp_d2u(zt) * 3));
+}
+// exact-equality lookup (hybrid_a_star.py:156,170); returns node position or -1
+AVP_D int32_t pl_hash_find(const PlanWs& w, int64_t hashCap, double x, double y, double th)
+{
+    if (x != x || y != y || th != th) return -1;
+    uint64_t h = pl_pose_hash(x, y, th) & (uint64_t)(hashCap - 1);
+    for (;;) {
+        const uint32_t v = w.hash[h];
+        if (v == 0) return -1;
+        const PlNode& n = w.nodes[v - 1];
+        if (n.x == x && n.y == y && n.th == th) return (int32_t)(v - 1);
+        h = (h + 1) & (uint64_t)(hashCap - 1);
+    }
+}
+AVP_D void pl_hash_put(const PlanWs& w, int64_t hashCap, int32_t pos)
+{
+    const PlNode& n = w.nodes[pos];
+    if (n.x != n.x || n.y != n.y || n.th != n.th) return;
+    uint64_t h = pl_pose_hash(n.x, n.y, n.th) & (uint64_t)(hashCap - 1);
+    while (w.hash[h] != 0) h = (h + 1) & (uint64_t)(hashCap - 1);
+    w.hash[h] = (uint32_t)pos + 1;
+}
+
+// ---- CPython heapq on node positions, key = node.f (Node.__lt__ hybrid_a_star.py:61-68) ---------
+AVP_D void pl_heap_set(const PlanWs& w, int32_t pos, uint32_t node) { w.heap[pos] = node; w.nodes[node].heap_pos = pos; }
+AVP_D void pl_siftdown(const PlanWs& w, int32_t startpos, int32_t pos)
+{
+    const uint32_t newitem = w.heap[pos];
+    const double nf = w.nodes[newitem].f;
+    while (pos > startpos) {
+        const int32_t parentpos = (pos - 1) >> 1;
+        const uint32_t parent = w.heap[parentpos];
+        if (nf < w.nodes[parent].f) { pl_heap_set(w, pos, parent); pos = parentpos; continue; }
+        break;
+    }
+    pl_heap_set(w, pos, newitem);
+}
+AVP_D void pl_siftup(const PlanWs& w, int32_t pos, int32_t endpos)
+{
+    const int32_t startpos = pos;
+    const uint32_t newitem = w.heap[pos];
+    int32_t childpos = 2 * pos + 1;
+    while (childpos < endpos) {
+        const int32_t rightpos = childpos + 1;
+        if (rightpos < endpos && !(w.nodes[w.heap[childpos]].f < w.nodes[w.heap[rightpos]].f)) childpos = rightpos;
+        pl_heap_set(w, pos, w.heap[childpos]);
+        pos = childpos;
+        childpos = 2 * pos + 1;
+    }
+    pl_heap_set(w, pos, newitem);
+    pl_siftdown(w, startpos, pos);
+}
+AVP_D void pl_heap_push(const PlanWs& w, PlShared& s, uint32_t node)
+{
+    w.heap[s.nheap] = node;
+    s.nheap++;
+    pl_siftdown(w, 0, s.nheap - 1);
+}
+AVP_D uint32_t pl_heap_pop(const PlanWs& w, PlShared& s)
+{
+    const uint32_t lastelt = w.heap[--s.nheap];
+    if (s.nheap) {
+        const uint32_t ret = w.heap[0];
+        w.heap[0] = lastelt;
+        pl_siftup(w, 0, s.nheap);
+        return ret;
+    }
+    return lastelt;
+}
+
+// ---- heuristic sweep ---------------------------------------------------------------------------
+// Relax lattice cell (col, row) with new distance nd, discovered from (srcDist, srcId) via
+// neighbour slot nbr (compute_h.py:216-235 add_grid_to_openlist).
+AVP_D void pl_relax(const DevMap& m, const PlanWs& w, PlShared& s, int col, int row, uint32_t nd, uint32_t srcDist,
+                    int64_t srcId, int nbr)
+{
+    if (col < s.colMin || col > s.colMax || row < s.rowMin || row > s.rowMax) return;   // one-sided bounds tests :95-191
+    // is_obstacle (compute_h.py:237-255): cell (ix-1, iy-1) with Python negative-index wrap
+    int ox = col - 1;
+    if (ox >= m.S) ox = m.S - 1;
+    if (ox < 0) ox += m.nx;
+    int oy = s.orow0 + (s.row0 - row);
+    if (oy >= m.Sy) oy = m.Sy - 1;
+    if (oy < 0) oy += m.ny;
+    if (m.occ[(size_t)ox * m.ny + oy] == 255) return;
+    const int64_t nid = (int64_t)col + (int64_t)row * m.S;
+    if (s.alias && (col == 0 || col == m.S)) {
+        const int slot = col == 0 ? row : row + 1;
+        const unsigned long long key = ((unsigned long long)srcDist << 44) | ((unsigned long long)srcId << 8) |
+                                       ((unsigned long long)nbr << 1) | (col == 0 ? 0ull : 1ull);
+        atomicMin(&w.aliasKey[slot], key);
+    }
+    const uint32_t old = atomicMin(&w.dist[nid], nd);
+    if (nd < old) {
+        const int q = pl_bucket(nd) & (PL_NQ - 1);
+        const uint32_t pos = atomicAdd(&s.qcount[q], 1u);
+        if (pos < PL_QCAP) w.queue[(size_t)q * PL_QCAP + pos] = ((unsigned long long)nd << 32) | (unsigned long long)nid;
+        else s.qover = 1;
+    }
+}
+
+// Expand bucket s.E (all threads). Each thread handles (entry, neighbour) pairs.
+AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
+{
+    const int q = s.E & (PL_NQ - 1);
+    const uint32_t cnt = min(s.qcount[q], (uint32_t)PL_QCAP);
+    __syncthreads();
+    const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
+    const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };      // y up = row down
+    const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
+    for (uint32_t p = threadIdx.x; p < cnt * 8u; p += PL_THREADS) {
+        const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + (p >> 3)];
+        const int nbr = (int)(p & 7);
+        const uint32_t d = (uint32_t)(ent >> 32);
+        const int64_t id = (int64_t)(ent & 0xffffffffull);
+        if (w.dist[id] != d) continue;                    // stale entry (distance was lowered later)
+        if (w.flags[id] & PL_FLAG_T) continue;            // terminator: closed but never expanded
+        int col = (int)(id % m.S), row = (int)(id / m.S);
+        if (s.alias && col == 0) {
+            if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
+        }
+        if (nbr == 0) atomicAdd((unsigned long long*)&s.h_cells, 1ull);
+        pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { s.qcount[q] = 0; s.E += 1; }
+    __syncthreads();
+}
+
+// Collective heuristic query (hybrid_a_star.py:268-283 + compute_h.py:198-214). All threads call
+// it with the same id; result in s.hq_d (PL_UNSEEN = unreachable). force_miss: the initial
+// compute_path(x0, y0) of hybrid_a_star.__init__ (:89-91), which always runs the sweep.
+AVP_D void pl_hquery(const DevMap& m, const PlanWs& w, PlShared& s, int64_t id, bool force_miss)
+{
+    __syncthreads();
+    const bool in_range = id >= 0 && id < (int64_t)m.S * (m.Sy + 3);
+    if (threadIdx.x == 0) {
+        s.hq_flag = 0;
+        if (!force_miss && id == s.goal_id) { s.hq_d = 0; s.hq_flag = 1; }
+        else if (!in_range) { s.hq_d = PL_UNSEEN; s.hq_flag = 1; }
+        else {
+            const uint32_t d = w.dist[id];
+            if (!force_miss && s.hasF && d != PL_UNSEEN && (d < s.dF || (d == s.dF && id <= s.idF))) { s.hq_d = d; s.hq_flag = 1; }
+        }
+    }
+    __syncthreads();
+    if (s.hq_flag) return;
+    // miss: extend the sweep until the cell's distance is final
+    for (;;) {
+        const uint32_t d = w.dist[id];
+        if (d != PL_UNSEEN && pl_bucket(d) <= s.E) break;
+        const uint32_t pending = s.qcount[0] + s.qcount[1] + s.qcount[2] + s.qcount[3];
+        if (pending == 0 || s.qover) break;
+        if (s.qcount[s.E & (PL_NQ - 1)] == 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) s.E += 1;
+            __syncthreads();
+            continue;
+        }
+        pl_expand_bucket(m, w, s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t d = w.dist[id];
+        s.hq_d = (d != PL_UNSEEN && pl_bucket(d) <= s.E) ? d : PL_UNSEEN;
+        if (s.hq_d != PL_UNSEEN) {
+            s.dF = d; s.idF = id; s.hasF = 1;
+            w.flags[id] |= PL_FLAG_T;
+            s.h_misses += 1;
+        }
+    }
+    __syncthreads();
+}
+
+// hybrid_a_star.py:243-259
+AVP_D double pl_node_cost(const avp_params& p, int node_forward, double node_theta, double father_theta, int father_gear)
+{
+    double cost_gear = 0;
+    if (node_forward != father_gear) cost_gear = p.cost_gear;
+    const double cost_heading = fabs(node_theta - father_theta);
+    const double cost = cost_gear + p.cost_heading * cost_heading;
+    return p.cost_scale * cost;
+}
+
+// Evaluate RS words for queries [0, nq): query 0 = current node (the shot), 1.. = children.
+// One thread per (query, word); then one thread per query folds the 46 results in source order.
+template <typename PoseFn>
+AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
+{
+    for (int t = threadIdx.x; t < nq * 46; t += PL_THREADS) {
+        const int q = t / 46, wd = t - q * 46;
+        double x, y, th;
+        pose(q, x, y, th);
+        const RsFrame f = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+        double l[5];
+        s.w_ok[t] = rs_word(wd, f, l) ? 1 : 0;
+        for (int k = 0; k < 5; k++) s.w_l[t][k] = l[k];
+    }
+    __syncthreads();
+}
+AVP_D int pl_rs_fold(const PlShared& s, const avp_params& p, int q, RsPath& out)
+{
+    RsKeep k;
+    rs_keep_init(k, p.maxc);
+    for (int wd = 0; wd < 46 && !k.err; wd++) {
+        const int t = q * 46 + wd;
+        if (!s.w_ok[t]) continue;
+        double l[5];
+        for (int i = 0; i < 5; i++) l[i] = s.w_l[t][i];
+        rs_keep_add(k, wd, l);
+    }
+    return rs_keep_result(k, out);
+}
+
+__global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
+                                                          const double* __restrict__ goals, int64_t n, int32_t maxNodes,
+                                                          char* __restrict__ workspace, unsigned int* __restrict__ counter,
+                                                          avp_plan_result_dev* __restrict__ results,
+                                                          double* __restrict__ paths, int32_t max_path,
+                                                          double* __restrict__ trace, int32_t max_trace)
+{
+    __shared__ PlShared s;
+    const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
+    const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
+    const int tid = threadIdx.x;
+    const int nchild = 2 * p.n_steer;
+    const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s.pid = (int32_t)atomicAdd(counter, 1u);
+        __syncthreads();
+        const int64_t pid = s.pid;
+        if (pid >= n) break;
+        const double sx = starts[3 * pid], sy = starts[3 * pid + 1], sth = starts[3 * pid + 2];
+        const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
+
+        // ---- init ------------------------------------------------------------------------------
+        for (int64_t i = tid; i < dims.idCap; i += PL_THREADS) { w.dist[i] = PL_UNSEEN; w.flags[i] = 0; }
+        for (int64_t i = tid; i < dims.rowCap; i += PL_THREADS) w.aliasKey[i] = ~0ull;
+        for (int64_t i = tid; i < dims.hashCap; i += PL_THREADS) w.hash[i] = 0;
+        if (tid == 0) {
+            s.status = 0; s.done = 0; s.E = 0; s.qover = 0; s.hasF = 0; s.dF = 0; s.idF = 0;
+            for (int q = 0; q < PL_NQ; q++) s.qcount[q] = 0;
+            s.h_cells = 0; s.h_misses = 0; s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0;
+            s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
+            s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
+            s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
+            // lattice anchored at the goal: columns/rows reachable by repeated +-pitch (compute_h.py:89-186)
+            const int col0 = (int)floor((gx - m.b0) / m.dx);
+            const int row0 = (int)floor((m.b3 - gy) / m.dy);
+            const int orow0 = (int)floor((gy - m.b2) / m.dy) - 1;
+            int regular = 1;
+            int colMin = col0, colMax = col0, rowMin = row0, rowMax = row0;
+            double v = gx;
+            for (int a = 1;; a++) { v = v + m.dx; if (!(v <= m.b1)) break; const int c = (int)floor((v - m.b0) / m.dx); if (c != col0 + a) regular = 0; colMax = col0 + a; }
+            v = gx;
+            for (int a = 1;; a++) { v = v - m.dx; if (!(v >= m.b0)) break; const int c = (int)floor((v - m.b0) / m.dx); if (c != col0 - a) regular = 0; colMin = col0 - a; }
+            v = gy;
+            for (int b = 1;; b++) {
+                v = v + m.dy; if (!(v <= m.b3)) break;
+                const int r = (int)floor((m.b3 - v) / m.dy), o = (int)floor((v - m.b2) / m.dy) - 1;
+                if (r != row0 - b || o != orow0 + b) regular = 0;
+                rowMin = row0 - b;
+            }
+            v = gy;
+            for (int b = 1;; b++) {
+                v = v - m.dy; if (!(v >= m.b2)) break;
+                const int r = (int)floor((m.b3 - v) / m.dy), o = (int)floor((v - m.b2) / m.dy) - 1;
+                if (r != row0 + b || o != orow0 - b) regular = 0;
+                rowMax = row0 + b;
+            }
+            if (!(gx >= m.b0 && gx <= m.b1 && gy >= m.b2 && gy <= m.b3)) regular = 0;
+            if (colMin < 0 || colMax > m.S || rowMin < 0 || rowMax > m.Sy + 1) regular = 0;
+            s.col0 = col0; s.row0 = row0; s.orow0 = orow0; s.colMin = colMin; s.colMax = colMax; s.rowMin = rowMin; s.rowMax = rowMax;
+            s.alias = (colMax == m.S) ? 1 : 0;
+            s.goal_id = (int64_t)col0 + (int64_t)row0 * m.S;
+            s.regular = regular;
+            if (!regular) s.status = 6;
+        }
+        __syncthreads();
+
+        if (s.status == 0) {
+            // first update_openlist(initial_grid): the goal's 8 neighbours at 10/14 (compute_h.py:207-210)
+            if (tid < 8) {
+                const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
+                const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
+                const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
+                pl_relax(m, w, s, s.col0 + dc[tid], s.row0 + dr[tid], cost[tid], 0, s.goal_id, tid);
+            }
+            __syncthreads();
+            // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
+            const int64_t sid = avp_pos_to_index(m, sx, sy);
+            pl_hquery(m, w, s, sid, true);
+            if (tid == 0) {
+                if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
+                else {
+                    PlNode& nd = w.nodes[0];
+                    nd.x = sx; nd.y = sy; nd.th = avp_pi_2_pi(sth); nd.g = 0; nd.h = 0; nd.f = 0;
+                    nd.index = 0; nd.parent_index = -1; nd.parent_pos = -1; nd.forward = 1; nd.steer_i = -1; nd.state = 1;
+                    s.nnodes = 1;
+                    pl_heap_push(w, s, 0);
+                    pl_hash_put(w, dims.hashCap, 0);
+                }
+            }
+            __syncthreads();
+        }
+
+        int64_t n_pops = 0;
+        // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
+        while (s.status == 0 && !s.done) {
+            __syncthreads();
+            if (tid == 0) {
+                if (s.nheap == 0) { s.status = 1; }
+                else if (n_pops >= max_pops) { s.status = 4; }
+                else {
+                    const uint32_t c = pl_heap_pop(w, s);
+                    s.cur = (int32_t)c;
+                    w.nodes[c].state = 3;
+                }
+            }
+            __syncthreads();
+            if (s.status != 0) break;
+            const PlNode cn = w.nodes[s.cur];
+            if (trace && tid == 0 && n_pops < max_trace) {
+                double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
+                t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(m, cn.x, cn.y);
+                t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
+                t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : p.steer[cn.steer_i];
+            }
+            n_pops++;
+
+            // ---- try_reach_goal (:300-349) -------------------------------------------------------
+            const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
+            const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
+            const bool in_radius = distance < p.flag_radius;
+            if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
+            __syncthreads();
+            if (in_radius) {
+                pl_rs_words(s, p, 1, [&](int, double& x, double& y, double& th) { x = cn.x; y = cn.y; th = cn.th; });
+                if (tid == 0) {
+                    s.n_rs += 1;
+                    RsPath rp;
+                    const int st = pl_rs_fold(s, p, 0, rp);
+                    s.rs_status = st;
+                    if (!st) {
+                        s.rs = rp;
+                        const int np = rs_sample(rp, p.maxc, cn.x, cn.y, cn.th, w.rsbuf, 3, w.rsdir, PL_RS_CAP);
+                        if (np < 0) s.rs_status = 5; else s.rs_npts = np;
+                    }
+                }
+                __syncthreads();
+                if (s.rs_status) { if (tid == 0) s.status = s.rs_status == 5 ? 5 : 3; __syncthreads(); break; }
+                const int np = s.rs_npts;
+                for (int i = tid; i < np; i += PL_THREADS) {
+                    // yaw is already wrapped; pi_2_pi again as the reference does (:339)
+                    if (pl_check_pose(m, p, w.rsbuf[3 * i], w.rsbuf[3 * i + 1], avp_pi_2_pi(w.rsbuf[3 * i + 2]))) atomicMin(&s.rs_first_coll, i);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    if (s.rs_first_coll != 0x7fffffff) { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
+                    else s.n_checks += np;
+                    if (!s.collision) s.done = 1;
+                }
+                __syncthreads();
+                if (s.done) break;
+            }
+
+            // ---- expand_node (:126-241) ----------------------------------------------------------
+            if (tid < nchild) {
+                PlChild& c = s.child[tid];
+                const int si = tid % p.n_steer;
+                const bool fwd = tid < p.n_steer;       // i < next_index / 2
+                const double travel = fwd ? p.travel_dt : -p.travel_dt;
+                double th_ = avp_pi_2_pi(cn.th + p.dth_dt[si]);
+                c.th = th_;
+                c.x = cn.x + travel * avp_cos(th_);
+                c.y = cn.y + travel * avp_sin(th_);
+                c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
+                c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
+                c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
+                c.id = avp_pos_to_index(m, c.x, c.y);
+                c.first_coll = 0x7fffffff;
+                c.rs_err = 0;
+                c.L = 0;
+            }
+            __syncthreads();
+            // sub-step collision checks (:185-204): one thread per (child, sub-step)
+            for (int t = tid; t < nchild * p.n_sub; t += PL_THREADS) {
+                const int ci = t / p.n_sub, j = t - ci * p.n_sub;
+                const int si = ci % p.n_steer;
+                const bool fwd = ci < p.n_steer;
+                const double td = fwd ? p.travel_ddt[j] : -p.travel_ddt[j];
+                const double th_i = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
+                const double x_i = cn.x + td * avp_cos(th_i);
+                const double y_i = cn.y + td * avp_sin(th_i);
+                if (pl_check_pose(m, p, x_i, y_i, th_i)) atomicMin(&s.child[ci].first_coll, j);
+            }
+            // RS length of every child to the goal (:286-294); query slot q <-> child q
+            for (int base = 0; base < nchild; base += PL_RSQ) {
+                const int cnt = min(PL_RSQ, nchild - base);
+                pl_rs_words(s, p, cnt, [&](int q, double& x, double& y, double& th) { x = s.child[base + q].x; y = s.child[base + q].y; th = s.child[base + q].th; });
+                if (tid < cnt) {
+                    RsPath rp;
+                    const int st = pl_rs_fold(s, p, tid, rp);
+                    s.child[base + tid].rs_err = (int8_t)st;
+                    s.child[base + tid].L = st ? 0.0 : rp.L / p.maxc;
+                }
+                __syncthreads();
+            }
+
+            // sequential resolution in child order; heuristic queries are collective
+            for (int i = 0; i < nchild && s.status == 0; i++) {
+                const PlChild c = s.child[i];
+                const int si = i % p.n_steer;
+                const int is_forward = i < p.n_steer ? 1 : 0;
+                const bool found_closed = c.found >= 0 && c.found_state == 2;
+                if (s.closed_nonempty && (found_closed || c.oob)) continue;          // :155-165
+                const bool found_open = c.found >= 0 && c.found_state == 1;
+                if (!found_open) {
+                    if (c.first_coll != 0x7fffffff) {
+                        if (tid == 0) {
+                            s.n_checks += c.first_coll + 1;
+                            if (s.nnodes >= maxNodes) s.status = 5;
+                            else {
+                                const int32_t pos = s.nnodes++;
+                                PlNode& nd = w.nodes[pos];
+                                nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = 0; nd.h = 0; nd.f = 0;
+                                nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                                nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
+                                pl_hash_put(w, dims.hashCap, pos);
+                                s.nclosed++; s.closed_nonempty = 1;
+                            }
+                        }
+                        __syncthreads();
+                        continue;
+                    }
+                    pl_hquery(m, w, s, c.id, false);
+                    if (tid == 0) {
+                        s.n_checks += p.n_sub;
+                        s.n_rs += 1;
+                        if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
+                        else if (c.rs_err) s.status = c.rs_err == 4 ? 5 : 3;
+                        else if (s.nnodes >= maxNodes) s.status = 5;
+                        else {
+                            const double g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
+                            const double hv1 = (double)s.hq_d / 100, hv2 = c.L;
+                            const double h = hv2 > hv1 ? hv2 : hv1;
+                            const int32_t pos = s.nnodes++;
+                            PlNode& nd = w.nodes[pos];
+                            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = g; nd.h = h; nd.f = g + h;
+                            nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                            nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
+                            pl_heap_push(w, s, (uint32_t)pos);
+                            pl_hash_put(w, dims.hashCap, pos);
+                        }
+                    }
+                    __syncthreads();
+                } else {
+                    pl_hquery(m, w, s, c.id, false);
+                    if (tid == 0) {
+                        s.n_rs += 1;
+                        if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
+                        else if (c.rs_err) s.status = c.rs_err == 4 ? 5 : 3;
+                        else {
+                            PlNode& ch = w.nodes[c.found];
+                            const double hv1 = (double)s.hq_d / 100, hv2 = c.L;
+                            const double new_h = hv2 > hv1 ? hv2 : hv1;
+                            const double new_g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
+                            const double new_f = new_h + new_g;
+                            if (new_f < ch.f) {
+                                ch.f = new_f; ch.g = new_g; ch.h = new_h;
+                                ch.parent_index = cn.index; ch.parent_pos = s.cur;
+                                ch.forward = (int8_t)is_forward; ch.steer_i = (int8_t)si;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                w.nodes[s.cur].state = 2;
+                s.nclosed++; s.closed_nonempty = 1;
+                s.global_index += nchild;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+
+        // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
+        if (tid == 0) {
+            avp_plan_result_dev r;
+            memset(&r, 0, sizeof(r));
+            r.status = s.status; r.n_pops = (int32_t)n_pops; r.in_radius_last = s.in_radius; r.rs_collision = s.collision;
+            r.n_checks = s.n_checks; r.n_rs = s.n_rs; r.n_closed = s.nclosed; r.n_open = s.nheap;
+            r.h_cells = s.h_cells; r.h_misses = s.h_misses; r.global_index = s.global_index; r.n_nodes = s.nnodes;
+            double* out = paths ? paths + (size_t)pid * max_path * 4 : nullptr;
+            if (out && s.cur >= 0 && (s.status == 0 || s.status == 1)) {
+                // chain child -> root
+                int32_t len = 0;
+                for (int32_t node = s.cur; node >= 0; node = w.nodes[node].parent_pos) { len++; if (w.nodes[node].index == 0) break; }
+                int32_t cnt = 0;
+                bool over = false;
+                auto push = [&](double X, double Y, double T, double D) { if (cnt < max_path) { out[4 * cnt] = X; out[4 * cnt + 1] = Y; out[4 * cnt + 2] = T; out[4 * cnt + 3] = D; cnt++; } else over = true; };
+                // walk from the root: position k of the chain is reached by (len-1-k) parent hops
+                int32_t prev = -1;
+                for (int32_t k = 0; k < len; k++) {
+                    int32_t node = s.cur;
+                    for (int32_t hop = 0; hop < len - 1 - k; hop++) node = w.nodes[node].parent_pos;
+                    const PlNode& nd = w.nodes[node];
+                    if (k == 0) push(nd.x, nd.y, nd.th, 0.0);
+                    else {
+                        const PlNode& par = w.nodes[prev];
+                        for (int j = 0; j < p.n_sub; j++) {
+                            const double td = nd.forward ? p.travel_ddt[j] : -p.travel_ddt[j];
+                            const double th_j = avp_pi_2_pi(par.th + p.dth_ddt[nd.steer_i][j]);
+                            push(par.x + td * avp_cos(th_j), par.y + td * avp_sin(th_j), th_j, 0.0);
+                        }
+                    }
+                    prev = node;
+                }
+                r.n_astar = cnt;
+                if (s.rs.n > 0 && s.rs_status == 0 && s.in_radius) {
+                    r.rs_n = s.rs.n; r.rs_L = s.rs.L / p.maxc;
+                    for (int k = 0; k < s.rs.n; k++) { r.rs_types[k] = s.rs.t[k]; r.rs_lengths[k] = s.rs.l[k] / p.maxc; }
+                    r.n_rs_pts = s.rs_npts;
+                    r.rs_start[0] = w.rsbuf[0]; r.rs_start[1] = w.rsbuf[1]; r.rs_start[2] = w.rsbuf[2]; r.rs_dir0 = w.rsdir[0];
+                    for (int k = 1; k < s.rs_npts; k++) push(w.rsbuf[3 * k], w.rsbuf[3 * k + 1], w.rsbuf[3 * k + 2], (double)w.rsdir[k]);
+                    r.n_final = cnt;
+                }
+                if (over) r.status = 5;
+            }
+            results[pid] = r;
+        }
+        __syncthreads();
+    }
+}

@@ -1,1 +1,437 @@
+// avp_rs_kernels.h -- Reeds-Shepp analytic shots on the device.
+//
+// Replaces rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-134) and everything under it:
+// generate_path :627-644 (46 word evaluations in 6 families, source order), set_path :137-156
+// (signed-sum duplicate filter, L >= 1000 reject, L >= 0.01 assertion), arg-min with "<=" (last of
+// equal minima wins :106-108), generate_local_course/interpolate :537-624 for the winner, world
+// transform :125-131.
+//
+// sin/cos are the glibc-exact avp_sin/avp_cos, hypot is CPython's algorithm (avp_hypot), float %
+// is CPython's (avp_pymod): all bit-identical to what the reference executes. tan/atan2/asin/acos
+// come from the ROCm device libm (<= 1-2 ulp from glibc) and the reference's libm pow(v, 2.0) is
+// evaluated as v*v (its correctly rounded value): path types are identical, lengths and
+// way-points agree to ~1e-15 relative (tests use 1e-9 absolute; north_star allows 1e-6).
 #pragma once
+#include "avp_device.h"
+
+enum { RS_S = 0, RS_L = 1, RS_R = 2 };
+#define RS_KEEP_MAX 24
+
+struct RsPath {
+    int n;                 // segments (3..5); 0 = none
+    int8_t t[AVP_RS_MAXSEG];
+    double l[AVP_RS_MAXSEG];   // normalised (unit turning radius) inside rs_generate; metres after rs_optimal
+    double L;
+};
+
+struct RsKeep {
+    int n;
+    uint32_t code[RS_KEEP_MAX];
+    double l[RS_KEEP_MAX][AVP_RS_MAXSEG];
+    int best;
+    double bestL;          // L / maxc of the current optimum
+    double bestLn;         // its normalised L
+    int err;               // 1 = assertion L >= 0.01 failed; 2 = RS_KEEP_MAX exceeded
+    double maxc;
+};
+
+AVP_D uint32_t rs_code(int n, int a, int b, int c, int d, int e)
+{
+    return (uint32_t)n | (a << 3) | (b << 5) | (c << 7) | (d << 9) | (e << 11);
+}
+
+// rs_curve.py:137-156 + the running arg-min of :103-108
+AVP_D void rs_set_path(RsKeep& k, uint32_t code, int n, double l0, double l1, double l2, double l3, double l4)
+{
+    const double len[5] = { l0, l1, l2, l3, l4 };
+    for (int e = 0; e < k.n; e++) {
+        if (k.code[e] != code) continue;
+        double sum = 0;
+        for (int i = 0; i < n; i++) sum = sum + (k.l[e][i] - len[i]);
+        if (sum <= 0.01) return;
+    }
+    double L = 0;
+    for (int i = 0; i < n; i++) L = L + fabs(len[i]);
+    if (L >= 1000.0) return;
+    if (!(L >= 0.01)) { k.err = 1; return; }
+    if (k.n >= RS_KEEP_MAX) { k.err = 2; return; }
+    const int idx = k.n++;
+    k.code[idx] = code;
+    for (int i = 0; i < 5; i++) k.l[idx][i] = i < n ? len[i] : 0.0;
+    const double Lm = L / k.maxc;
+    if (idx == 0 || Lm <= k.bestL) { k.bestL = Lm; k.best = idx; k.bestLn = L; }
+}
+
+AVP_D void rs_polar(double x, double y, double& r, double& th) { r = avp_hypot(x, y); th = atan2(y, x); }
+
+// rs_curve.py:159-167
+AVP_D bool rs_LSL(double x, double y, double phi, double& t, double& u, double& v)
+{
+    double uu, tt;
+    rs_polar(x - avp_sin(phi), y - 1.0 + avp_cos(phi), uu, tt);
+    if (tt >= 0.0) {
+        const double vv = avp_M(phi - tt);
+        if (vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+// rs_curve.py:170-183
+AVP_D bool rs_LSR(double x, double y, double phi, double& t, double& u, double& v)
+{
+    double u1, t1;
+    rs_polar(x + avp_sin(phi), y - 1.0 - avp_cos(phi), u1, t1);
+    u1 = u1 * u1;
+    if (u1 >= 4.0) {
+        const double uu = sqrt(u1 - 4.0);
+        const double theta = atan2(2.0, uu);
+        const double tt = avp_M(t1 + theta);
+        const double vv = avp_M(tt - phi);
+        if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+// rs_curve.py:186-197
+AVP_D bool rs_LRL(double x, double y, double phi, double& t, double& u, double& v)
+{
+    double u1, t1;
+    rs_polar(x - avp_sin(phi), y - 1.0 + avp_cos(phi), u1, t1);
+    if (u1 <= 4.0) {
+        const double uu = -2.0 * asin(0.25 * u1);
+        const double tt = avp_M(t1 + 0.5 * uu + AVP_PI);
+        const double vv = avp_M(phi - tt + uu);
+        if (tt >= 0.0 && uu <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+// rs_curve.py:213-229
+AVP_D bool rs_SLS(double x, double y, double phi, double& t, double& u, double& v)
+{
+    phi = avp_M(phi);
+    if (y > 0.0 && 0.0 < phi && phi < AVP_PI * 0.99) {
+        const double xd = -y / tan(phi) + x;
+        t = xd - tan(phi / 2.0);
+        u = phi;
+        v = sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        return true;
+    } else if (y < 0.0 && 0.0 < phi && phi < AVP_PI * 0.99) {
+        const double xd = -y / tan(phi) + x;
+        t = xd - tan(phi / 2.0);
+        u = phi;
+        v = -sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        return true;
+    }
+    return false;
+}
+// rs_curve.py:308-323
+AVP_D void rs_tauOmega(double u, double v, double xi, double eta, double phi, double& tau, double& omega)
+{
+    const double delta = avp_M(u - v);
+    const double A = avp_sin(u) - avp_sin(delta);
+    const double B = avp_cos(u) - avp_cos(delta) - 1.0;
+    const double t1 = atan2(eta * A - xi * B, xi * A + eta * B);
+    const double t2 = 2.0 * (avp_cos(delta) - avp_cos(v) - avp_cos(u)) + 3.0;
+    tau = t2 < 0 ? avp_M(t1 + AVP_PI) : avp_M(t1);
+    omega = avp_M(tau - u + v - phi);
+}
+// rs_curve.py:326-337
+AVP_D bool rs_LRLRn(double x, double y, double phi, double& t, double& u, double& v)
+{
+    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    const double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
+    if (rho <= 1.0) {
+        const double uu = acos(rho);
+        double tt, vv;
+        rs_tauOmega(uu, -uu, xi, eta, phi, tt, vv);
+        if (tt >= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+// rs_curve.py:340-352
+AVP_D bool rs_LRLRp(double x, double y, double phi, double& t, double& u, double& v)
+{
+    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    const double rho = (20.0 - xi * xi - eta * eta) / 16.0;
+    if (0.0 <= rho && rho <= 1.0) {
+        const double uu = -acos(rho);
+        if (uu >= -0.5 * AVP_PI) {
+            double tt, vv;
+            rs_tauOmega(uu, uu, xi, eta, phi, tt, vv);
+            if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+        }
+    }
+    return false;
+}
+// rs_curve.py:391-403
+AVP_D bool rs_LRSR(double x, double y, double phi, double& t, double& u, double& v)
+{
+    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    double rho, theta;
+    rs_polar(-eta, xi, rho, theta);
+    if (rho >= 2.0) {
+        const double tt = theta, uu = 2.0 - rho, vv = avp_M(tt + 0.5 * AVP_PI - phi);
+        if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+// rs_curve.py:406-419
+AVP_D bool rs_LRSL(double x, double y, double phi, double& t, double& u, double& v)
+{
+    const double xi = x - avp_sin(phi), eta = y - 1.0 + avp_cos(phi);
+    double rho, theta;
+    rs_polar(xi, eta, rho, theta);
+    if (rho >= 2.0) {
+        const double r = sqrt(rho * rho - 4.0);
+        const double uu = 2.0 - r;
+        const double tt = avp_M(theta + atan2(r, -2.0));
+        const double vv = avp_M(phi - 0.5 * AVP_PI - tt);
+        if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+// rs_curve.py:494-510
+AVP_D bool rs_LRSLR(double x, double y, double phi, double& t, double& u, double& v)
+{
+    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    double rho, theta;
+    rs_polar(xi, eta, rho, theta);
+    if (rho >= 2.0) {
+        const double uu = 4.0 - sqrt(rho * rho - 4.0);
+        if (uu <= 0.0) {
+            const double tt = avp_M(atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
+            const double vv = avp_M(tt - phi);
+            if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+        }
+    }
+    return false;
+}
+
+// Word table: the 46 evaluations of generate_path in source order. Each row: solver id, sign of x
+// (the mirrored/time-flipped variants call f(-x, y, -phi) etc.), sign of y, sign of phi, "backwards"
+// frame flag, output permutation/sign recipe and the type word.
+//   solver: 0 SLS 1 LSL 2 LSR 3 LRL 4 LRLRn 5 LRLRp 6 LRSL 7 LRSR 8 LRSLR
+//   recipe: 0 (t,u,v) 1 -(t,u,v) 2 (v,u,t) 3 -(v,u,t)
+//           4 (t,u,-u,v) 5 (-t,-u,u,-v) 6 (t,u,u,v) 7 -(t,u,u,v)
+//           8 (t,-hp,u,v) 9 (-t,hp,-u,-v) 10 (v,u,-hp,t) 11 (-v,-u,hp,-t)
+//           12 (t,-hp,u,-hp,v) 13 (-t,hp,-u,hp,-v)
+struct RsWord { int8_t solver, sx, sy, sphi, back, recipe, n, a, b, c, d, e; };
+#define W_(solver, sx, sy, sp, back, rec, n, a, b, c, d, e) { solver, sx, sy, sp, back, rec, n, a, b, c, d, e }
+static __device__ const RsWord RS_WORDS[46] = {
+    // SCS :200-210
+    W_(0, 1, 1, 1, 0, 0, 3, RS_S, RS_L, RS_S, 0, 0), W_(0, 1, -1, -1, 0, 0, 3, RS_S, RS_R, RS_S, 0, 0),
+    // CSC :232-265
+    W_(1, 1, 1, 1, 0, 0, 3, RS_L, RS_S, RS_L, 0, 0), W_(1, -1, 1, -1, 0, 1, 3, RS_L, RS_S, RS_L, 0, 0),
+    W_(1, 1, -1, -1, 0, 0, 3, RS_R, RS_S, RS_R, 0, 0), W_(1, -1, -1, 1, 0, 1, 3, RS_R, RS_S, RS_R, 0, 0),
+    W_(2, 1, 1, 1, 0, 0, 3, RS_L, RS_S, RS_R, 0, 0), W_(2, -1, 1, -1, 0, 1, 3, RS_L, RS_S, RS_R, 0, 0),
+    W_(2, 1, -1, -1, 0, 0, 3, RS_R, RS_S, RS_L, 0, 0), W_(2, -1, -1, 1, 0, 1, 3, RS_R, RS_S, RS_L, 0, 0),
+    // CCC :268-305
+    W_(3, 1, 1, 1, 0, 0, 3, RS_L, RS_R, RS_L, 0, 0), W_(3, -1, 1, -1, 0, 1, 3, RS_L, RS_R, RS_L, 0, 0),
+    W_(3, 1, -1, -1, 0, 0, 3, RS_R, RS_L, RS_R, 0, 0), W_(3, -1, -1, 1, 0, 1, 3, RS_R, RS_L, RS_R, 0, 0),
+    W_(3, 1, 1, 1, 1, 2, 3, RS_L, RS_R, RS_L, 0, 0), W_(3, -1, 1, -1, 1, 3, 3, RS_L, RS_R, RS_L, 0, 0),
+    W_(3, 1, -1, -1, 1, 2, 3, RS_R, RS_L, RS_R, 0, 0), W_(3, -1, -1, 1, 1, 3, 3, RS_R, RS_L, RS_R, 0, 0),
+    // CCCC :355-388
+    W_(4, 1, 1, 1, 0, 4, 4, RS_L, RS_R, RS_L, RS_R, 0), W_(4, -1, 1, -1, 0, 5, 4, RS_L, RS_R, RS_L, RS_R, 0),
+    W_(4, 1, -1, -1, 0, 4, 4, RS_R, RS_L, RS_R, RS_L, 0), W_(4, -1, -1, 1, 0, 5, 4, RS_R, RS_L, RS_R, RS_L, 0),
+    W_(5, 1, 1, 1, 0, 6, 4, RS_L, RS_R, RS_L, RS_R, 0), W_(5, -1, 1, -1, 0, 7, 4, RS_L, RS_R, RS_L, RS_R, 0),
+    W_(5, 1, -1, -1, 0, 6, 4, RS_R, RS_L, RS_R, RS_L, 0), W_(5, -1, -1, 1, 0, 7, 4, RS_R, RS_L, RS_R, RS_L, 0),
+    // CCSC :422-491
+    W_(6, 1, 1, 1, 0, 8, 4, RS_L, RS_R, RS_S, RS_L, 0), W_(6, -1, 1, -1, 0, 9, 4, RS_L, RS_R, RS_S, RS_L, 0),
+    W_(6, 1, -1, -1, 0, 8, 4, RS_R, RS_L, RS_S, RS_R, 0), W_(6, -1, -1, 1, 0, 9, 4, RS_R, RS_L, RS_S, RS_R, 0),
+    W_(7, 1, 1, 1, 0, 8, 4, RS_L, RS_R, RS_S, RS_R, 0), W_(7, -1, 1, -1, 0, 9, 4, RS_L, RS_R, RS_S, RS_R, 0),
+    W_(7, 1, -1, -1, 0, 8, 4, RS_R, RS_L, RS_S, RS_L, 0), W_(7, -1, -1, 1, 0, 9, 4, RS_R, RS_L, RS_S, RS_L, 0),
+    W_(6, 1, 1, 1, 1, 10, 4, RS_L, RS_S, RS_R, RS_L, 0), W_(6, -1, 1, -1, 1, 11, 4, RS_L, RS_S, RS_R, RS_L, 0),
+    W_(6, 1, -1, -1, 1, 10, 4, RS_R, RS_S, RS_L, RS_R, 0), W_(6, -1, -1, 1, 1, 11, 4, RS_R, RS_S, RS_L, RS_R, 0),
+    W_(7, 1, 1, 1, 1, 10, 4, RS_R, RS_S, RS_R, RS_L, 0), W_(7, -1, 1, -1, 1, 11, 4, RS_R, RS_S, RS_R, RS_L, 0),
+    W_(7, 1, -1, -1, 1, 10, 4, RS_L, RS_S, RS_L, RS_R, 0), W_(7, -1, -1, 1, 1, 11, 4, RS_L, RS_S, RS_L, RS_R, 0),
+    // CCSCC :513-534
+    W_(8, 1, 1, 1, 0, 12, 5, RS_L, RS_R, RS_S, RS_L, RS_R), W_(8, -1, 1, -1, 0, 13, 5, RS_L, RS_R, RS_S, RS_L, RS_R),
+    W_(8, 1, -1, -1, 0, 12, 5, RS_R, RS_L, RS_S, RS_R, RS_L), W_(8, -1, -1, 1, 0, 13, 5, RS_R, RS_L, RS_S, RS_R, RS_L),
+};
+#undef W_
+
+// Start-frame normalisation of generate_path (rs_curve.py:627-634) + the "backwards" frame
+// (:286-287, :456-457).
+struct RsFrame { double x0, y0, phi0, xb, yb; };
+AVP_D RsFrame rs_frame(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t, double maxc)
+{
+    RsFrame f;
+    const double dx = q1x - q0x, dy = q1y - q0y;
+    f.phi0 = q1t - q0t;
+    const double c = avp_cos(q0t), s = avp_sin(q0t);
+    f.x0 = (c * dx + s * dy) * maxc;
+    f.y0 = (-s * dx + c * dy) * maxc;
+    f.xb = f.x0 * avp_cos(f.phi0) + f.y0 * avp_sin(f.phi0);
+    f.yb = f.x0 * avp_sin(f.phi0) - f.y0 * avp_cos(f.phi0);
+    return f;
+}
+
+// Word w of the 46 (source order): returns validity and the signed normalised segment lengths.
+__device__ __noinline__ bool rs_word(int w, const RsFrame& f, double l[5])
+{
+    const RsWord W = RS_WORDS[w];
+    const double bx = W.back ? f.xb : f.x0, by = W.back ? f.yb : f.y0;
+    const double x = W.sx < 0 ? -bx : bx, y = W.sy < 0 ? -by : by, phi = W.sphi < 0 ? -f.phi0 : f.phi0;
+    const double hp = 0.5 * AVP_PI;
+    double t = 0, u = 0, v = 0;
+    bool ok;
+    switch (W.solver) {
+        case 0: ok = rs_SLS(x, y, phi, t, u, v); break;
+        case 1: ok = rs_LSL(x, y, phi, t, u, v); break;
+        case 2: ok = rs_LSR(x, y, phi, t, u, v); break;
+        case 3: ok = rs_LRL(x, y, phi, t, u, v); break;
+        case 4: ok = rs_LRLRn(x, y, phi, t, u, v); break;
+        case 5: ok = rs_LRLRp(x, y, phi, t, u, v); break;
+        case 6: ok = rs_LRSL(x, y, phi, t, u, v); break;
+        case 7: ok = rs_LRSR(x, y, phi, t, u, v); break;
+        default: ok = rs_LRSLR(x, y, phi, t, u, v); break;
+    }
+    l[0] = l[1] = l[2] = l[3] = l[4] = 0.0;
+    if (!ok) return false;
+    switch (W.recipe) {
+        case 0: l[0] = t; l[1] = u; l[2] = v; break;
+        case 1: l[0] = -t; l[1] = -u; l[2] = -v; break;
+        case 2: l[0] = v; l[1] = u; l[2] = t; break;
+        case 3: l[0] = -v; l[1] = -u; l[2] = -t; break;
+        case 4: l[0] = t; l[1] = u; l[2] = -u; l[3] = v; break;
+        case 5: l[0] = -t; l[1] = -u; l[2] = u; l[3] = -v; break;
+        case 6: l[0] = t; l[1] = u; l[2] = u; l[3] = v; break;
+        case 7: l[0] = -t; l[1] = -u; l[2] = -u; l[3] = -v; break;
+        case 8: l[0] = t; l[1] = -hp; l[2] = u; l[3] = v; break;
+        case 9: l[0] = -t; l[1] = hp; l[2] = -u; l[3] = -v; break;
+        case 10: l[0] = v; l[1] = u; l[2] = -hp; l[3] = t; break;
+        case 11: l[0] = -v; l[1] = -u; l[2] = hp; l[3] = -t; break;
+        case 12: l[0] = t; l[1] = -hp; l[2] = u; l[3] = -hp; l[4] = v; break;
+        default: l[0] = -t; l[1] = hp; l[2] = -u; l[3] = hp; l[4] = -v; break;
+    }
+    return true;
+}
+
+AVP_D void rs_keep_init(RsKeep& k, double maxc) { k.n = 0; k.err = 0; k.best = -1; k.bestL = 0; k.bestLn = 0; k.maxc = maxc; }
+AVP_D void rs_keep_add(RsKeep& k, int w, const double l[5])
+{
+    const RsWord W = RS_WORDS[w];
+    rs_set_path(k, rs_code(W.n, W.a, W.b, W.c, W.d, W.e), W.n, l[0], l[1], l[2], l[3], l[4]);
+}
+
+// rs_curve.py:627-644, serial form: fills `k` with the kept candidates and the optimum.
+AVP_D void rs_generate(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t, double maxc, RsKeep& k)
+{
+    const RsFrame f = rs_frame(q0x, q0y, q0t, q1x, q1y, q1t, maxc);
+    rs_keep_init(k, maxc);
+    for (int w = 0; w < 46; w++) {
+        double l[5];
+        if (!rs_word(w, f, l)) continue;
+        rs_keep_add(k, w, l);
+        if (k.err) return;
+    }
+}
+
+// winner of a filled RsKeep -> RsPath (normalised lengths); same status codes as rs_optimal
+AVP_D int rs_keep_result(const RsKeep& k, RsPath& out)
+{
+    out.n = 0; out.L = 0;
+    if (k.err == 1) return 2;
+    if (k.err == 2) return 4;
+    if (k.n == 0) return 1;
+    const uint32_t code = k.code[k.best];
+    out.n = code & 7;
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) {
+        out.t[i] = i < out.n ? (int8_t)((code >> (3 + 2 * i)) & 3) : (int8_t)-1;
+        out.l[i] = k.l[k.best][i];
+    }
+    out.L = k.bestLn;
+    return 0;
+}
+
+// status: 0 ok, 1 no candidate (IndexError in the reference), 2 L >= 0.01 assertion, 4 keep overflow
+AVP_D int rs_optimal(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t, double maxc, RsPath& out)
+{
+    RsKeep k;
+    rs_generate(q0x, q0y, q0t, q1x, q1y, q1t, maxc, k);
+    return rs_keep_result(k, out);
+}
+
+// rs_curve.py:597-624
+AVP_D void rs_interpolate(double l, int m, double maxc, double ox, double oy, double oyaw, double& px, double& py, double& pyaw)
+{
+    if (m == RS_S) {
+        px = ox + l / maxc * avp_cos(oyaw);
+        py = oy + l / maxc * avp_sin(oyaw);
+        pyaw = oyaw;
+    } else {
+        const double ldx = avp_sin(l) / maxc;
+        const double ldy = (m == RS_L) ? (1.0 - avp_cos(l)) / maxc : (1.0 - avp_cos(l)) / (-maxc);
+        const double gdx = avp_cos(-oyaw) * ldx + avp_sin(-oyaw) * ldy;
+        const double gdy = -avp_sin(-oyaw) * ldx + avp_cos(-oyaw) * ldy;
+        px = ox + gdx;
+        py = oy + gdy;
+        pyaw = (m == RS_L) ? oyaw + l : oyaw - l;
+    }
+}
+
+// rs_curve.py:537-594 + :125-131. `p` holds normalised lengths. Writes world-frame samples
+// (x, y, pi_2_pi(yaw)) with stride `stride` doubles and directions; returns the number of points,
+// or -1 when cap is too small. The index bookkeeping (segment ends overwritten by the next
+// segment's first step, trailing px == 0.0 entries dropped) follows the reference exactly.
+__device__ __noinline__ int rs_sample(const RsPath& p, double maxc, double q0x, double q0y, double q0t, double* xyyaw, int stride,
+                    int8_t* dir, int cap)
+{
+    const double step = 0.5 * maxc;
+    const int point_num = (int)(p.L / step) + p.n + 3;
+    if (point_num > cap) return -1;
+    for (int i = 0; i < point_num; i++) { xyyaw[i * stride] = 0.0; xyyaw[i * stride + 1] = 0.0; xyyaw[i * stride + 2] = 0.0; if (dir) dir[i] = 0; }
+    int ind = 1;
+    if (dir) dir[0] = p.l[0] > 0.0 ? 1 : -1;
+    double d = p.l[0] > 0.0 ? step : -step;
+    double pd = d, ll = 0.0;
+    for (int i = 0; i < p.n; i++) {
+        const double l = p.l[i];
+        const int m = p.t[i];
+        d = l > 0.0 ? step : -step;
+        const double ox = xyyaw[ind * stride], oy = xyyaw[ind * stride + 1], oyaw = xyyaw[ind * stride + 2];
+        ind -= 1;
+        if (i >= 1 && (p.l[i - 1] * p.l[i]) > 0) pd = -d - ll; else pd = d - ll;
+        while (fabs(pd) <= fabs(l)) {
+            ind += 1;
+            rs_interpolate(pd, m, maxc, ox, oy, oyaw, xyyaw[ind * stride], xyyaw[ind * stride + 1], xyyaw[ind * stride + 2]);
+            if (dir) dir[ind] = pd > 0.0 ? 1 : -1;
+            pd += d;
+        }
+        ll = l - pd - d;
+        ind += 1;
+        rs_interpolate(l, m, maxc, ox, oy, oyaw, xyyaw[ind * stride], xyyaw[ind * stride + 1], xyyaw[ind * stride + 2]);
+        if (dir) dir[ind] = l > 0.0 ? 1 : -1;
+    }
+    int np = point_num;
+    while (np > 0 && xyyaw[(np - 1) * stride] == 0.0) np--;
+    const double cm = avp_cos(-q0t), sm = avp_sin(-q0t);
+    for (int i = 0; i < np; i++) {
+        const double ix = xyyaw[i * stride], iy = xyyaw[i * stride + 1];
+        xyyaw[i * stride] = cm * ix + sm * iy + q0x;
+        xyyaw[i * stride + 1] = -sm * ix + cm * iy + q0y;
+        xyyaw[i * stride + 2] = avp_pi_2_pi(xyyaw[i * stride + 2] + q0t);
+    }
+    return np;
+}
+
+// One thread = one (q0, q1) query.
+__global__ __launch_bounds__(64) void rs_optimal_kernel(const double* __restrict__ q0, const double* __restrict__ q1,
+                                                        double maxc, int64_t n, int32_t maxpts, int32_t* __restrict__ status,
+                                                        double* __restrict__ L, int8_t* __restrict__ types,
+                                                        double* __restrict__ lens, int32_t* __restrict__ npts,
+                                                        double* __restrict__ xyyaw, int8_t* __restrict__ dir)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RsPath p;
+    const double ax = q0[3 * i], ay = q0[3 * i + 1], at = q0[3 * i + 2];
+    int st = rs_optimal(ax, ay, at, q1[3 * i], q1[3 * i + 1], q1[3 * i + 2], maxc, p);
+    for (int k = 0; k < 5; k++) { types[i * 5 + k] = st ? (int8_t)-1 : p.t[k]; lens[i * 5 + k] = st ? 0.0 : p.l[k] / maxc; }
+    L[i] = st ? 0.0 : p.L / maxc;
+    int np = 0;
+    if (!st && maxpts > 0 && xyyaw) {
+        np = rs_sample(p, maxc, ax, ay, at, xyyaw + (size_t)i * maxpts * 3, 3, dir ? dir + (size_t)i * maxpts : nullptr, maxpts);
+        if (np < 0) { st = 3; np = (int)(p.L / (0.5 * maxc)) + p.n + 3; }
+    }
+    npts[i] = np;
+    status[i] = st;
+}

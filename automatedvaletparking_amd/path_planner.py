@@ -1,0 +1,271 @@
+"""`PathPlanner` with the reference's interface (`path_plan/path_planner.py`), executed by the
+batched HIP planner.
+
+    planner = PathPlanner(config=config, map=park_map, vehicle=ego_vehicle)     # main.py:37-39
+    original_path, path_info, split_path = planner.path_planning()              # main.py:66
+
+plus the additive batched surface `plan_batch(starts[N,3], goals[N,3]) -> list[PlanResult]`.
+`a_star_plan`/`path_planning` raise what the reference raises (AttributeError when no path exists,
+IndexError when the path has no gear change); conditions under which the reference hangs or has no
+error of its own are reported as RuntimeError with the per-problem status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from . import collision_check
+from .costmap import Map, Vehicle
+from .rs_curve import PATH, path_from_arrays
+
+STATUS_NAMES = {0: "OK", 1: "NO_PATH", 2: "H_UNREACHABLE", 3: "RS_ERROR", 4: "ITER_LIMIT", 5: "CAPACITY", 6: "LATTICE"}
+
+
+class AvpPlanResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_pops", C.c_int32), ("n_astar", C.c_int32), ("n_rs_pts", C.c_int32),
+                ("n_final", C.c_int32), ("rs_n", C.c_int32), ("in_radius_last", C.c_int32), ("rs_collision", C.c_int32),
+                ("n_checks", C.c_int64), ("n_rs", C.c_int64), ("n_closed", C.c_int64), ("n_open", C.c_int64),
+                ("h_cells", C.c_int64), ("h_misses", C.c_int64), ("global_index", C.c_int64), ("n_nodes", C.c_int64),
+                ("rs_types", C.c_int8 * 8), ("rs_lengths", C.c_double * 5), ("rs_L", C.c_double),
+                ("rs_start", C.c_double * 3), ("rs_dir0", C.c_int32), ("pad", C.c_int32)]
+
+
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_pops", "<i4"), ("n_astar", "<i4"), ("n_rs_pts", "<i4"), ("n_final", "<i4"),
+                         ("rs_n", "<i4"), ("in_radius_last", "<i4"), ("rs_collision", "<i4"),
+                         ("n_checks", "<i8"), ("n_rs", "<i8"), ("n_closed", "<i8"), ("n_open", "<i8"), ("h_cells", "<i8"),
+                         ("h_misses", "<i8"), ("global_index", "<i8"), ("n_nodes", "<i8"),
+                         ("rs_types", "i1", (8,)), ("rs_lengths", "<f8", (5,)), ("rs_L", "<f8"),
+                         ("rs_start", "<f8", (3,)), ("rs_dir0", "<i4"), ("pad", "<i4")])
+assert RESULT_DTYPE.itemsize == C.sizeof(AvpPlanResult)
+
+
+@dataclass
+class PlanResult:
+    status: int
+    n_pops: int
+    final_path: np.ndarray            # (n_final, 3)  astar way-points + RS samples[1:]
+    astar_path: np.ndarray            # (n_astar, 3)
+    rs_types: List[str]
+    rs_lengths: List[float]
+    rs_L: float
+    n_rs_pts: int
+    rs_xyyaw: np.ndarray = None       # (n_rs_pts, 3) samples of the final RS shot (sample 0 = last popped node)
+    rs_dirs: np.ndarray = None        # (n_rs_pts,) +1 forward / -1 reverse
+    counters: Dict[str, int] = field(default_factory=dict)
+    trace: Optional[np.ndarray] = None
+
+    @property
+    def ok(self) -> bool:
+        return self.status == 0
+
+    @property
+    def status_name(self) -> str:
+        return STATUS_NAMES.get(self.status, str(self.status))
+
+
+class BatchPlanner:
+    """Device-side batched planner bound to one DeviceMap. Owns the scratch workspace (torch tensor)."""
+
+    def __init__(self, device_map: _native.DeviceMap, max_nodes: int = 65536, n_slots: Optional[int] = None,
+                 max_path: int = 512):
+        self.dm = device_map
+        self.max_nodes = int(max_nodes)
+        L = _native.lib()
+        self.n_slots = int(n_slots) if n_slots else int(L.avp_plan_default_slots(device_map.h))
+        self.max_path = int(max_path)
+        if L.avp_sizeof_plan_result() != C.sizeof(AvpPlanResult):
+            raise RuntimeError("avp_plan_result layout mismatch")
+        self._ws = None
+        self._ws_slots = 0
+
+    def _workspace(self, slots):
+        if self._ws is None or self._ws_slots < slots:
+            L = _native.lib()
+            nbytes = int(L.avp_plan_workspace_bytes(self.dm.h, C.c_int32(slots), C.c_int32(self.max_nodes)))
+            if nbytes <= 0:
+                raise RuntimeError(_native.last_error())
+            self._ws = self.dm.empty(nbytes, self.dm.torch.uint8)
+            self._ws_slots = slots
+        return self._ws
+
+    def plan_dev(self, starts_t, goals_t, want_paths=True, max_trace: int = 0):
+        """starts_t/goals_t: (n,3) float64 CUDA tensors. Asynchronous; returns device tensors
+        (results as uint8 (n, sizeof result), paths (n, max_path, 3) or None, trace or None)."""
+        torch = self.dm.torch
+        n = starts_t.shape[0]
+        slots = max(1, min(self.n_slots, n))
+        ws = self._workspace(slots)
+        res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
+        paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
+        trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
+        _native.chk(_native.lib().avp_plan_batch(
+            self.dm.h, C.c_void_p(starts_t.data_ptr()), C.c_void_p(goals_t.data_ptr()), C.c_int64(n), C.c_int32(slots),
+            C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
+            C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
+            C.c_void_p(trace.data_ptr()) if trace is not None else None, C.c_int32(max_trace)), "avp_plan_batch")
+        return res, paths, trace
+
+    def plan(self, starts, goals, max_trace: int = 0) -> List[PlanResult]:
+        starts = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+        goals = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 3)
+        if len(starts) != len(goals):
+            raise ValueError("starts and goals must have the same length")
+        n = len(starts)
+        if n == 0:
+            return []
+        res, paths, trace = self.plan_dev(self.dm.dev_tensor(starts), self.dm.dev_tensor(goals), True, max_trace)
+        rec = res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)[:n]
+        paths = paths.cpu().numpy()
+        trace = trace.cpu().numpy() if trace is not None else None
+        out = []
+        for i in range(n):
+            r = rec[i]
+            nf, na, k = int(r["n_final"]), int(r["n_astar"]), int(r["rs_n"])
+            cnt = {name: int(r[name]) for name in ("n_checks", "n_rs", "n_closed", "n_open", "h_cells", "h_misses",
+                                                   "global_index", "n_nodes", "in_radius_last", "rs_collision")}
+            if k > 0 and nf > 0:
+                rs_xy = np.concatenate([np.asarray(r["rs_start"], dtype=np.float64)[None, :], paths[i, na:nf, :3]], 0)
+                rs_dirs = np.concatenate([[int(r["rs_dir0"])], paths[i, na:nf, 3].astype(np.int64)]).astype(np.int8)
+            else:
+                rs_xy, rs_dirs = np.zeros((0, 3)), np.zeros(0, np.int8)
+            out.append(PlanResult(status=int(r["status"]), n_pops=int(r["n_pops"]), final_path=paths[i, :nf, :3].copy(),
+                                  astar_path=paths[i, :na, :3].copy(), rs_types=[("S", "L", "R")[int(t)] for t in r["rs_types"][:k]],
+                                  rs_lengths=[float(v) for v in r["rs_lengths"][:k]], rs_L=float(r["rs_L"]),
+                                  n_rs_pts=int(r["n_rs_pts"]), rs_xyyaw=rs_xy, rs_dirs=rs_dirs, counters=cnt,
+                                  trace=None if trace is None else trace[i, :min(int(r["n_pops"]), trace.shape[1])].copy()))
+        return out
+
+
+class _PlannerView:
+    """What the reference exposes as `PathPlanner.planner` (a hybrid_a_star instance): the pieces
+    callers read (`ddt`, `dt`, `collision_checker`, `steering_angle`)."""
+
+    def __init__(self, config, vehicle, checker):
+        self.config = config
+        self.vehicle = vehicle
+        self.dt = config['dt']
+        self.ddt = config['trajectory_dt']
+        self.collision_checker = checker
+        self.steering_angle = np.linspace(-vehicle.max_steering_angle, vehicle.max_steering_angle, config['steering_angle_num'])
+
+
+class PathPlanner:
+    def __init__(self, config: dict = None, map: Map = None, vehicle: Vehicle = None) -> None:
+        self.config = config
+        self.map = map
+        self.vehicle = vehicle
+        if config['collision_check'] == 'circle':
+            self.collision_checker = collision_check.two_circle_checker(map=map, vehicle=vehicle, config=config)
+        else:
+            self.collision_checker = collision_check.distance_checker(map=map, vehicle=vehicle, config=config)
+        self.planner = _PlannerView(config, vehicle, self.collision_checker)
+        self._batch: Optional[BatchPlanner] = None
+
+    # -- batched surface -----------------------------------------------------------------------------
+    def batch_planner(self, **kw) -> BatchPlanner:
+        if self._batch is None or kw:
+            self._batch = BatchPlanner(_native.device_map(self.map, self.vehicle, self.config), **kw)
+        return self._batch
+
+    def plan_batch(self, starts, goals, max_trace: int = 0) -> List[PlanResult]:
+        """N independent (start, goal) problems on this map; element i equals what
+        `a_star_plan()` gives for `map.case.{x0..thetaf}` = (starts[i], goals[i])."""
+        return self.batch_planner().plan(starts, goals, max_trace=max_trace)
+
+    # -- reference API -----------------------------------------------------------------------------------
+    def a_star_plan(self) -> Tuple[List[List], List[List], PATH]:
+        c = self.map.case
+        r = self.plan_batch([[c.x0, c.y0, c.theta0]], [[c.xf, c.yf, c.thetaf]])[0]
+        if r.status in (0, 1):
+            if not r.rs_types:
+                raise AttributeError("'NoneType' object has no attribute 'x'")       # path_planner.py:104
+        elif r.status == 3:
+            raise AssertionError("path.L >= 0.01")                                   # rs_curve.py:153
+        else:
+            raise RuntimeError(f"hybrid A* stopped with status {r.status_name}")
+        final_path = [[float(p[0]), float(p[1]), float(p[2])] for p in r.final_path]
+        astar_path = [[float(p[0]), float(p[1]), float(p[2])] for p in r.astar_path]
+        rs_path = PATH(lengths=list(r.rs_lengths), ctypes=list(r.rs_types), L=r.rs_L,
+                       x=[float(v) for v in r.rs_xyyaw[:, 0]], y=[float(v) for v in r.rs_xyyaw[:, 1]],
+                       yaw=[float(v) for v in r.rs_xyyaw[:, 2]], directions=[int(d) for d in r.rs_dirs])
+        return final_path, astar_path, rs_path
+
+    def split_path(self, final_path: List[List]) -> Tuple[List[List[List]], int]:
+        return split_path(final_path, self.config, self.vehicle, self.collision_checker)
+
+    def path_planning(self) -> Tuple[List[List], Dict, List[List[List]]]:
+        final_path, astar_path, rs_path = self.a_star_plan()
+        split_path_list, change_gear = self.split_path(final_path)
+        path_info = {'astar_path': astar_path, 'rs_path': rs_path, 'change_gear': change_gear}
+        return sum(split_path_list, []), path_info, split_path_list
+
+
+def _cosine_distance(u, v):
+    """scipy.spatial.distance.cosine (1 - u.v / sqrt(u.u * v.v), clipped to [0, 2]); np.dot keeps
+    the BLAS rounding the reference gets."""
+    import math
+    u = np.asarray(u, dtype=np.float64)
+    v = np.asarray(v, dtype=np.float64)
+    uv, uu, vv = np.dot(u, v), np.dot(u, u), np.dot(v, v)
+    with np.errstate(all="ignore"):
+        dist = 1.0 - uv / math.sqrt(uu * vv) if uu * vv > 0 else np.float64(np.nan)
+    return np.clip(dist, 0.0, 2.0)
+
+
+def split_path(final_path, config, vehicle, checker):
+    """Gear-change segmentation + collision-checked end extension (`path_planner.py:112-192`).
+    A cut is placed where consecutive steps point in opposite directions (cosine < 0); each
+    segment end is extended by up to `extended_num` collision-free points which are also prepended
+    (last first) to the next segment. Raises IndexError when the path has no gear change, like
+    the reference (`path_planner.py:181`)."""
+    segments: List[List[List]] = []
+    change_gear = 0
+    seg_start = 0
+    n_extend = config['extended_num']
+    ddt = config['trajectory_dt']
+    carried = 0                      # extension points of the previous segment still to be prepended
+
+    def prepend_carried(seg):
+        prev = segments[-1]
+        for j in range(carried):
+            q = prev[-(carried - j)]
+            seg.insert(0, [q[0], q[1], q[2]])
+
+    for i in range(len(final_path) - 2):
+        a, b, c = final_path[i], final_path[i + 1], final_path[i + 2]
+        cosine = 1 - _cosine_distance((b[0] - a[0], b[1] - a[1]), (c[0] - b[0], c[1] - b[1]))
+        if not (cosine < 0):
+            continue
+        change_gear += 1
+        seg = final_path[seg_start:i + 2]
+        if change_gear > 1 and carried > 0:
+            prepend_carried(seg)
+            carried = 0
+        for j in range(n_extend):
+            heading = a[2]
+            moving_pos_x = b[0] > a[0]
+            moving_neg_x = b[0] < a[0]
+            facing_pos_x = -np.pi / 2 < heading < np.pi / 2
+            facing_neg_x = (np.pi / 2 < heading < np.pi) or (-np.pi < heading < -np.pi / 2)
+            forward = (moving_pos_x and facing_pos_x) or (moving_neg_x and facing_neg_x)
+            speed = vehicle.max_v if forward else -vehicle.max_v
+            step = speed * ddt * (j + 1)
+            th = b[2]
+            ex = b[0] + step * np.cos(th)
+            ey = b[1] + step * np.sin(th)
+            if not checker.check(node_x=ex, node_y=ey, theta=th):
+                seg.append([ex, ey, th])
+                carried += 1
+        segments.append(seg)
+        seg_start = i + 1
+
+    tail = final_path[seg_start:]
+    prev = segments[-1]              # IndexError here when there was no gear change (as the reference)
+    if carried > 0:
+        prepend_carried(tail)
+    segments.append(tail)
+    return segments, int(change_gear)

@@ -42,7 +42,8 @@ enum {
                                    PriorityQueue.get(), compute_h.py:77                          */
     AVP_PLAN_RS_ERROR = 3,      /* start == goal: AssertionError rs_curve.py:153                */
     AVP_PLAN_ITER_LIMIT = 4,    /* params.max_pops reached (the reference has no cap)           */
-    AVP_PLAN_CAPACITY = 5       /* node arena / path buffer exhausted                           */
+    AVP_PLAN_CAPACITY = 5,      /* node arena / path buffer / sweep queue exhausted             */
+    AVP_PLAN_LATTICE = 6        /* goal outside the map or goal-anchored lattice not regular     */
 };
 
 /*
@@ -102,6 +103,63 @@ int32_t avp_sync(avp_map* map);
  */
 int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, const double* y, const double* th,
                         int64_t n, uint8_t* out, int32_t variant);
+
+/*
+ * Replaces: rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-134), one call per (start, goal)
+ * pair in the reference. All pointers device. q0, q1: n x 3 (x, y, yaw) row-major; maxc = 1 /
+ * min turning radius. Outputs per query i: status[i] (0 ok, 1 no candidate word, 2 the reference's
+ * "L >= 0.01" assertion fails, 3 more than maxpts samples (npts[i] = needed), 4 internal candidate
+ * capacity), L[i] total length [m], types[i*5+k] in {0 S, 1 L, 2 R, -1 unused}, lens[i*5+k] signed
+ * segment lengths [m], npts[i], xyyaw[(i*maxpts+j)*3 + {0,1,2}] world-frame samples every 0.5 m
+ * (yaw wrapped by pi_2_pi), dir[i*maxpts+j] in {+1,-1}. maxpts = 0 (xyyaw/dir NULL) skips sampling.
+ */
+int32_t avp_rs_optimal_batch(avp_map* map, const double* q0, const double* q1, double maxc, int64_t n,
+                             int32_t maxpts, int32_t* status, double* L, int8_t* types, double* lens,
+                             int32_t* npts, double* xyyaw, int8_t* dir);
+
+/*
+ * Per-problem record written by avp_plan_batch (device memory, n entries).
+ * Replaces what PathPlanner.a_star_plan returns/raises (path_planner.py:58-110).
+ */
+typedef struct avp_plan_result {
+    int32_t status;          /* AVP_PLAN_*                                                        */
+    int32_t n_pops;          /* nodes popped from the open list (expansions + the final pop)      */
+    int32_t n_astar;         /* way-points of finish_path (hybrid_a_star.py:351-389)              */
+    int32_t n_rs_pts;        /* samples of the last Reeds-Shepp shot (rs_path.x)                   */
+    int32_t n_final;         /* way-points of final_path = astar_path + rs samples[1:]; 0 if none  */
+    int32_t rs_n;            /* segments of the last RS shot, 0 = no shot (rs_path is None)        */
+    int32_t in_radius_last;  /* info['in_radius'] of the last pop                                  */
+    int32_t rs_collision;    /* collision flag of the last shot                                    */
+    int64_t n_checks;        /* collision checks the reference would have executed                 */
+    int64_t n_rs;            /* calc_optimal_path calls the reference would have executed          */
+    int64_t n_closed, n_open;/* len(closed_list), len(open_list.queue) at termination              */
+    int64_t h_cells;         /* heuristic-field cells expanded by the sweep                        */
+    int64_t h_misses;        /* heuristic queries that extended the sweep (Dijkstra.compute_path calls) */
+    int64_t global_index;    /* hybrid_a_star.global_index                                         */
+    int64_t n_nodes;         /* nodes created                                                      */
+    int8_t rs_types[8];      /* 0 S, 1 L, 2 R                                                      */
+    double rs_lengths[5];    /* signed segment lengths [m]                                         */
+    double rs_L;             /* total RS length [m]                                                */
+    double rs_start[3];      /* sample 0 of the last RS shot = pose of the last popped node        */
+    int32_t rs_dir0, pad;    /* its direction flag                                                 */
+} avp_plan_result;
+
+/*
+ * Replaces: PathPlanner.a_star_plan (path_plan/path_planner.py:58-110), one call per (start, goal)
+ * in the reference, including hybrid_a_star.__init__'s heuristic sweep (hybrid_a_star.py:72-124).
+ * One workgroup per problem; n_slots persistent workgroups pull problems from a counter.
+ * All pointers device unless noted. starts/goals: n x 3 (x, y, theta). workspace: at least
+ * avp_plan_workspace_bytes(map, n_slots, max_nodes) bytes, caller-owned scratch (no initialisation
+ * needed). results: n records. paths: n x max_path x 4 doubles (x, y, theta, RS direction flag or 0) =
+ * final_path of each problem; the first n_astar rows are astar_path; may be NULL. trace: n x max_trace x 11 doubles, optional
+ * pop trace (node index, parent index, grid id, x, y, theta, g, h, f, forward, steering), may be NULL.
+ */
+int64_t avp_plan_workspace_bytes(avp_map* map, int32_t n_slots, int32_t max_nodes);
+int32_t avp_plan_default_slots(avp_map* map);   /* = number of compute units */
+int32_t avp_sizeof_plan_result(void);
+int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
+                       int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
+                       double* paths, int32_t max_path, double* trace, int32_t max_trace);
 
 /* Device evaluation of the shared scalar maths (test hook): out_sin/out_cos = avp_sin/avp_cos(x). */
 int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos);
