@@ -8,11 +8,15 @@
 //
 // sin/cos are the glibc-exact avp_sin/avp_cos, hypot is CPython's algorithm (avp_hypot), float %
 // is CPython's (avp_pymod): all bit-identical to what the reference executes. tan/atan2/asin/acos
-// come from the ROCm device libm (<= 1-2 ulp from glibc) and the reference's libm pow(v, 2.0) is
-// evaluated as v*v (its correctly rounded value): path types are identical, lengths and
-// way-points agree to ~1e-15 relative (tests use 1e-9 absolute; north_star allows 1e-6).
+// are the portable kernels of include/avp_libm.h (the CPU oracle's "portable" mode compiles the very
+// same functions, so device == CPU-port bit for bit) and the reference's libm pow(v, 2.0) is
+// evaluated as v*v (its correctly rounded value). Against glibc these differ by <= 1.5 ulp in a few
+// percent of calls: lengths and way-points agree to ~1e-14; where two mirror-image words tie exactly
+// in real arithmetic (about 1 % of random queries) the reference's winner is decided by libm rounding
+// noise and may be the other, equally long, word ("Numerics").
 #pragma once
 #include "avp_device.h"
+#include "../../include/avp_libm.h"
 
 enum { RS_S = 0, RS_L = 1, RS_R = 2 };
 #define RS_KEEP_MAX 24
@@ -62,7 +66,7 @@ AVP_D void rs_set_path(RsKeep& k, uint32_t code, int n, double l0, double l1, do
     if (idx == 0 || Lm <= k.bestL) { k.bestL = Lm; k.best = idx; k.bestLn = L; }
 }
 
-AVP_D void rs_polar(double x, double y, double& r, double& th) { r = avp_hypot(x, y); th = atan2(y, x); }
+AVP_D void rs_polar(double x, double y, double& r, double& th) { r = avp_hypot(x, y); th = avp_atan2(y, x); }
 
 // rs_curve.py:159-167
 AVP_D bool rs_LSL(double x, double y, double phi, double& t, double& u, double& v)
@@ -83,7 +87,7 @@ AVP_D bool rs_LSR(double x, double y, double phi, double& t, double& u, double& 
     u1 = u1 * u1;
     if (u1 >= 4.0) {
         const double uu = sqrt(u1 - 4.0);
-        const double theta = atan2(2.0, uu);
+        const double theta = avp_atan2(2.0, uu);
         const double tt = avp_M(t1 + theta);
         const double vv = avp_M(tt - phi);
         if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
@@ -96,7 +100,7 @@ AVP_D bool rs_LRL(double x, double y, double phi, double& t, double& u, double& 
     double u1, t1;
     rs_polar(x - avp_sin(phi), y - 1.0 + avp_cos(phi), u1, t1);
     if (u1 <= 4.0) {
-        const double uu = -2.0 * asin(0.25 * u1);
+        const double uu = -2.0 * avp_asin(0.25 * u1);
         const double tt = avp_M(t1 + 0.5 * uu + AVP_PI);
         const double vv = avp_M(phi - tt + uu);
         if (tt >= 0.0 && uu <= 0.0) { t = tt; u = uu; v = vv; return true; }
@@ -108,16 +112,16 @@ AVP_D bool rs_SLS(double x, double y, double phi, double& t, double& u, double& 
 {
     phi = avp_M(phi);
     if (y > 0.0 && 0.0 < phi && phi < AVP_PI * 0.99) {
-        const double xd = -y / tan(phi) + x;
-        t = xd - tan(phi / 2.0);
+        const double xd = -y / avp_tan(phi) + x;
+        t = xd - avp_tan(phi / 2.0);
         u = phi;
-        v = sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        v = sqrt((x - xd) * (x - xd) + y * y) - avp_tan(phi / 2.0);
         return true;
     } else if (y < 0.0 && 0.0 < phi && phi < AVP_PI * 0.99) {
-        const double xd = -y / tan(phi) + x;
-        t = xd - tan(phi / 2.0);
+        const double xd = -y / avp_tan(phi) + x;
+        t = xd - avp_tan(phi / 2.0);
         u = phi;
-        v = -sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        v = -sqrt((x - xd) * (x - xd) + y * y) - avp_tan(phi / 2.0);
         return true;
     }
     return false;
@@ -128,7 +132,7 @@ AVP_D void rs_tauOmega(double u, double v, double xi, double eta, double phi, do
     const double delta = avp_M(u - v);
     const double A = avp_sin(u) - avp_sin(delta);
     const double B = avp_cos(u) - avp_cos(delta) - 1.0;
-    const double t1 = atan2(eta * A - xi * B, xi * A + eta * B);
+    const double t1 = avp_atan2(eta * A - xi * B, xi * A + eta * B);
     const double t2 = 2.0 * (avp_cos(delta) - avp_cos(v) - avp_cos(u)) + 3.0;
     tau = t2 < 0 ? avp_M(t1 + AVP_PI) : avp_M(t1);
     omega = avp_M(tau - u + v - phi);
@@ -139,7 +143,7 @@ AVP_D bool rs_LRLRn(double x, double y, double phi, double& t, double& u, double
     const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
     const double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
     if (rho <= 1.0) {
-        const double uu = acos(rho);
+        const double uu = avp_acos(rho);
         double tt, vv;
         rs_tauOmega(uu, -uu, xi, eta, phi, tt, vv);
         if (tt >= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
@@ -152,7 +156,7 @@ AVP_D bool rs_LRLRp(double x, double y, double phi, double& t, double& u, double
     const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
     const double rho = (20.0 - xi * xi - eta * eta) / 16.0;
     if (0.0 <= rho && rho <= 1.0) {
-        const double uu = -acos(rho);
+        const double uu = -avp_acos(rho);
         if (uu >= -0.5 * AVP_PI) {
             double tt, vv;
             rs_tauOmega(uu, uu, xi, eta, phi, tt, vv);
@@ -182,7 +186,7 @@ AVP_D bool rs_LRSL(double x, double y, double phi, double& t, double& u, double&
     if (rho >= 2.0) {
         const double r = sqrt(rho * rho - 4.0);
         const double uu = 2.0 - r;
-        const double tt = avp_M(theta + atan2(r, -2.0));
+        const double tt = avp_M(theta + avp_atan2(r, -2.0));
         const double vv = avp_M(phi - 0.5 * AVP_PI - tt);
         if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
     }
@@ -197,7 +201,7 @@ AVP_D bool rs_LRSLR(double x, double y, double phi, double& t, double& u, double
     if (rho >= 2.0) {
         const double uu = 4.0 - sqrt(rho * rho - 4.0);
         if (uu <= 0.0) {
-            const double tt = avp_M(atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
+            const double tt = avp_M(avp_atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
             const double vv = avp_M(tt - phi);
             if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
         }

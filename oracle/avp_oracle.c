@@ -27,6 +27,19 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* "portable" mode: atan2/asin/acos/tan come from include/avp_libm.h (the functions the device
+ * compiles) and pow(v, 2.0) becomes v*v, so that this oracle is bit-identical to the HIP path.
+ * Default (0) = glibc libm = the reference's arithmetic, pinned by the golden vectors. */
+#include "../include/avp_libm.h"
+static int g_portable = 0;
+ORC_API void orc_set_portable(int v) { g_portable = v; }
+ORC_API int orc_get_portable(void) { return g_portable; }
+#define ATAN2(y, x) (g_portable ? avp_atan2((y), (x)) : atan2((y), (x)))
+#define ASIN(x) (g_portable ? avp_asin(x) : asin(x))
+#define ACOS(x) (g_portable ? avp_acos(x) : acos(x))
+#define TAN(x) (g_portable ? avp_tan(x) : tan(x))
+#define POW2(v) (g_portable ? (v) * (v) : pow((v), 2.0))
+
 /* ------------------------------------------------------------------------------------------ */
 /* context: map + vehicle + config                                                            */
 typedef struct {
@@ -220,8 +233,8 @@ ORC_API int32_t orc_check_circle(const orc_ctx *c, double x, double y, double th
         double px = c->ox[p], py = c->oy[p];
         if (!(px > left && px < right)) continue;
         if (!(py > down && py < upper)) continue;
-        if (sqrt(pow(px - fx, 2.0) + pow(py - fy, 2.0)) <= Rd) { hit = 1; break; }
-        else if (sqrt(pow(px - rx, 2.0) + pow(py - ry, 2.0)) <= Rd) { hit = 1; break; }
+        if (sqrt(POW2(px - fx) + POW2(py - fy)) <= Rd) { hit = 1; break; }
+        else if (sqrt(POW2(px - rx) + POW2(py - ry)) <= Rd) { hit = 1; break; }
     }
     return hit;
 }
@@ -271,7 +284,7 @@ static void set_path(rs_set *s, int n, const double *len, const int8_t *ty)
     for (int i = 0; i < n; i++) { p->t[i] = ty[i]; p->l[i] = len[i]; }
 }
 
-static void polar(double x, double y, double *r, double *th) { *r = py_hypot(x, y); *th = atan2(y, x); }
+static void polar(double x, double y, double *r, double *th) { *r = py_hypot(x, y); *th = ATAN2(y, x); }
 
 /* rs_curve.py:159-167 */
 static int LSL(double x, double y, double phi, double *t, double *u, double *v)
@@ -289,10 +302,10 @@ static int LSR(double x, double y, double phi, double *t, double *u, double *v)
 {
     double u1, t1;
     polar(x + sin(phi), y - 1.0 - cos(phi), &u1, &t1);
-    u1 = pow(u1, 2.0);
+    u1 = POW2(u1);
     if (u1 >= 4.0) {
         double uu = sqrt(u1 - 4.0);
-        double theta = atan2(2.0, uu);
+        double theta = ATAN2(2.0, uu);
         double tt = orc_M(t1 + theta);
         double vv = orc_M(tt - phi);
         if (tt >= 0.0 && vv >= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
@@ -305,7 +318,7 @@ static int LRL(double x, double y, double phi, double *t, double *u, double *v)
     double u1, t1;
     polar(x - sin(phi), y - 1.0 + cos(phi), &u1, &t1);
     if (u1 <= 4.0) {
-        double uu = -2.0 * asin(0.25 * u1);
+        double uu = -2.0 * ASIN(0.25 * u1);
         double tt = orc_M(t1 + 0.5 * uu + PI);
         double vv = orc_M(phi - tt + uu);
         if (tt >= 0.0 && uu <= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
@@ -317,16 +330,16 @@ static int SLS(double x, double y, double phi, double *t, double *u, double *v)
 {
     phi = orc_M(phi);
     if (y > 0.0 && 0.0 < phi && phi < PI * 0.99) {
-        double xd = -y / tan(phi) + x;
-        *t = xd - tan(phi / 2.0);
+        double xd = -y / TAN(phi) + x;
+        *t = xd - TAN(phi / 2.0);
         *u = phi;
-        *v = sqrt(pow(x - xd, 2.0) + pow(y, 2.0)) - tan(phi / 2.0);
+        *v = sqrt(POW2(x - xd) + POW2(y)) - TAN(phi / 2.0);
         return 1;
     } else if (y < 0.0 && 0.0 < phi && phi < PI * 0.99) {
-        double xd = -y / tan(phi) + x;
-        *t = xd - tan(phi / 2.0);
+        double xd = -y / TAN(phi) + x;
+        *t = xd - TAN(phi / 2.0);
         *u = phi;
-        *v = -sqrt(pow(x - xd, 2.0) + pow(y, 2.0)) - tan(phi / 2.0);
+        *v = -sqrt(POW2(x - xd) + POW2(y)) - TAN(phi / 2.0);
         return 1;
     }
     return 0;
@@ -337,7 +350,7 @@ static void calc_tauOmega(double u, double v, double xi, double eta, double phi,
     double delta = orc_M(u - v);
     double A = sin(u) - sin(delta);
     double B = cos(u) - cos(delta) - 1.0;
-    double t1 = atan2(eta * A - xi * B, xi * A + eta * B);
+    double t1 = ATAN2(eta * A - xi * B, xi * A + eta * B);
     double t2 = 2.0 * (cos(delta) - cos(v) - cos(u)) + 3.0;
     if (t2 < 0) *tau = orc_M(t1 + PI); else *tau = orc_M(t1);
     *omega = orc_M(*tau - u + v - phi);
@@ -348,7 +361,7 @@ static int LRLRn(double x, double y, double phi, double *t, double *u, double *v
     double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
     double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
     if (rho <= 1.0) {
-        double uu = acos(rho), tt, vv;
+        double uu = ACOS(rho), tt, vv;
         calc_tauOmega(uu, -uu, xi, eta, phi, &tt, &vv);
         if (tt >= 0.0 && vv <= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
     }
@@ -360,7 +373,7 @@ static int LRLRp(double x, double y, double phi, double *t, double *u, double *v
     double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
     double rho = (20.0 - xi * xi - eta * eta) / 16.0;
     if (0.0 <= rho && rho <= 1.0) {
-        double uu = -acos(rho);
+        double uu = -ACOS(rho);
         if (uu >= -0.5 * PI) {
             double tt, vv;
             calc_tauOmega(uu, uu, xi, eta, phi, &tt, &vv);
@@ -388,7 +401,7 @@ static int LRSL(double x, double y, double phi, double *t, double *u, double *v)
     if (rho >= 2.0) {
         double r = sqrt(rho * rho - 4.0);
         double uu = 2.0 - r;
-        double tt = orc_M(theta + atan2(r, -2.0));
+        double tt = orc_M(theta + ATAN2(r, -2.0));
         double vv = orc_M(phi - 0.5 * PI - tt);
         if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
     }
@@ -402,7 +415,7 @@ static int LRSLR(double x, double y, double phi, double *t, double *u, double *v
     if (rho >= 2.0) {
         double uu = 4.0 - sqrt(rho * rho - 4.0);
         if (uu <= 0.0) {
-            double tt = orc_M(atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
+            double tt = orc_M(ATAN2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
             double vv = orc_M(tt - phi);
             if (tt >= 0.0 && vv >= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
         }
@@ -1041,7 +1054,7 @@ ORC_API int32_t orc_plan(const orc_ctx *c, const double start[3], const double g
         /* try_reach_goal :300-316 */
         collision = 0; in_radius = 0; rs_valid = 0;
         double ddx = cn.x - a->goal[0], ddy = cn.y - a->goal[1];
-        double distance = sqrt(pow(ddx, 2.0) + pow(ddy, 2.0));
+        double distance = sqrt(POW2(ddx) + POW2(ddy));
         if (distance < c->flag_radius) {
             in_radius = 1;
             /* try_rs_curve :318-349 */

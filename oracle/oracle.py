@@ -77,6 +77,8 @@ def lib():
         L.orc_dij_nclosed.restype = C.c_int64
         L.orc_dij_nclosed.argtypes = [C.c_void_p]
         L.orc_dij_dump.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orc_set_portable.argtypes = [C.c_int]
+        L.orc_get_portable.restype = C.c_int
         L.orc_plan.restype = C.c_int32
         L.orc_split_path.restype = C.c_int32
         _LIB = L
@@ -85,6 +87,23 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class portable_libm:
+    """Context manager: run the oracle with the portable atan2/asin/acos/tan of include/avp_libm.h
+    (bit-identical to the device path) instead of glibc's (the reference's arithmetic)."""
+
+    def __init__(self, on: bool = True):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        self.prev = lib().orc_get_portable()
+        lib().orc_set_portable(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_portable(self.prev)
+        return False
 
 
 class Oracle:
