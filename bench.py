@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- hybrid-A* plans/s on batched poses (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the hot path over one batch: every rank plans its own 256 random
+(start, goal) pairs on the Case1 map (BASELINE config[1]; weak scaling, seeds differ per rank)
+with inputs resident in HBM, then the fixed-stride results are gathered to rank 0 (the only
+collective of the data path, RCCL over xGMI). The map is built once on rank 0 and broadcast
+before the timed region. Pop cap per problem: 1000 (the reference has no cap and needs hours on
+the ~20 % of random pairs whose goal cannot be reached; see DESIGN.md "Workload").
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 256
+POP_CAP = 1000
+MAX_NODES = 16384
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from automatedvaletparking_amd import costmap, config, sampling, _native, path_planner, distributed as avd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    cfg = config.default_config()
+    veh = costmap.Vehicle()
+    m = None
+    if rank == 0:
+        m = costmap.Map(file=os.path.join(ROOT, "data", "BenchmarkCases", "Case1.csv"), discrete_size=cfg["map_discrete_size"])
+    m = avd.broadcast_map(m, src=0)          # RCCL broadcast of the packed costmap (setup, untimed)
+    dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=POP_CAP)
+    bp = path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=256)
+
+    # synthetic poses: SURVEY 8(d) sampler, footprint-free start/goal pairs
+    chk_dm = dm
+
+    def gpu_check(x, y, t):
+        return bool(chk_dm.check_batch(np.array([[x, y, t]]))[0])
+
+    rng = np.random.default_rng(20260927 + rank)
+    cand = sampling.sample_free_poses(m.boundary, m.case.obs, 4 * BATCH, rng, margin=6.0, reject=False)
+    hit = dm.check_batch(cand)
+    free = [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
+    assert len(free) >= 2 * BATCH
+    poses = np.array(free[:2 * BATCH])
+    starts, goals = poses[0::2], poses[1::2]
+    st_t, go_t = dm.dev_tensor(starts), dm.dev_tensor(goals)
+
+    rec_stride = path_planner.RESULT_DTYPE.itemsize
+    gathered = torch.empty((world, BATCH, rec_stride), dtype=torch.uint8, device=f"cuda:{local}") if world > 1 else None
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        res, paths, _ = bp.plan_dev(st_t, go_t, want_paths=True)
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, res[:BATCH].contiguous())   # final gather of the solved records
+        return res, paths
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        res, paths = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    rec = res.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:BATCH]
+    pops_local = int(rec["n_pops"].sum())
+    if world > 1:
+        pt = torch.tensor([pops_local], dtype=torch.int64, device=f"cuda:{local}")
+        dist.all_reduce(pt)
+        pops_total = int(pt.item())
+    else:
+        pops_total = pops_local
+
+    if rank == 0:
+        plans = BATCH * world * a.steps
+        value = plans / elapsed
+        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        # algorithmic bytes of one plan_kernel launch: U2 per pop + U3 per heuristic sweep
+        B_cc = 16 * dm.P + 25
+        alg = (float(rec["n_checks"].sum()) * B_cc
+               + 240.0 * float((rec["n_pops"].astype(np.float64) * (rec["n_closed"] + rec["n_open"]) / 2).sum())
+               + 680.0 * float(rec["n_pops"].sum()) + 16.0 * float(rec["h_cells"].sum()))
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "hybrid-A* plans/sec, batched poses", "value": value, "unit": "plans/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Case1 map, 256 random start/goal pairs per GPU (config[1]), pop cap 1000",
+                       "batch_per_gpu": BATCH, "pop_cap": POP_CAP, "obstacle_points": dm.P, "parallelism": f"shard{world}"},
+            "expansions_per_s": pops_total * a.steps / elapsed,
+            "solved_frac": float((rec["status"] == 0).mean()), "iter_limit_frac": float((rec["status"] == 4).mean()),
+            "roofline": {"kernel": "plan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launch_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        # secondary: the footprint-collision kernel alone (north_star's >= 40 % target), measured live
+        n_chk = 1 << 20
+        cp = np.stack([rng.uniform(m.boundary[0] + 6, m.boundary[1] - 6, n_chk), rng.uniform(m.boundary[2] + 6, m.boundary[3] - 6, n_chk),
+                       rng.uniform(-np.pi, np.pi, n_chk)], 0)
+        ct = dm.dev_tensor(cp)
+        co = dm.empty(n_chk, torch.uint8)
+        dm.check_batch_dev(ct[0], ct[1], ct[2], out=co)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dm.check_batch_dev(ct[0], ct[1], ct[2], out=co)
+        e1.record()
+        torch.cuda.synchronize()
+        cms = e0.elapsed_time(e1) / 10
+        cg = n_chk * B_cc / (cms * 1e-3) / 1e9
+        out["roofline_check"] = {"kernel": "check_distance_kernel", "bound": "hbm", "achieved": cg, "peak": HBM_PEAK_GBPS,
+                                 "unit": "GB/s", "frac": cg / HBM_PEAK_GBPS, "traffic": None, "launch_ms": cms,
+                                 "checks_per_s": n_chk / (cms * 1e-3), "bytes_per_check": B_cc}
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import oracle
+            o = oracle.Oracle(m, veh, cfg, max_pops=POP_CAP)
+            t1 = time.perf_counter()
+            pops_cpu = 0
+            for s_, g_ in zip(starts, goals):
+                pops_cpu += o.plan(s_, g_, max_trace=1)["n_pops"]
+            tc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": BATCH / tc, "unit": "plans/s", "cores": 1, "kind": "port",
+                                   "sample": f"the same {BATCH} problems, pop cap {POP_CAP}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s",
+                                   "expansions_per_s": pops_cpu / tc}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
