@@ -167,10 +167,23 @@ AVP_HD double avp_pi_2_pi(double theta)
     return theta;
 }
 
+// theta % (2*pi) with CPython semantics. For |theta| < 4*pi the quotient is 0 or +-1 and theta -+ 2*pi
+// is exact (Sterbenz), so fmod's exact remainder is obtained without the generic loop.
+AVP_HD double avp_pymod_2pi(double theta)
+{
+    const double w = 2.0 * AVP_PI;
+    const double a = fabs(theta);
+    if (!(a < 2.0 * w)) return avp_pymod(theta, w);
+    double mod = a < w ? theta : (theta < 0 ? theta + w : theta - w);     // == fmod(theta, w), sign of theta
+    if (mod != 0.0) { if (mod < 0) mod += w; }
+    else mod = 0.0;                                                         // copysign(0.0, w)
+    return mod;
+}
+
 // path_plan/rs_curve.py:669-680
 AVP_HD double avp_M(double theta)
 {
-    double phi = avp_pymod(theta, 2.0 * AVP_PI);
+    double phi = avp_pymod_2pi(theta);
     if (phi < -AVP_PI) phi += 2.0 * AVP_PI;
     if (phi > AVP_PI) phi -= 2.0 * AVP_PI;
     return phi;

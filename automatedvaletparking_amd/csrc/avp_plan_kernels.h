@@ -28,11 +28,18 @@
 #define PL_QCAP 32768                 // entries per rotating bucket queue
 #define PL_NQ 4                       // rotating bucket queues
 #define PL_MAXCHILD 32
-#define PL_RSQ 10                     // RS queries evaluated per pass (46 words each)
+#define PL_RSQ 11                     // RS queries evaluated per pass (46 words each): the shot + 10 children
+#define PL_CHK_MAX 160                // poses per cooperative collision pass
+#define PL_CHK_QCAP 12288             // (pose, obstacle point) candidates per pass
 #define PL_RS_CAP 1024                // samples of one RS shot
 #define PL_UNSEEN 0x7fffffffu
 #define PL_TRACE_W 11
 #define PL_FLAG_T 1
+// phase timers (thread 0, s_memtime): init, heap pop, shot words+fold, shot sampling, shot checks,
+// children poses + sub-step checks, children RS, sequential resolution, of which sweep, finish
+enum { PH_INIT = 0, PH_POP, PH_SHOT_RS, PH_SHOT_SAMPLE, PH_SHOT_CHECK, PH_CHILD, PH_CHILD_RS, PH_RESOLVE, PH_SWEEP, PH_FINISH };
+#define PH_T0() const long long ph_t0_ = clock64()
+#define PH_ADD(k) do { if (threadIdx.x == 0) s.phase[k] += clock64() - ph_t0_; } while (0)
 
 struct PlNode {
     double x, y, th, g, h, f;
@@ -49,6 +56,7 @@ struct avp_plan_result_dev {          // mirrors avp_plan_result in include/avp.
     double rs_L;
     double rs_start[3];               // RS sample 0 (the popped node's pose)
     int32_t rs_dir0, pad;
+    int64_t phase_cycles[10];         // diagnostics: shader cycles per phase (see PH_* below)
 };
 
 struct PlanWs {                       // per-slot workspace carve (device pointers)
@@ -180,7 +188,7 @@ struct PlShared {
     int32_t E;                        // buckets [0, E) are expanded
     uint32_t qcount[PL_NQ];
     int32_t qover;
-    uint32_t dF; int64_t idF;         // key of the last miss (closed frontier), dF = 0xffffffff before the first
+    uint32_t dF; int64_t idF;         // key of the last miss (closed frontier)
     int32_t hasF;
     int64_t h_cells, h_misses;
     // A*
@@ -194,13 +202,32 @@ struct PlShared {
     int32_t rs_status, rs_npts, rs_first_coll, in_radius, collision;
     RsPath rs;                        // normalised winner of the shot
     int64_t n_checks, n_rs;
+    long long phase[10];
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
+    // sequential child resolution state machine (thread 0 runs alone between sweep extensions)
+    int32_t next_child, need_sweep, have_d;
+    int64_t pending_id;
     PlChild child[PL_MAXCHILD];
-    // RS word results: [query][word] ok + 5 lengths
+    // RS word results: [query][word] ok + 5 lengths; kept candidates per query
     uint8_t w_ok[PL_RSQ * 46];
     double w_l[PL_RSQ * 46][5];
+    RsKeep keep[PL_RSQ];
+    // RS sampling: per output index the last writer (length argument, segment), segment origins
+    int32_t smp_hi, smp_point_num;
+    double smp_l[PL_RS_CAP];
+    int8_t smp_seg[PL_RS_CAP];
+    double seg_o[AVP_RS_MAXSEG][3];
+    // cooperative collision pass
+    int32_t chk_qn, chk_qover;
+    double chk_pose[PL_CHK_MAX][3];
+    Footprint chk_fp[PL_CHK_MAX];
+    int16_t chk_rng[PL_CHK_MAX][4];   // ixlo, ncol, iylo, iyhi
+    uint32_t chk_hit[PL_CHK_MAX];
+    uint32_t chk_q[PL_CHK_QCAP];      // pose << 24 | ix << 12 | iy   (nx, ny < 4096 on this path)
 };
+
+static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
 
 AVP_D int32_t pl_bucket(uint32_t d) { return (int32_t)(d / 10u); }
 
@@ -313,6 +340,7 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, PlShared& s, int col, int 
 // Expand bucket s.E (all threads). Each thread handles (entry, neighbour) pairs.
 AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
 {
+    const long long t_sw = clock64();
     const int q = s.E & (PL_NQ - 1);
     const uint32_t cnt = min(s.qcount[q], (uint32_t)PL_QCAP);
     __syncthreads();
@@ -334,29 +362,27 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
         pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { s.qcount[q] = 0; s.E += 1; }
+    if (threadIdx.x == 0) { s.qcount[q] = 0; s.E += 1; s.phase[PH_SWEEP] += clock64() - t_sw; }
     __syncthreads();
 }
 
-// Collective heuristic query (hybrid_a_star.py:268-283 + compute_h.py:198-214). All threads call
-// it with the same id; result in s.hq_d (PL_UNSEEN = unreachable). force_miss: the initial
-// compute_path(x0, y0) of hybrid_a_star.__init__ (:89-91), which always runs the sweep.
-AVP_D void pl_hquery(const DevMap& m, const PlanWs& w, PlShared& s, int64_t id, bool force_miss)
+// Heuristic query (hybrid_a_star.py:268-283 + compute_h.py:198-214), split in two:
+//  pl_hquery_hit : pure test against the closed frontier, callable by a single thread;
+//  pl_hquery_miss: collective sweep extension until the cell's distance is final (all threads).
+// force_miss: the initial compute_path(x0, y0) of hybrid_a_star.__init__ (:89-91) always sweeps.
+AVP_D bool pl_hquery_hit(const DevMap& m, const PlanWs& w, const PlShared& s, int64_t id, uint32_t& d_out)
+{
+    if (id == s.goal_id) { d_out = 0; return true; }                 // first closedlist entry: the goal Grid, distance 0
+    if (!(id >= 0 && id < (int64_t)m.S * (m.Sy + 3))) { d_out = PL_UNSEEN; return true; }
+    const uint32_t d = w.dist[id];
+    if (s.hasF && d != PL_UNSEEN && (d < s.dF || (d == s.dF && id <= s.idF))) { d_out = d; return true; }
+    return false;
+}
+
+AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, PlShared& s, int64_t id)
 {
     __syncthreads();
-    const bool in_range = id >= 0 && id < (int64_t)m.S * (m.Sy + 3);
-    if (threadIdx.x == 0) {
-        s.hq_flag = 0;
-        if (!force_miss && id == s.goal_id) { s.hq_d = 0; s.hq_flag = 1; }
-        else if (!in_range) { s.hq_d = PL_UNSEEN; s.hq_flag = 1; }
-        else {
-            const uint32_t d = w.dist[id];
-            if (!force_miss && s.hasF && d != PL_UNSEEN && (d < s.dF || (d == s.dF && id <= s.idF))) { s.hq_d = d; s.hq_flag = 1; }
-        }
-    }
-    __syncthreads();
-    if (s.hq_flag) return;
-    // miss: extend the sweep until the cell's distance is final
+    if (!(id >= 0 && id < (int64_t)m.S * (m.Sy + 3))) { if (threadIdx.x == 0) s.hq_d = PL_UNSEEN; __syncthreads(); return; }
     for (;;) {
         const uint32_t d = w.dist[id];
         if (d != PL_UNSEEN && pl_bucket(d) <= s.E) break;
@@ -409,9 +435,9 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
     }
     __syncthreads();
 }
-AVP_D int pl_rs_fold(const PlShared& s, const avp_params& p, int q, RsPath& out)
+AVP_D int pl_rs_fold(PlShared& s, const avp_params& p, int q, RsPath& out)
 {
-    RsKeep k;
+    RsKeep& k = s.keep[q];
     rs_keep_init(k, p.maxc);
     for (int wd = 0; wd < 46 && !k.err; wd++) {
         const int t = q * 46 + wd;
@@ -423,6 +449,139 @@ AVP_D int pl_rs_fold(const PlShared& s, const avp_params& p, int q, RsPath& out)
     return rs_keep_result(k, out);
 }
 
+// ---- parallel Reeds-Shepp sampling (rs_curve.py:537-594 + :125-131) ---------------------------------
+// Thread 0 replays the index bookkeeping of generate_local_course (which output index each
+// interpolate() call writes; later writes overwrite earlier ones) and chains the segment origins;
+// all threads then evaluate the interpolations, thread 0 trims the trailing px == 0.0 entries and
+// all threads apply the world transform. Results (x, y, pi_2_pi(yaw)) in w.rsbuf, dirs in w.rsdir.
+AVP_D void pl_rs_sample(const PlanWs& w, PlShared& s, const avp_params& p, double q0x, double q0y, double q0t)
+{
+    const double maxc = p.maxc;
+    if (threadIdx.x == 0) {
+        const RsPath& rp = s.rs;
+        const double step = 0.5 * maxc;
+        const int point_num = (int)(rp.L / step) + rp.n + 3;
+        s.smp_point_num = point_num;
+        s.smp_hi = 0;
+        if (point_num > PL_RS_CAP) s.rs_status = 5;
+        else {
+            int ind = 1, hi = 0;
+            double d = rp.l[0] > 0.0 ? step : -step;
+            double pd = d, ll = 0.0;
+            double ox = 0.0, oy = 0.0, oyaw = 0.0;               // px[1] before any write
+            int end_ind = -1;                                     // index holding the previous segment's end
+            for (int i = 0; i < rp.n; i++) {
+                const double l = rp.l[i];
+                d = l > 0.0 ? step : -step;
+                // origin = px[ind]: the previous segment's end point if that is what index `ind` holds
+                s.seg_o[i][0] = ox; s.seg_o[i][1] = oy; s.seg_o[i][2] = oyaw;
+                ind -= 1;
+                if (i >= 1 && (rp.l[i - 1] * rp.l[i]) > 0) pd = -d - ll; else pd = d - ll;
+                while (fabs(pd) <= fabs(l)) {
+                    ind += 1;
+                    s.smp_l[ind] = pd; s.smp_seg[ind] = (int8_t)i;
+                    pd += d;
+                }
+                ll = l - pd - d;
+                ind += 1;
+                s.smp_l[ind] = l; s.smp_seg[ind] = (int8_t)i;
+                if (ind > hi) hi = ind;
+                end_ind = ind;
+                // next origin = this segment's end point
+                double ex, ey, eyaw;
+                rs_interpolate(l, rp.t[i], maxc, ox, oy, oyaw, ex, ey, eyaw);
+                ox = ex; oy = ey; oyaw = eyaw;
+            }
+            (void)end_ind;
+            s.smp_hi = hi;
+        }
+    }
+    __syncthreads();
+    if (s.rs_status) return;
+    const int point_num = s.smp_point_num, hi = s.smp_hi;
+    for (int i = threadIdx.x; i < point_num; i += PL_THREADS) {
+        double px = 0.0, py = 0.0, pyaw = 0.0;
+        int8_t dr = 0;
+        if (i == 0) dr = s.rs.l[0] > 0.0 ? 1 : -1;
+        else if (i <= hi) {
+            const int sg = s.smp_seg[i];
+            const double l = s.smp_l[i];
+            rs_interpolate(l, s.rs.t[sg], maxc, s.seg_o[sg][0], s.seg_o[sg][1], s.seg_o[sg][2], px, py, pyaw);
+            dr = l > 0.0 ? 1 : -1;
+        }
+        w.rsbuf[3 * i] = px; w.rsbuf[3 * i + 1] = py; w.rsbuf[3 * i + 2] = pyaw; w.rsdir[i] = dr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int np = point_num;
+        while (np > 0 && w.rsbuf[3 * (np - 1)] == 0.0) np--;
+        s.rs_npts = np;
+    }
+    __syncthreads();
+    const double cm = avp_cos(-q0t), sm = avp_sin(-q0t);
+    for (int i = threadIdx.x; i < s.rs_npts; i += PL_THREADS) {
+        const double ix = w.rsbuf[3 * i], iy = w.rsbuf[3 * i + 1];
+        w.rsbuf[3 * i] = cm * ix + sm * iy + q0x;
+        w.rsbuf[3 * i + 1] = -sm * ix + cm * iy + q0y;
+        w.rsbuf[3 * i + 2] = avp_pi_2_pi(w.rsbuf[3 * i + 2] + q0t);
+    }
+    __syncthreads();
+}
+
+// ---- cooperative collision pass over s.chk_pose[0..N) -> s.chk_hit (all threads) ---------------------
+// distance_checker semantics (collision_check.py:144-240). The work of a pose is spread over the
+// workgroup: one thread per (pose, map column under the AABB) gathers the near obstacle points from
+// the column bitmaps into an LDS queue, then one thread per (pose, point) runs the exact test.
+AVP_D void pl_check_set(const DevMap& m, const avp_params& p, PlShared& s, int N)
+{
+    const int tid = threadIdx.x;
+    if (p.checker_kind == 1) {
+        for (int i = tid; i < N; i += PL_THREADS) s.chk_hit[i] = pl_check_pose(m, p, s.chk_pose[i][0], s.chk_pose[i][1], s.chk_pose[i][2]) ? 1u : 0u;
+        __syncthreads();
+        return;
+    }
+    if (tid == 0) { s.chk_qn = 0; s.chk_qover = 0; }
+    for (int i = tid; i < N; i += PL_THREADS) {
+        Footprint f;
+        avp_footprint_setup(p, s.chk_pose[i][0], s.chk_pose[i][1], s.chk_pose[i][2], f);
+        double xmin, xmax, ymin, ymax;
+        avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
+        const int ixlo = avp_first_ge(m.X, m.nx, m.b0, m.dx, xmin), ixhi = avp_last_le(m.X, m.nx, m.b0, m.dx, xmax);
+        const int iylo = avp_first_ge(m.Y, m.ny, m.b2, m.dy, ymin), iyhi = avp_last_le(m.Y, m.ny, m.b2, m.dy, ymax);
+        int ncol = ixhi - ixlo + 1;
+        if (ncol < 0 || iylo > iyhi) ncol = 0;
+        s.chk_fp[i] = f;
+        s.chk_rng[i][0] = (int16_t)ixlo; s.chk_rng[i][1] = (int16_t)ncol; s.chk_rng[i][2] = (int16_t)iylo; s.chk_rng[i][3] = (int16_t)iyhi;
+        s.chk_hit[i] = 0;
+    }
+    __syncthreads();
+    for (int t = tid; t < N * 64; t += PL_THREADS) {
+        const int i = t >> 6, c = t & 63;
+        if (c >= s.chk_rng[i][1]) continue;
+        const int ix = s.chk_rng[i][0] + c, iylo = s.chk_rng[i][2], iyhi = s.chk_rng[i][3];
+        for (int wd = iylo >> 6; wd <= (iyhi >> 6); wd++) {
+            uint64_t bits = m.colBits[(size_t)ix * m.wpc + wd];
+            if (wd == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
+            if (wd == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
+            if (!bits) continue;
+            const int cnt = __popcll(bits);
+            int pos = atomicAdd(&s.chk_qn, cnt);
+            if (pos + cnt > PL_CHK_QCAP) { s.chk_qover = 1; continue; }
+            const uint32_t tag = ((uint32_t)i << 24) | ((uint32_t)ix << 12);
+            while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; s.chk_q[pos++] = tag | (uint32_t)((wd << 6) + bpos); }
+        }
+    }
+    __syncthreads();
+    const int qn = min(s.chk_qn, PL_CHK_QCAP);
+    for (int e = tid; e < qn; e += PL_THREADS) {
+        const uint32_t ent = s.chk_q[e];
+        const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
+        if (s.chk_hit[i]) continue;
+        if (avp_footprint_point_hit(s.chk_fp[i], m.X[ix], m.Y[iy])) s.chk_hit[i] = 1;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                           const double* __restrict__ goals, int64_t n, int32_t maxNodes,
                                                           char* __restrict__ workspace, unsigned int* __restrict__ counter,
@@ -430,7 +589,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                                           double* __restrict__ paths, int32_t max_path,
                                                           double* __restrict__ trace, int32_t max_trace)
 {
-    __shared__ PlShared s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
     const int tid = threadIdx.x;
@@ -447,6 +607,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
 
         // ---- init ------------------------------------------------------------------------------
+        const long long t_init0 = clock64();
         for (int64_t i = tid; i < dims.idCap; i += PL_THREADS) { w.dist[i] = PL_UNSEEN; w.flags[i] = 0; }
         for (int64_t i = tid; i < dims.rowCap; i += PL_THREADS) w.aliasKey[i] = ~0ull;
         for (int64_t i = tid; i < dims.hashCap; i += PL_THREADS) w.hash[i] = 0;
@@ -455,6 +616,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             for (int q = 0; q < PL_NQ; q++) s.qcount[q] = 0;
             s.h_cells = 0; s.h_misses = 0; s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0;
             s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
+            for (int k = 0; k < 10; k++) s.phase[k] = 0;
             s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
             s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
             // lattice anchored at the goal: columns/rows reachable by repeated +-pitch (compute_h.py:89-186)
@@ -502,7 +664,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
             // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
             const int64_t sid = avp_pos_to_index(m, sx, sy);
-            pl_hquery(m, w, s, sid, true);
+            pl_hquery_miss(m, w, s, sid);
             if (tid == 0) {
                 if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
                 else {
@@ -517,10 +679,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
         }
 
+        if (tid == 0) s.phase[PH_INIT] += clock64() - t_init0;
         int64_t n_pops = 0;
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
         while (s.status == 0 && !s.done) {
             __syncthreads();
+            { PH_T0();
             if (tid == 0) {
                 if (s.nheap == 0) { s.status = 1; }
                 else if (n_pops >= max_pops) { s.status = 4; }
@@ -530,6 +694,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     w.nodes[c].state = 3;
                 }
             }
+            PH_ADD(PH_POP); }
             __syncthreads();
             if (s.status != 0) break;
             const PlNode cn = w.nodes[s.cur];
@@ -541,49 +706,18 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             n_pops++;
 
-            // ---- try_reach_goal (:300-349) -------------------------------------------------------
+            // ---- children poses (expand_node :134-151) + try_reach_goal radius test (:308-312) ----------
+            const long long t_d = clock64();
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
             const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
             const bool in_radius = distance < p.flag_radius;
             if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
-            __syncthreads();
-            if (in_radius) {
-                pl_rs_words(s, p, 1, [&](int, double& x, double& y, double& th) { x = cn.x; y = cn.y; th = cn.th; });
-                if (tid == 0) {
-                    s.n_rs += 1;
-                    RsPath rp;
-                    const int st = pl_rs_fold(s, p, 0, rp);
-                    s.rs_status = st;
-                    if (!st) {
-                        s.rs = rp;
-                        const int np = rs_sample(rp, p.maxc, cn.x, cn.y, cn.th, w.rsbuf, 3, w.rsdir, PL_RS_CAP);
-                        if (np < 0) s.rs_status = 5; else s.rs_npts = np;
-                    }
-                }
-                __syncthreads();
-                if (s.rs_status) { if (tid == 0) s.status = s.rs_status == 5 ? 5 : 3; __syncthreads(); break; }
-                const int np = s.rs_npts;
-                for (int i = tid; i < np; i += PL_THREADS) {
-                    // yaw is already wrapped; pi_2_pi again as the reference does (:339)
-                    if (pl_check_pose(m, p, w.rsbuf[3 * i], w.rsbuf[3 * i + 1], avp_pi_2_pi(w.rsbuf[3 * i + 2]))) atomicMin(&s.rs_first_coll, i);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    if (s.rs_first_coll != 0x7fffffff) { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
-                    else s.n_checks += np;
-                    if (!s.collision) s.done = 1;
-                }
-                __syncthreads();
-                if (s.done) break;
-            }
-
-            // ---- expand_node (:126-241) ----------------------------------------------------------
             if (tid < nchild) {
                 PlChild& c = s.child[tid];
                 const int si = tid % p.n_steer;
                 const bool fwd = tid < p.n_steer;       // i < next_index / 2
                 const double travel = fwd ? p.travel_dt : -p.travel_dt;
-                double th_ = avp_pi_2_pi(cn.th + p.dth_dt[si]);
+                const double th_ = avp_pi_2_pi(cn.th + p.dth_dt[si]);
                 c.th = th_;
                 c.x = cn.x + travel * avp_cos(th_);
                 c.y = cn.y + travel * avp_sin(th_);
@@ -596,108 +730,165 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 c.L = 0;
             }
             __syncthreads();
-            // sub-step collision checks (:185-204): one thread per (child, sub-step)
-            for (int t = tid; t < nchild * p.n_sub; t += PL_THREADS) {
-                const int ci = t / p.n_sub, j = t - ci * p.n_sub;
-                const int si = ci % p.n_steer;
-                const bool fwd = ci < p.n_steer;
-                const double td = fwd ? p.travel_ddt[j] : -p.travel_ddt[j];
-                const double th_i = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
-                const double x_i = cn.x + td * avp_cos(th_i);
-                const double y_i = cn.y + td * avp_sin(th_i);
-                if (pl_check_pose(m, p, x_i, y_i, th_i)) atomicMin(&s.child[ci].first_coll, j);
+            const long long t_e = clock64();
+            if (tid == 0) s.phase[PH_CHILD] += t_e - t_d;
+
+            // ---- Reeds-Shepp words: query 0 = the shot from the popped node (:326-332), 1.. = children (:286-294)
+            {
+                const int nq = nchild + 1;
+                for (int base = 0; base < nq; base += PL_RSQ) {
+                    const int cnt = min(PL_RSQ, nq - base);
+                    pl_rs_words(s, p, cnt, [&](int q, double& x, double& y, double& th) {
+                        const int g = base + q;
+                        if (g == 0) { x = cn.x; y = cn.y; th = cn.th; }
+                        else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
+                    });
+                    if (tid < cnt) {
+                        const int g = base + tid;
+                        RsPath rp;
+                        const int st = pl_rs_fold(s, p, tid, rp);
+                        if (g == 0) { s.rs_status = in_radius ? st : 0; if (!st) s.rs = rp; }
+                        else { s.child[g - 1].rs_err = (int8_t)st; s.child[g - 1].L = st ? 0.0 : rp.L / p.maxc; }
+                    }
+                    __syncthreads();
+                }
             }
-            // RS length of every child to the goal (:286-294); query slot q <-> child q
-            for (int base = 0; base < nchild; base += PL_RSQ) {
-                const int cnt = min(PL_RSQ, nchild - base);
-                pl_rs_words(s, p, cnt, [&](int q, double& x, double& y, double& th) { x = s.child[base + q].x; y = s.child[base + q].y; th = s.child[base + q].th; });
-                if (tid < cnt) {
-                    RsPath rp;
-                    const int st = pl_rs_fold(s, p, tid, rp);
-                    s.child[base + tid].rs_err = (int8_t)st;
-                    s.child[base + tid].L = st ? 0.0 : rp.L / p.maxc;
+            const long long t_f0 = clock64();
+            if (tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
+            if (in_radius && s.rs_status) { if (tid == 0) s.status = s.rs_status == 4 ? 5 : 3; __syncthreads(); break; }
+
+            // ---- shot sampling ------------------------------------------------------------------------
+            if (in_radius) {
+                if (tid == 0) s.n_rs += 1;
+                pl_rs_sample(w, s, p, cn.x, cn.y, cn.th);
+                if (s.rs_status) { if (tid == 0) s.status = 5; __syncthreads(); break; }
+            }
+            const long long t_g = clock64();
+            if (tid == 0) s.phase[PH_SHOT_SAMPLE] += t_g - t_f0;
+
+            // ---- collision pass: shot samples (:335-345) then the sub-steps of every child (:185-204) ----
+            {
+                const int np = in_radius ? s.rs_npts : 0;
+                const int nsubs = nchild * p.n_sub;
+                const int total = np + nsubs;
+                for (int base = 0; base < total; base += PL_CHK_MAX) {
+                    const int cnt = min(PL_CHK_MAX, total - base);
+                    for (int k = tid; k < cnt; k += PL_THREADS) {
+                        const int g = base + k;
+                        if (g < np) {
+                            s.chk_pose[k][0] = w.rsbuf[3 * g]; s.chk_pose[k][1] = w.rsbuf[3 * g + 1];
+                            s.chk_pose[k][2] = avp_pi_2_pi(w.rsbuf[3 * g + 2]);        // :339
+                        } else {
+                            const int t = g - np;
+                            const int ci = t / p.n_sub, j = t - ci * p.n_sub;
+                            const int si = ci % p.n_steer;
+                            const double td = ci < p.n_steer ? p.travel_ddt[j] : -p.travel_ddt[j];
+                            const double th_i = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
+                            s.chk_pose[k][0] = cn.x + td * avp_cos(th_i);
+                            s.chk_pose[k][1] = cn.y + td * avp_sin(th_i);
+                            s.chk_pose[k][2] = th_i;
+                        }
+                    }
+                    __syncthreads();
+                    pl_check_set(m, p, s, cnt);
+                    if (s.chk_qover) { if (tid == 0) s.status = 5; }
+                    for (int k = tid; k < cnt; k += PL_THREADS) {
+                        if (!s.chk_hit[k]) continue;
+                        const int g = base + k;
+                        if (g < np) atomicMin(&s.rs_first_coll, g);
+                        else { const int t = g - np; const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0 && in_radius) {
+                    if (s.rs_first_coll != 0x7fffffff) { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
+                    else s.n_checks += np;
+                    if (!s.collision) s.done = 1;
                 }
                 __syncthreads();
             }
+            const long long t_f = clock64();
+            if (tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
+            if (s.status != 0 || s.done) break;
 
-            // sequential resolution in child order; heuristic queries are collective
-            for (int i = 0; i < nchild && s.status == 0; i++) {
-                const PlChild c = s.child[i];
-                const int si = i % p.n_steer;
-                const int is_forward = i < p.n_steer ? 1 : 0;
-                const bool found_closed = c.found >= 0 && c.found_state == 2;
-                if (s.closed_nonempty && (found_closed || c.oob)) continue;          // :155-165
-                const bool found_open = c.found >= 0 && c.found_state == 1;
-                if (!found_open) {
-                    if (c.first_coll != 0x7fffffff) {
-                        if (tid == 0) {
+            // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
+            // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
+            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; }
+            __syncthreads();
+            for (;;) {
+                if (tid == 0) {
+                    s.need_sweep = 0;
+                    int i = s.next_child;
+                    for (; i < nchild && s.status == 0; i++) {
+                        const PlChild c = s.child[i];
+                        const int si = i % p.n_steer;
+                        const int is_forward = i < p.n_steer ? 1 : 0;
+                        const bool found_closed = c.found >= 0 && c.found_state == 2;
+                        if (s.closed_nonempty && (found_closed || c.oob)) continue;          // :155-165
+                        const bool found_open = c.found >= 0 && c.found_state == 1;
+                        if (!found_open && c.first_coll != 0x7fffffff) {
                             s.n_checks += c.first_coll + 1;
-                            if (s.nnodes >= maxNodes) s.status = 5;
-                            else {
-                                const int32_t pos = s.nnodes++;
-                                PlNode& nd = w.nodes[pos];
-                                nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = 0; nd.h = 0; nd.f = 0;
-                                nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
-                                nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
-                                pl_hash_put(w, dims.hashCap, pos);
-                                s.nclosed++; s.closed_nonempty = 1;
-                            }
-                        }
-                        __syncthreads();
-                        continue;
-                    }
-                    pl_hquery(m, w, s, c.id, false);
-                    if (tid == 0) {
-                        s.n_checks += p.n_sub;
-                        s.n_rs += 1;
-                        if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
-                        else if (c.rs_err) s.status = c.rs_err == 4 ? 5 : 3;
-                        else if (s.nnodes >= maxNodes) s.status = 5;
-                        else {
-                            const double g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
-                            const double hv1 = (double)s.hq_d / 100, hv2 = c.L;
-                            const double h = hv2 > hv1 ? hv2 : hv1;
+                            if (s.nnodes >= maxNodes) { s.status = 5; break; }
                             const int32_t pos = s.nnodes++;
                             PlNode& nd = w.nodes[pos];
-                            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = g; nd.h = h; nd.f = g + h;
+                            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = 0; nd.h = 0; nd.f = 0;
+                            nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                            nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
+                            pl_hash_put(w, dims.hashCap, pos);
+                            s.nclosed++; s.closed_nonempty = 1;
+                            continue;
+                        }
+                        // heuristic query (hit: answered here; miss: hand over to the workgroup)
+                        uint32_t hd;
+                        if (s.have_d) { hd = s.hq_d; s.have_d = 0; }
+                        else if (!pl_hquery_hit(m, w, s, c.id, hd)) { s.pending_id = c.id; s.need_sweep = 1; break; }
+                        s.n_rs += 1;
+                        if (hd == PL_UNSEEN) { s.status = s.qover ? 5 : 2; break; }
+                        if (c.rs_err) { s.status = c.rs_err == 4 ? 5 : 3; break; }
+                        const double hv1 = (double)hd / 100, hv2 = c.L;
+                        const double hval = hv2 > hv1 ? hv2 : hv1;
+                        if (!found_open) {
+                            s.n_checks += p.n_sub;
+                            if (s.nnodes >= maxNodes) { s.status = 5; break; }
+                            const double g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
+                            const int32_t pos = s.nnodes++;
+                            PlNode& nd = w.nodes[pos];
+                            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = g; nd.h = hval; nd.f = g + hval;
                             nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
                             nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
                             pl_heap_push(w, s, (uint32_t)pos);
                             pl_hash_put(w, dims.hashCap, pos);
-                        }
-                    }
-                    __syncthreads();
-                } else {
-                    pl_hquery(m, w, s, c.id, false);
-                    if (tid == 0) {
-                        s.n_rs += 1;
-                        if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
-                        else if (c.rs_err) s.status = c.rs_err == 4 ? 5 : 3;
-                        else {
+                        } else {
                             PlNode& ch = w.nodes[c.found];
-                            const double hv1 = (double)s.hq_d / 100, hv2 = c.L;
-                            const double new_h = hv2 > hv1 ? hv2 : hv1;
                             const double new_g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
-                            const double new_f = new_h + new_g;
+                            const double new_f = hval + new_g;
                             if (new_f < ch.f) {
-                                ch.f = new_f; ch.g = new_g; ch.h = new_h;
+                                ch.f = new_f; ch.g = new_g; ch.h = hval;
                                 ch.parent_index = cn.index; ch.parent_pos = s.cur;
                                 ch.forward = (int8_t)is_forward; ch.steer_i = (int8_t)si;
                             }
                         }
                     }
-                    __syncthreads();
+                    s.next_child = i;
                 }
+                __syncthreads();
+                if (!s.need_sweep) break;
+                pl_hquery_miss(m, w, s, s.pending_id);
+                if (tid == 0) s.have_d = 1;
+                __syncthreads();
             }
-            __syncthreads();
             if (tid == 0) {
-                w.nodes[s.cur].state = 2;
-                s.nclosed++; s.closed_nonempty = 1;
-                s.global_index += nchild;
+                if (s.status == 0) {
+                    w.nodes[s.cur].state = 2;
+                    s.nclosed++; s.closed_nonempty = 1;
+                    s.global_index += nchild;
+                }
+                s.phase[PH_RESOLVE] += clock64() - t_f;
             }
             __syncthreads();
         }
         __syncthreads();
+        const long long t_fin = clock64();
 
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
         if (tid == 0) {
@@ -742,6 +933,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 }
                 if (over) r.status = 5;
             }
+            s.phase[PH_FINISH] += clock64() - t_fin;
+            for (int k = 0; k < 10; k++) r.phase_cycles[k] = s.phase[k];
             results[pid] = r;
         }
         __syncthreads();

@@ -67,10 +67,11 @@ def main():
         return bool(chk_dm.check_batch(np.array([[x, y, t]]))[0])
 
     rng = np.random.default_rng(20260927 + rank)
-    cand = sampling.sample_free_poses(m.boundary, m.case.obs, 4 * BATCH, rng, margin=6.0, reject=False)
-    hit = dm.check_batch(cand)
-    free = [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
-    assert len(free) >= 2 * BATCH
+    free = []
+    while len(free) < 2 * BATCH:
+        cand = sampling.sample_free_poses(m.boundary, m.case.obs, 8 * BATCH, rng, margin=6.0, reject=False)
+        hit = dm.check_batch(cand)                      # footprint vs obstacle edges: the HIP kernel
+        free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
     poses = np.array(free[:2 * BATCH])
     starts, goals = poses[0::2], poses[1::2]
     st_t, go_t = dm.dev_tensor(starts), dm.dev_tensor(goals)

@@ -142,6 +142,9 @@ typedef struct avp_plan_result {
     double rs_L;             /* total RS length [m]                                                */
     double rs_start[3];      /* sample 0 of the last RS shot = pose of the last popped node        */
     int32_t rs_dir0, pad;    /* its direction flag                                                 */
+    int64_t phase_cycles[10];/* diagnostics: shader cycles spent per phase of the problem (init, heap pop,
+                                shot words, shot sampling, shot checks, children, children RS, resolution,
+                                of which sweep, finish)                                              */
 } avp_plan_result;
 
 /*
