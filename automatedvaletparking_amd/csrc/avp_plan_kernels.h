@@ -59,13 +59,15 @@ struct avp_plan_result_dev {          // mirrors avp_plan_result in include/avp.
     int64_t phase_cycles[10];         // diagnostics: shader cycles per phase (see PH_* below)
 };
 
+struct PlHeapEnt { double f; uint32_t node; uint32_t pad; };
+
 struct PlanWs {                       // per-slot workspace carve (device pointers)
     uint32_t* dist;                   // [idCap]
     uint8_t* flags;                   // [idCap]
     unsigned long long* aliasKey;     // [rowCap]
     unsigned long long* queue;        // [PL_NQ][PL_QCAP]  (dist << 32 | id)
     PlNode* nodes;                    // [maxNodes]
-    uint32_t* heap;                   // [maxNodes]
+    PlHeapEnt* heap;                  // [maxNodes] binary heap, key copied next to the node position
     uint32_t* hash;                   // [hashCap] node position + 1, 0 = empty
     double* rsbuf;                    // [PL_RS_CAP * 3]
     int8_t* rsdir;                    // [PL_RS_CAP]
@@ -90,7 +92,7 @@ static inline __host__ __device__ PlanDims plan_dims(int32_t S, int32_t Sy, int3
     b += pl_al((size_t)d.rowCap * 8);
     b += pl_al((size_t)PL_NQ * PL_QCAP * 8);
     b += pl_al((size_t)maxNodes * sizeof(PlNode));
-    b += pl_al((size_t)maxNodes * 4);
+    b += pl_al((size_t)maxNodes * sizeof(PlHeapEnt));
     b += pl_al((size_t)d.hashCap * 4);
     b += pl_al((size_t)PL_RS_CAP * 3 * 8);
     b += pl_al((size_t)PL_RS_CAP);
@@ -107,7 +109,7 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
     w.aliasKey = (unsigned long long*)(base + o); o += pl_al((size_t)d.rowCap * 8);
     w.queue = (unsigned long long*)(base + o); o += pl_al((size_t)PL_NQ * PL_QCAP * 8);
     w.nodes = (PlNode*)(base + o); o += pl_al((size_t)d.maxNodes * sizeof(PlNode));
-    w.heap = (uint32_t*)(base + o); o += pl_al((size_t)d.maxNodes * 4);
+    w.heap = (PlHeapEnt*)(base + o); o += pl_al((size_t)d.maxNodes * sizeof(PlHeapEnt));
     w.hash = (uint32_t*)(base + o); o += pl_al((size_t)d.hashCap * 4);
     w.rsbuf = (double*)(base + o); o += pl_al((size_t)PL_RS_CAP * 3 * 8);
     w.rsdir = (int8_t*)(base + o);
@@ -177,6 +179,7 @@ struct PlChild {
     int32_t found;                    // node position of an equal open/closed node, -1 none
     int32_t first_coll;               // first colliding sub-step, -1 none
     int8_t found_state, oob, rs_err, pad;
+    uint32_t pre_d;                   // dist[id] read ahead of the sequential resolution
 };
 
 struct PlShared {
@@ -210,6 +213,7 @@ struct PlShared {
     int64_t pending_id;
     PlChild child[PL_MAXCHILD];
     // RS word results: [query][word] ok + 5 lengths; kept candidates per query
+    RsFrame frame[PL_RSQ];
     uint8_t w_ok[PL_RSQ * 46];
     double w_l[PL_RSQ * 46][5];
     RsKeep keep[PL_RSQ];
@@ -260,15 +264,16 @@ AVP_D void pl_hash_put(const PlanWs& w, int64_t hashCap, int32_t pos)
 }
 
 // ---- CPython heapq on node positions, key = node.f (Node.__lt__ hybrid_a_star.py:61-68) ---------
-AVP_D void pl_heap_set(const PlanWs& w, int32_t pos, uint32_t node) { w.heap[pos] = node; w.nodes[node].heap_pos = pos; }
+// The key is stored next to the position (one load per comparison); an in-place improvement of an
+// open node updates both copies and, like the reference (:224-230), does NOT restore the heap order.
+AVP_D void pl_heap_set(const PlanWs& w, int32_t pos, PlHeapEnt e) { w.heap[pos] = e; w.nodes[e.node].heap_pos = pos; }
 AVP_D void pl_siftdown(const PlanWs& w, int32_t startpos, int32_t pos)
 {
-    const uint32_t newitem = w.heap[pos];
-    const double nf = w.nodes[newitem].f;
+    const PlHeapEnt newitem = w.heap[pos];
     while (pos > startpos) {
         const int32_t parentpos = (pos - 1) >> 1;
-        const uint32_t parent = w.heap[parentpos];
-        if (nf < w.nodes[parent].f) { pl_heap_set(w, pos, parent); pos = parentpos; continue; }
+        const PlHeapEnt parent = w.heap[parentpos];
+        if (newitem.f < parent.f) { pl_heap_set(w, pos, parent); pos = parentpos; continue; }
         break;
     }
     pl_heap_set(w, pos, newitem);
@@ -276,12 +281,16 @@ AVP_D void pl_siftdown(const PlanWs& w, int32_t startpos, int32_t pos)
 AVP_D void pl_siftup(const PlanWs& w, int32_t pos, int32_t endpos)
 {
     const int32_t startpos = pos;
-    const uint32_t newitem = w.heap[pos];
+    const PlHeapEnt newitem = w.heap[pos];
     int32_t childpos = 2 * pos + 1;
     while (childpos < endpos) {
         const int32_t rightpos = childpos + 1;
-        if (rightpos < endpos && !(w.nodes[w.heap[childpos]].f < w.nodes[w.heap[rightpos]].f)) childpos = rightpos;
-        pl_heap_set(w, pos, w.heap[childpos]);
+        PlHeapEnt c = w.heap[childpos];
+        if (rightpos < endpos) {
+            const PlHeapEnt r = w.heap[rightpos];
+            if (!(c.f < r.f)) { childpos = rightpos; c = r; }
+        }
+        pl_heap_set(w, pos, c);
         pos = childpos;
         childpos = 2 * pos + 1;
     }
@@ -290,20 +299,21 @@ AVP_D void pl_siftup(const PlanWs& w, int32_t pos, int32_t endpos)
 }
 AVP_D void pl_heap_push(const PlanWs& w, PlShared& s, uint32_t node)
 {
-    w.heap[s.nheap] = node;
+    PlHeapEnt e; e.f = w.nodes[node].f; e.node = node; e.pad = 0;
+    w.heap[s.nheap] = e;
     s.nheap++;
     pl_siftdown(w, 0, s.nheap - 1);
 }
 AVP_D uint32_t pl_heap_pop(const PlanWs& w, PlShared& s)
 {
-    const uint32_t lastelt = w.heap[--s.nheap];
+    const PlHeapEnt lastelt = w.heap[--s.nheap];
     if (s.nheap) {
-        const uint32_t ret = w.heap[0];
+        const PlHeapEnt ret = w.heap[0];
         w.heap[0] = lastelt;
         pl_siftup(w, 0, s.nheap);
-        return ret;
+        return ret.node;
     }
-    return lastelt;
+    return lastelt.node;
 }
 
 // ---- heuristic sweep ---------------------------------------------------------------------------
@@ -370,11 +380,12 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
 //  pl_hquery_hit : pure test against the closed frontier, callable by a single thread;
 //  pl_hquery_miss: collective sweep extension until the cell's distance is final (all threads).
 // force_miss: the initial compute_path(x0, y0) of hybrid_a_star.__init__ (:89-91) always sweeps.
-AVP_D bool pl_hquery_hit(const DevMap& m, const PlanWs& w, const PlShared& s, int64_t id, uint32_t& d_out)
+AVP_D bool pl_id_in_range(const DevMap& m, int64_t id) { return id >= 0 && id < (int64_t)m.S * (m.Sy + 3); }
+AVP_D bool pl_hquery_hit(const DevMap& m, const PlShared& s, int64_t id, uint32_t d, uint32_t& d_out)
 {
+    // d = current dist[id] (PL_UNSEEN when the id is outside the id space)
     if (id == s.goal_id) { d_out = 0; return true; }                 // first closedlist entry: the goal Grid, distance 0
-    if (!(id >= 0 && id < (int64_t)m.S * (m.Sy + 3))) { d_out = PL_UNSEEN; return true; }
-    const uint32_t d = w.dist[id];
+    if (!pl_id_in_range(m, id)) { d_out = PL_UNSEEN; return true; }
     if (s.hasF && d != PL_UNSEEN && (d < s.dF || (d == s.dF && id <= s.idF))) { d_out = d; return true; }
     return false;
 }
@@ -400,10 +411,10 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, PlShared& s, int64_t
     if (threadIdx.x == 0) {
         const uint32_t d = w.dist[id];
         s.hq_d = (d != PL_UNSEEN && pl_bucket(d) <= s.E) ? d : PL_UNSEEN;
+        s.h_misses += 1;
         if (s.hq_d != PL_UNSEEN) {
             s.dF = d; s.idF = id; s.hasF = 1;
             w.flags[id] |= PL_FLAG_T;
-            s.h_misses += 1;
         }
     }
     __syncthreads();
@@ -424,14 +435,21 @@ AVP_D double pl_node_cost(const avp_params& p, int node_forward, double node_the
 template <typename PoseFn>
 AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
 {
-    for (int t = threadIdx.x; t < nq * 46; t += PL_THREADS) {
-        const int q = t / 46, wd = t - q * 46;
+    // start-frame normalisation once per query
+    if ((int)threadIdx.x < nq) {
         double x, y, th;
-        pose(q, x, y, th);
-        const RsFrame f = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+        pose((int)threadIdx.x, x, y, th);
+        s.frame[threadIdx.x] = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+    }
+    __syncthreads();
+    // word-major mapping: consecutive lanes evaluate the SAME word for different queries, so a wave
+    // runs one or two of the nine word solvers instead of all of them
+    for (int t = threadIdx.x; t < nq * 46; t += PL_THREADS) {
+        const int wd = t / nq, q = t - wd * nq;
         double l[5];
-        s.w_ok[t] = rs_word(wd, f, l) ? 1 : 0;
-        for (int k = 0; k < 5; k++) s.w_l[t][k] = l[k];
+        const int slot = q * 46 + wd;
+        s.w_ok[slot] = rs_word(wd, s.frame[q], l) ? 1 : 0;
+        for (int k = 0; k < 5; k++) s.w_l[slot][k] = l[k];
     }
     __syncthreads();
 }
@@ -814,6 +832,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
             // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
             if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; }
+            if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
             for (;;) {
                 if (tid == 0) {
@@ -841,9 +860,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         // heuristic query (hit: answered here; miss: hand over to the workgroup)
                         uint32_t hd;
                         if (s.have_d) { hd = s.hq_d; s.have_d = 0; }
-                        else if (!pl_hquery_hit(m, w, s, c.id, hd)) { s.pending_id = c.id; s.need_sweep = 1; break; }
+                        else if (!pl_hquery_hit(m, s, c.id, c.pre_d, hd)) { s.pending_id = c.id; s.need_sweep = 1; break; }
+                        if (hd == PL_UNSEEN) { if (!found_open) s.n_checks += p.n_sub; s.status = s.qover ? 5 : 2; break; }
                         s.n_rs += 1;
-                        if (hd == PL_UNSEEN) { s.status = s.qover ? 5 : 2; break; }
                         if (c.rs_err) { s.status = c.rs_err == 4 ? 5 : 3; break; }
                         const double hv1 = (double)hd / 100, hv2 = c.L;
                         const double hval = hv2 > hv1 ? hv2 : hv1;
@@ -864,6 +883,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             const double new_f = hval + new_g;
                             if (new_f < ch.f) {
                                 ch.f = new_f; ch.g = new_g; ch.h = hval;
+                                w.heap[ch.heap_pos].f = new_f;
                                 ch.parent_index = cn.index; ch.parent_pos = s.cur;
                                 ch.forward = (int8_t)is_forward; ch.steer_i = (int8_t)si;
                             }
@@ -875,6 +895,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (!s.need_sweep) break;
                 pl_hquery_miss(m, w, s, s.pending_id);
                 if (tid == 0) s.have_d = 1;
+                if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
                 __syncthreads();
             }
             if (tid == 0) {
