@@ -1,0 +1,106 @@
+"""Multi-GPU data path on CPU: world_size-2 gloo processes exercise the map broadcast, the cost-sorted
+sharding and the fixed-stride gather; results must be identical to the single-process order
+(shard invariance). The per-shard planner is the CPU oracle here (test infrastructure standing in
+for the HIP planner, which has no CPU form)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, case_map_from_gold
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from automatedvaletparking_amd import costmap, config, distributed as avd
+    from oracle import oracle
+    from conftest import case_map_from_gold
+    cfg = config.default_config()
+    veh = costmap.Vehicle()
+    m = case_map_from_gold(1) if rank == 0 else None
+    m = avd.broadcast_map(m, src=0, device="cpu")
+    o = oracle.Oracle(m, veh, cfg, max_pops=200)
+    rng = np.random.default_rng(7)
+    b = m.boundary
+    poses = np.stack([rng.uniform(b[0] + 6, b[1] - 6, 24), rng.uniform(b[2] + 6, b[3] - 6, 24), rng.uniform(-3, 3, 24)], 1)
+    starts, goals = poses[0::2], poses[1::2]
+
+    def plan_fn(s, g):
+        out = np.zeros((len(s), 4 + 3 * 64))
+        for i in range(len(s)):
+            r = o.plan(s[i], g[i], max_trace=1)
+            k = min(len(r["final_path"]), 64)
+            out[i, :4] = [r["status"], r["n_pops"], len(r["final_path"]), r["rs_L"]]
+            out[i, 4:4 + 3 * k] = r["final_path"][:k].ravel()
+        return out
+
+    rec = avd.plan_sharded(plan_fn, starts, goals, dst=0, device="cpu")
+    if rank == 0:
+        q.put((rec, avd.pack_map_blob(m)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_invariance_world2(vehicle, cfg):
+    import torch.multiprocessing as mp
+    from automatedvaletparking_amd import distributed as avd
+    from oracle import oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rec2, blob = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single process reference
+    m = case_map_from_gold(1)
+    assert np.array_equal(blob, avd.pack_map_blob(m))
+    o = oracle.Oracle(m, vehicle, cfg, max_pops=200)
+    rng = np.random.default_rng(7)
+    b = m.boundary
+    poses = np.stack([rng.uniform(b[0] + 6, b[1] - 6, 24), rng.uniform(b[2] + 6, b[3] - 6, 24), rng.uniform(-3, 3, 24)], 1)
+    starts, goals = poses[0::2], poses[1::2]
+    for i in range(len(starts)):
+        r = o.plan(starts[i], goals[i], max_trace=1)
+        assert rec2[i, 0] == r["status"] and rec2[i, 1] == r["n_pops"] and rec2[i, 2] == len(r["final_path"])
+        k = min(len(r["final_path"]), 64)
+        assert np.array_equal(rec2[i, 4:4 + 3 * k], r["final_path"][:k].ravel())
+
+
+def test_map_blob_roundtrip():
+    from automatedvaletparking_amd import distributed as avd
+    m = case_map_from_gold(19)
+    m2 = avd.unpack_map_blob(avd.pack_map_blob(m))
+    assert np.array_equal(m.cost_map, m2.cost_map) and np.array_equal(m.boundary, m2.boundary)
+    assert m._discrete_x == m2._discrete_x and m._discrete_y == m2._discrete_y
+    assert all(np.array_equal(a, b) for a, b in zip(m.case.obs, m2.case.obs))
+    assert (m.case.x0, m.case.thetaf) == (m2.case.x0, m2.case.thetaf)
+
+
+def test_shard_indices_partition():
+    from automatedvaletparking_amd import distributed as avd
+    rng = np.random.default_rng(1)
+    s, g = rng.uniform(-10, 10, (101, 3)), rng.uniform(-10, 10, (101, 3))
+    for world in (1, 2, 4, 8):
+        parts = [avd.shard_indices(s, g, r, world) for r in range(world)]
+        allidx = np.sort(np.concatenate(parts))
+        assert np.array_equal(allidx, np.arange(101))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
