@@ -329,6 +329,7 @@ def gen_micro_g4(rng, veh):
     # structured: close poses (short paths, many CCC/CCCC winners)
     q1[n // 2:, :2] = q0[n // 2:, :2] + rng.uniform(-6, 6, (n - n // 2, 2))
     MAXP = 320
+    NSAMP = 2500   # sampled way-points are stored for the first NSAMP queries only (fixture size)
     L = np.zeros(n)
     types = np.full((n, 5), -1, np.int8)
     lens = np.zeros((n, 5))
@@ -356,9 +357,9 @@ def gen_micro_g4(rng, veh):
             for j, pc in enumerate(c):
                 cand_types[i, j, :len(pc.ctypes)] = [TYPE_CODE[t] for t in pc.ctypes]
                 cand_lens[i, j, :len(pc.lengths)] = pc.lengths
-    mp = int(npts.max())
-    save("g4_rs.npz", dict(maxc=maxc, q0=q0, q1=q1, L=L, types=types, lens=lens, npts=npts, pts=pts[:, :mp],
-                           dirs=dirs[:, :mp], ncand=ncand[:2000], cand_types=cand_types, cand_lens=cand_lens))
+    mp = int(npts[:NSAMP].max())
+    save("g4_rs.npz", dict(maxc=maxc, q0=q0, q1=q1, L=L, types=types, lens=lens, npts=npts, pts=pts[:NSAMP, :mp],
+                           dirs=dirs[:NSAMP, :mp], ncand=ncand[:2000], cand_types=cand_types, cand_lens=cand_lens))
     # pi_2_pi / M
     th = rng.uniform(-20, 20, 5000)
     save("g4_angles.npz", dict(th=th, pi2pi=np.array([ref_rs.pi_2_pi(t) for t in th]), M=np.array([ref_rs.M(t) for t in th])))

@@ -45,12 +45,13 @@ def test_rs_optimal_and_candidates(vehicle, cfg):
     g4 = gold("g4_rs.npz")
     o = _oracle(case_map_from_gold(1), vehicle, cfg)
     maxc = float(g4["maxc"])
-    r = o.rs_optimal(g4["q0"], g4["q1"], maxc, maxpts=g4["pts"].shape[1])
+    r = o.rs_optimal(g4["q0"], g4["q1"], maxc, maxpts=int(g4["npts"].max()) + 8)
     assert (r["status"] == 0).all()
     assert np.array_equal(r["L"], g4["L"])
     assert np.array_equal(r["types"], g4["types"]) and np.array_equal(r["lens"], g4["lens"])
     assert np.array_equal(r["npts"], g4["npts"])
-    assert np.array_equal(r["pts"], g4["pts"]) and np.array_equal(r["dirs"], g4["dirs"])
+    ns, k = g4["pts"].shape[:2]          # sampled way-points are stored for the first ns queries
+    assert np.array_equal(r["pts"][:ns, :k], g4["pts"]) and np.array_equal(r["dirs"][:ns, :k], g4["dirs"])
     nc, ty, le = o.rs_candidates(g4["q0"][:2000], g4["q1"][:2000], maxc)
     assert np.array_equal(nc, g4["ncand"])
     assert np.array_equal(ty, g4["cand_types"]) and np.array_equal(le, g4["cand_lens"])
@@ -73,6 +74,9 @@ def test_hfield_resumable_sweep(path, vehicle, cfg):
     dj = o.dijkstra(m.case.xf, m.case.yf)
     for (x, y, d, ncl) in g["queries"]:
         if d < 0:
+            # the reference was interrupted inside this query (unreachable cell: it blocks forever in
+            # PriorityQueue.get(), compute_h.py:77); its closed list keeps what it swept until then
+            dj.compute_path(x, y)
             break
         assert dj.compute_path(x, y) == int(d)
     ids, dist, xs, ys = dj.dump()
