@@ -24,7 +24,7 @@
 #include "avp_device.h"
 #include "avp_rs_kernels.h"
 
-#define PL_THREADS 256
+#define PL_THREADS 512
 #define PL_QCAP 32768                 // entries per rotating bucket queue
 #define PL_NQ 4                       // rotating bucket queues
 #define PL_MAXCHILD 32
@@ -214,9 +214,12 @@ struct PlShared {
     PlChild child[PL_MAXCHILD];
     // RS word results: [query][word] ok + 5 lengths; kept candidates per query
     RsFrame frame[PL_RSQ];
-    uint8_t w_ok[PL_RSQ * 46];
+    uint8_t w_ok[PL_RSQ * 46];        // word valid
+    uint8_t w_acc[PL_RSQ * 46];       // word accepted by set_path
+    uint8_t w_err[PL_RSQ];            // assertion L >= 0.01 failed for an accepted word
     double w_l[PL_RSQ * 46][5];
-    RsKeep keep[PL_RSQ];
+    double w_Ln[PL_RSQ * 46];         // normalised length of an accepted word
+    double w_Lm[PL_RSQ * 46];         // its length in metres (L / maxc)
     // RS sampling: per output index the last writer (length argument, segment), segment origins
     int32_t smp_hi, smp_point_num;
     double smp_l[PL_RS_CAP];
@@ -453,18 +456,64 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
     }
     __syncthreads();
 }
+// set_path (rs_curve.py:137-156) for all queries at once: one thread per (query, type group); a
+// candidate is only ever compared with kept candidates of the same type sequence, so the groups are
+// independent and the within-group order is the source order.
+AVP_D void pl_rs_accept(PlShared& s, const avp_params& p, int nq)
+{
+    if ((int)threadIdx.x < nq) s.w_err[threadIdx.x] = 0;
+    for (int t = threadIdx.x; t < nq * 46; t += PL_THREADS) s.w_acc[t] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nq * 20; t += PL_THREADS) {
+        const int g = t / nq, q = t - g * nq;
+        double kept[4][5];
+        int nk = 0;
+        for (int j = 0; j < 4; j++) {
+            const int wd = RS_GROUPS[g][j];
+            if (wd < 0) break;
+            const int slot = q * 46 + wd;
+            if (!s.w_ok[slot]) continue;
+            const int n = RS_WORDS[wd].n;
+            double l[5];
+            for (int i = 0; i < 5; i++) l[i] = s.w_l[slot][i];
+            bool dup = false;
+            for (int e = 0; e < nk && !dup; e++) {
+                double sum = 0;
+                for (int i = 0; i < n; i++) sum = sum + (kept[e][i] - l[i]);
+                if (sum <= 0.01) dup = true;
+            }
+            if (dup) continue;
+            double L = 0;
+            for (int i = 0; i < n; i++) L = L + fabs(l[i]);
+            if (L >= 1000.0) continue;
+            if (!(L >= 0.01)) { s.w_err[q] = 1; continue; }
+            for (int i = 0; i < 5; i++) kept[nk][i] = l[i];
+            nk++;
+            s.w_acc[slot] = 1; s.w_Ln[slot] = L; s.w_Lm[slot] = L / p.maxc;
+        }
+    }
+    __syncthreads();
+}
+
+// arg-min over the accepted words of query q with "<=" (the last of equal minima wins, rs_curve.py:103-108)
 AVP_D int pl_rs_fold(PlShared& s, const avp_params& p, int q, RsPath& out)
 {
-    RsKeep& k = s.keep[q];
-    rs_keep_init(k, p.maxc);
-    for (int wd = 0; wd < 46 && !k.err; wd++) {
-        const int t = q * 46 + wd;
-        if (!s.w_ok[t]) continue;
-        double l[5];
-        for (int i = 0; i < 5; i++) l[i] = s.w_l[t][i];
-        rs_keep_add(k, wd, l);
+    out.n = 0; out.L = 0;
+    if (s.w_err[q]) return 2;
+    int best = -1;
+    double bestL = 0;
+    for (int wd = 0; wd < 46; wd++) {
+        const int slot = q * 46 + wd;
+        if (!s.w_acc[slot]) continue;
+        if (best < 0 || s.w_Lm[slot] <= bestL) { best = wd; bestL = s.w_Lm[slot]; }
     }
-    return rs_keep_result(k, out);
+    if (best < 0) return 1;
+    const RsWord W = RS_WORDS[best];
+    const int8_t ty[5] = { W.a, W.b, W.c, W.d, W.e };
+    out.n = W.n;
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) { out.t[i] = i < W.n ? ty[i] : (int8_t)-1; out.l[i] = s.w_l[q * 46 + best][i]; }
+    out.L = s.w_Ln[q * 46 + best];
+    return 0;
 }
 
 // ---- parallel Reeds-Shepp sampling (rs_curve.py:537-594 + :125-131) ---------------------------------
@@ -761,6 +810,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (g == 0) { x = cn.x; y = cn.y; th = cn.th; }
                         else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
                     });
+                    pl_rs_accept(s, p, cnt);
                     if (tid < cnt) {
                         const int g = base + tid;
                         RsPath rp;

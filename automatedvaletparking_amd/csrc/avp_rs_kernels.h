@@ -69,10 +69,10 @@ AVP_D void rs_set_path(RsKeep& k, uint32_t code, int n, double l0, double l1, do
 AVP_D void rs_polar(double x, double y, double& r, double& th) { r = avp_hypot(x, y); th = avp_atan2(y, x); }
 
 // rs_curve.py:159-167
-AVP_D bool rs_LSL(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LSL(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
     double uu, tt;
-    rs_polar(x - avp_sin(phi), y - 1.0 + avp_cos(phi), uu, tt);
+    rs_polar(x - sp, y - 1.0 + cp, uu, tt);
     if (tt >= 0.0) {
         const double vv = avp_M(phi - tt);
         if (vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
@@ -80,10 +80,10 @@ AVP_D bool rs_LSL(double x, double y, double phi, double& t, double& u, double& 
     return false;
 }
 // rs_curve.py:170-183
-AVP_D bool rs_LSR(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LSR(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
     double u1, t1;
-    rs_polar(x + avp_sin(phi), y - 1.0 - avp_cos(phi), u1, t1);
+    rs_polar(x + sp, y - 1.0 - cp, u1, t1);
     u1 = u1 * u1;
     if (u1 >= 4.0) {
         const double uu = sqrt(u1 - 4.0);
@@ -95,10 +95,10 @@ AVP_D bool rs_LSR(double x, double y, double phi, double& t, double& u, double& 
     return false;
 }
 // rs_curve.py:186-197
-AVP_D bool rs_LRL(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LRL(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
     double u1, t1;
-    rs_polar(x - avp_sin(phi), y - 1.0 + avp_cos(phi), u1, t1);
+    rs_polar(x - sp, y - 1.0 + cp, u1, t1);
     if (u1 <= 4.0) {
         const double uu = -2.0 * avp_asin(0.25 * u1);
         const double tt = avp_M(t1 + 0.5 * uu + AVP_PI);
@@ -138,9 +138,9 @@ AVP_D void rs_tauOmega(double u, double v, double xi, double eta, double phi, do
     omega = avp_M(tau - u + v - phi);
 }
 // rs_curve.py:326-337
-AVP_D bool rs_LRLRn(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LRLRn(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
-    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    const double xi = x + sp, eta = y - 1.0 - cp;
     const double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
     if (rho <= 1.0) {
         const double uu = avp_acos(rho);
@@ -151,9 +151,9 @@ AVP_D bool rs_LRLRn(double x, double y, double phi, double& t, double& u, double
     return false;
 }
 // rs_curve.py:340-352
-AVP_D bool rs_LRLRp(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LRLRp(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
-    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    const double xi = x + sp, eta = y - 1.0 - cp;
     const double rho = (20.0 - xi * xi - eta * eta) / 16.0;
     if (0.0 <= rho && rho <= 1.0) {
         const double uu = -avp_acos(rho);
@@ -166,9 +166,9 @@ AVP_D bool rs_LRLRp(double x, double y, double phi, double& t, double& u, double
     return false;
 }
 // rs_curve.py:391-403
-AVP_D bool rs_LRSR(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LRSR(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
-    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    const double xi = x + sp, eta = y - 1.0 - cp;
     double rho, theta;
     rs_polar(-eta, xi, rho, theta);
     if (rho >= 2.0) {
@@ -178,9 +178,9 @@ AVP_D bool rs_LRSR(double x, double y, double phi, double& t, double& u, double&
     return false;
 }
 // rs_curve.py:406-419
-AVP_D bool rs_LRSL(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LRSL(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
-    const double xi = x - avp_sin(phi), eta = y - 1.0 + avp_cos(phi);
+    const double xi = x - sp, eta = y - 1.0 + cp;
     double rho, theta;
     rs_polar(xi, eta, rho, theta);
     if (rho >= 2.0) {
@@ -193,9 +193,9 @@ AVP_D bool rs_LRSL(double x, double y, double phi, double& t, double& u, double&
     return false;
 }
 // rs_curve.py:494-510
-AVP_D bool rs_LRSLR(double x, double y, double phi, double& t, double& u, double& v)
+AVP_D bool rs_LRSLR(double x, double y, double phi, double sp, double cp, double& t, double& u, double& v)
 {
-    const double xi = x + avp_sin(phi), eta = y - 1.0 - avp_cos(phi);
+    const double xi = x + sp, eta = y - 1.0 - cp;
     double rho, theta;
     rs_polar(xi, eta, rho, theta);
     if (rho >= 2.0) {
@@ -252,9 +252,18 @@ static __device__ const RsWord RS_WORDS[46] = {
 };
 #undef W_
 
+// Words grouped by type sequence (set_path only compares candidates of identical ctypes), ascending
+// word index inside a group, -1 padded.
+static __device__ const int8_t RS_GROUPS[20][4] = {
+    { 0, -1, -1, -1 }, { 1, -1, -1, -1 }, { 2, 3, -1, -1 }, { 4, 5, -1, -1 }, { 6, 7, -1, -1 }, { 8, 9, -1, -1 },
+    { 10, 11, 14, 15 }, { 12, 13, 16, 17 }, { 18, 19, 22, 23 }, { 20, 21, 24, 25 },
+    { 26, 27, -1, -1 }, { 28, 29, -1, -1 }, { 30, 31, -1, -1 }, { 32, 33, -1, -1 },
+    { 34, 35, -1, -1 }, { 36, 37, -1, -1 }, { 38, 39, -1, -1 }, { 40, 41, -1, -1 }, { 42, 43, -1, -1 }, { 44, 45, -1, -1 },
+};
+
 // Start-frame normalisation of generate_path (rs_curve.py:627-634) + the "backwards" frame
 // (:286-287, :456-457).
-struct RsFrame { double x0, y0, phi0, xb, yb; };
+struct RsFrame { double x0, y0, phi0, xb, yb, sphi, cphi; };
 AVP_D RsFrame rs_frame(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t, double maxc)
 {
     RsFrame f;
@@ -263,8 +272,10 @@ AVP_D RsFrame rs_frame(double q0x, double q0y, double q0t, double q1x, double q1
     const double c = avp_cos(q0t), s = avp_sin(q0t);
     f.x0 = (c * dx + s * dy) * maxc;
     f.y0 = (-s * dx + c * dy) * maxc;
-    f.xb = f.x0 * avp_cos(f.phi0) + f.y0 * avp_sin(f.phi0);
-    f.yb = f.x0 * avp_sin(f.phi0) - f.y0 * avp_cos(f.phi0);
+    f.sphi = avp_sin(f.phi0);          // sin is odd and cos even bit for bit, so the mirrored / time-flipped
+    f.cphi = avp_cos(f.phi0);          // words (phi -> -phi) reuse these two values
+    f.xb = f.x0 * f.cphi + f.y0 * f.sphi;
+    f.yb = f.x0 * f.sphi - f.y0 * f.cphi;
     return f;
 }
 
@@ -274,19 +285,20 @@ __device__ __noinline__ bool rs_word(int w, const RsFrame& f, double l[5])
     const RsWord W = RS_WORDS[w];
     const double bx = W.back ? f.xb : f.x0, by = W.back ? f.yb : f.y0;
     const double x = W.sx < 0 ? -bx : bx, y = W.sy < 0 ? -by : by, phi = W.sphi < 0 ? -f.phi0 : f.phi0;
+    const double sp = W.sphi < 0 ? -f.sphi : f.sphi, cp = f.cphi;
     const double hp = 0.5 * AVP_PI;
     double t = 0, u = 0, v = 0;
     bool ok;
     switch (W.solver) {
         case 0: ok = rs_SLS(x, y, phi, t, u, v); break;
-        case 1: ok = rs_LSL(x, y, phi, t, u, v); break;
-        case 2: ok = rs_LSR(x, y, phi, t, u, v); break;
-        case 3: ok = rs_LRL(x, y, phi, t, u, v); break;
-        case 4: ok = rs_LRLRn(x, y, phi, t, u, v); break;
-        case 5: ok = rs_LRLRp(x, y, phi, t, u, v); break;
-        case 6: ok = rs_LRSL(x, y, phi, t, u, v); break;
-        case 7: ok = rs_LRSR(x, y, phi, t, u, v); break;
-        default: ok = rs_LRSLR(x, y, phi, t, u, v); break;
+        case 1: ok = rs_LSL(x, y, phi, sp, cp, t, u, v); break;
+        case 2: ok = rs_LSR(x, y, phi, sp, cp, t, u, v); break;
+        case 3: ok = rs_LRL(x, y, phi, sp, cp, t, u, v); break;
+        case 4: ok = rs_LRLRn(x, y, phi, sp, cp, t, u, v); break;
+        case 5: ok = rs_LRLRp(x, y, phi, sp, cp, t, u, v); break;
+        case 6: ok = rs_LRSL(x, y, phi, sp, cp, t, u, v); break;
+        case 7: ok = rs_LRSR(x, y, phi, sp, cp, t, u, v); break;
+        default: ok = rs_LRSLR(x, y, phi, sp, cp, t, u, v); break;
     }
     l[0] = l[1] = l[2] = l[3] = l[4] = 0.0;
     if (!ok) return false;

@@ -171,6 +171,16 @@ def main():
             out["cpu_baseline"] = {"value": BATCH / tc, "unit": "plans/s", "cores": 1, "kind": "port",
                                    "sample": f"the same {BATCH} problems, pop cap {POP_CAP}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s",
                                    "expansions_per_s": pops_cpu / tc}
+        # HBM traffic per launch from the committed PMC passes of this same command (profiles/README.md)
+        try:
+            import glob
+            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+            pj = json.load(open(pmc))
+            out["roofline"]["traffic"] = pj["plan_kernel"]["hbm_bytes_per_launch_corrected"]
+            out["roofline_check"]["traffic"] = pj["check_distance_kernel<true>"]["hbm_bytes_per_launch_corrected"]
+            out["roofline"]["traffic_source"] = out["roofline_check"]["traffic_source"] = os.path.relpath(pmc, ROOT)
+        except Exception:
+            pass
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
