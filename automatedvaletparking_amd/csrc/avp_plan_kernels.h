@@ -180,7 +180,11 @@ struct PlChild {
     int32_t first_coll;               // first colliding sub-step, -1 none
     int8_t found_state, oob, rs_err, pad;
     uint32_t pre_d;                   // dist[id] read ahead of the sequential resolution
+    // fast-path resolution (all heuristic queries hit): class, arena slot, costs, prefetched open-node fields
+    int32_t cls, pos, old_heap_pos;
+    double g, h, f, old_f;
 };
+enum { CL_SKIP = 0, CL_NEW_CLOSED = 1, CL_NEW_OPEN = 2, CL_IMPROVE = 3, CL_KEEP = 4 };
 
 struct PlShared {
     // lattice / id space (compute_h.py lattice anchored at the goal)
@@ -209,7 +213,7 @@ struct PlShared {
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
     // sequential child resolution state machine (thread 0 runs alone between sweep extensions)
-    int32_t next_child, need_sweep, have_d;
+    int32_t next_child, need_sweep, have_d, fast;
     int64_t pending_id;
     PlChild child[PL_MAXCHILD];
     // RS word results: [query][word] ok + 5 lengths; kept candidates per query
@@ -264,6 +268,14 @@ AVP_D void pl_hash_put(const PlanWs& w, int64_t hashCap, int32_t pos)
     uint64_t h = pl_pose_hash(n.x, n.y, n.th) & (uint64_t)(hashCap - 1);
     while (w.hash[h] != 0) h = (h + 1) & (uint64_t)(hashCap - 1);
     w.hash[h] = (uint32_t)pos + 1;
+}
+
+// parallel-safe insert (fast-path resolution: several lanes insert at once; order is irrelevant)
+AVP_D void pl_hash_put_atomic(const PlanWs& w, int64_t hashCap, int32_t pos, double x, double y, double th)
+{
+    if (x != x || y != y || th != th) return;
+    uint64_t h = pl_pose_hash(x, y, th) & (uint64_t)(hashCap - 1);
+    while (atomicCAS(&w.hash[h], 0u, (uint32_t)pos + 1) != 0u) h = (h + 1) & (uint64_t)(hashCap - 1);
 }
 
 // ---- CPython heapq on node positions, key = node.f (Node.__lt__ hybrid_a_star.py:61-68) ---------
@@ -881,9 +893,84 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
             // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
-            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; }
+            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes); }
             if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
+            // ---- fast path: closed list non-empty and every heuristic query hits the closed frontier.
+            // Lanes classify and cost their child in parallel; thread 0 then applies, in child order, only
+            // what is order dependent: arena slots, in-place improvements of open nodes and heap pushes.
+            if (s.fast) {
+                if (tid < nchild) {
+                    PlChild& c = s.child[tid];
+                    const int is_forward = tid < p.n_steer ? 1 : 0;
+                    const bool found_closed = c.found >= 0 && c.found_state == 2;
+                    const bool found_open = c.found >= 0 && c.found_state == 1;
+                    int cls;
+                    if (found_closed || c.oob) cls = CL_SKIP;
+                    else if (!found_open && c.first_coll != 0x7fffffff) cls = CL_NEW_CLOSED;
+                    else {
+                        uint32_t hd = PL_UNSEEN;
+                        const bool hit = pl_hquery_hit(m, s, c.id, c.pre_d, hd);
+                        if (!hit || hd == PL_UNSEEN || c.rs_err) { s.fast = 0; cls = CL_SKIP; }
+                        else {
+                            const double hv1 = (double)hd / 100, hv2 = c.L;
+                            const double hval = hv2 > hv1 ? hv2 : hv1;
+                            if (!found_open) {
+                                c.g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
+                                c.h = hval; c.f = c.g + hval;
+                                cls = CL_NEW_OPEN;
+                            } else {
+                                const PlNode& ch = w.nodes[c.found];
+                                c.g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
+                                c.h = hval; c.f = hval + c.g;
+                                c.old_f = ch.f; c.old_heap_pos = ch.heap_pos;
+                                cls = c.f < ch.f ? CL_IMPROVE : CL_KEEP;
+                            }
+                        }
+                    }
+                    c.cls = cls;
+                }
+                __syncthreads();
+            }
+            if (s.fast) {
+                if (tid == 0) {
+                    for (int i = 0; i < nchild; i++) {
+                        PlChild& c = s.child[i];
+                        if (c.cls == CL_NEW_CLOSED) { c.pos = s.nnodes++; s.n_checks += c.first_coll + 1; s.nclosed++; }
+                        else if (c.cls == CL_NEW_OPEN) { c.pos = s.nnodes++; s.n_checks += p.n_sub; s.n_rs += 1; }
+                        else if (c.cls == CL_IMPROVE || c.cls == CL_KEEP) s.n_rs += 1;
+                    }
+                }
+                __syncthreads();
+                if (tid < nchild) {
+                    const PlChild& c = s.child[tid];
+                    if (c.cls == CL_NEW_CLOSED || c.cls == CL_NEW_OPEN) {
+                        const bool open = c.cls == CL_NEW_OPEN;
+                        PlNode& nd = w.nodes[c.pos];
+                        nd.x = c.x; nd.y = c.y; nd.th = c.th;
+                        nd.g = open ? c.g : 0.0; nd.h = open ? c.h : 0.0; nd.f = open ? c.f : 0.0;
+                        nd.index = (int32_t)(s.global_index + tid + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                        nd.forward = (int8_t)(tid < p.n_steer ? 1 : 0); nd.steer_i = (int8_t)(tid % p.n_steer);
+                        nd.state = open ? 1 : 2; nd.heap_pos = -1;
+                        pl_hash_put_atomic(w, dims.hashCap, c.pos, c.x, c.y, c.th);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int i = 0; i < nchild; i++) {
+                        const PlChild& c = s.child[i];
+                        if (c.cls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)c.pos);
+                        else if (c.cls == CL_IMPROVE) {
+                            PlNode& ch = w.nodes[c.found];
+                            ch.f = c.f; ch.g = c.g; ch.h = c.h;
+                            ch.parent_index = cn.index; ch.parent_pos = s.cur;
+                            ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
+                            w.heap[ch.heap_pos].f = c.f;      // current slot: earlier pushes of this pop may have moved it
+                        }
+                    }
+                }
+                __syncthreads();
+            } else
             for (;;) {
                 if (tid == 0) {
                     s.need_sweep = 0;
