@@ -22,6 +22,7 @@ EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
     "avp_check_batch", "avp_trig_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
     "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch",
+    "avp_hfield_id_capacity", "avp_hfield_queries",
 ]
 
 
@@ -97,8 +98,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(L, name).restype = C.c_int32
-        if hasattr(L, "avp_plan_workspace_bytes"):
-            L.avp_plan_workspace_bytes.restype = C.c_int64
+        L.avp_plan_workspace_bytes.restype = C.c_int64
+        L.avp_hfield_id_capacity.restype = C.c_int64
         if L.avp_sizeof_params() != C.sizeof(AvpParams):
             raise RuntimeError("avp_params layout mismatch between include/avp.h and _native.AvpParams")
         _lib = L
@@ -208,6 +209,26 @@ class DeviceMap:
                                        C.c_void_p(dr.data_ptr()) if maxpts > 0 else None), "avp_rs_optimal_batch")
         return dict(status=st.cpu().numpy(), L=L.cpu().numpy(), types=ty.cpu().numpy(), lens=le.cpu().numpy(),
                     npts=npts.cpu().numpy(), pts=pts.cpu().numpy(), dirs=dr.cpu().numpy())
+
+    # ---- heuristic field (diagnostic entry) ----------------------------------------------------------
+    def hfield_queries(self, goal_xy, queries, force=None) -> dict:
+        torch = self.torch
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 2)
+        nq = len(q)
+        f = np.zeros(nq, np.int32) if force is None else np.ascontiguousarray(force, dtype=np.int32)
+        cap = int(lib().avp_hfield_id_capacity(self.h))
+        nbytes = int(lib().avp_plan_workspace_bytes(self.h, C.c_int32(1), C.c_int32(16)))
+        ws = self.empty(nbytes, torch.uint8)
+        tq, tf = self.dev_tensor(q), self.dev_tensor(f)
+        od, om = self.empty(max(nq, 1), torch.int32), self.empty(max(nq, 1), torch.int32)
+        dist, flags, info = self.empty(cap, torch.int32), self.empty(cap, torch.uint8), self.empty(8, torch.int64)
+        g = (C.c_double * 2)(float(goal_xy[0]), float(goal_xy[1]))
+        chk(lib().avp_hfield_queries(self.h, g, C.c_void_p(tq.data_ptr()), C.c_void_p(tf.data_ptr()), C.c_int32(nq),
+                                     C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), C.c_void_p(od.data_ptr()), C.c_void_p(om.data_ptr()),
+                                     C.c_void_p(dist.data_ptr()), C.c_void_p(flags.data_ptr()), C.c_void_p(info.data_ptr())),
+            "avp_hfield_queries")
+        return dict(d=od.cpu().numpy()[:nq], miss=om.cpu().numpy()[:nq], dist=dist.cpu().numpy().view(np.uint32),
+                    flags=flags.cpu().numpy(), info=info.cpu().numpy())
 
     def __del__(self):
         try:

@@ -435,6 +435,92 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, PlShared& s, int64_t
     __syncthreads();
 }
 
+// Heuristic-sweep state for a new goal: clears the id-space arrays, builds the goal-anchored lattice
+// description (compute_h.py:89-186 positions are xf +- k*dx by repeated addition) and performs the first
+// update_openlist(initial_grid) (:207-210). Sets s.status = 6 when the lattice is not regular w.r.t. the
+// id grid or the goal lies outside the map. All threads.
+AVP_D void pl_sweep_init(const DevMap& m, const PlanWs& w, PlShared& s, const PlanDims& dims, double gx, double gy)
+{
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < dims.idCap; i += PL_THREADS) { w.dist[i] = PL_UNSEEN; w.flags[i] = 0; }
+    for (int64_t i = tid; i < dims.rowCap; i += PL_THREADS) w.aliasKey[i] = ~0ull;
+    if (tid == 0) {
+        s.E = 0; s.qover = 0; s.hasF = 0; s.dF = 0; s.idF = 0;
+        for (int q = 0; q < PL_NQ; q++) s.qcount[q] = 0;
+        s.h_cells = 0; s.h_misses = 0;
+        const int col0 = (int)floor((gx - m.b0) / m.dx);
+        const int row0 = (int)floor((m.b3 - gy) / m.dy);
+        const int orow0 = (int)floor((gy - m.b2) / m.dy) - 1;
+        int regular = 1;
+        int colMin = col0, colMax = col0, rowMin = row0, rowMax = row0;
+        double v = gx;
+        for (int a = 1;; a++) { v = v + m.dx; if (!(v <= m.b1)) break; const int c = (int)floor((v - m.b0) / m.dx); if (c != col0 + a) regular = 0; colMax = col0 + a; }
+        v = gx;
+        for (int a = 1;; a++) { v = v - m.dx; if (!(v >= m.b0)) break; const int c = (int)floor((v - m.b0) / m.dx); if (c != col0 - a) regular = 0; colMin = col0 - a; }
+        v = gy;
+        for (int b = 1;; b++) {
+            v = v + m.dy; if (!(v <= m.b3)) break;
+            const int r = (int)floor((m.b3 - v) / m.dy), o = (int)floor((v - m.b2) / m.dy) - 1;
+            if (r != row0 - b || o != orow0 + b) regular = 0;
+            rowMin = row0 - b;
+        }
+        v = gy;
+        for (int b = 1;; b++) {
+            v = v - m.dy; if (!(v >= m.b2)) break;
+            const int r = (int)floor((m.b3 - v) / m.dy), o = (int)floor((v - m.b2) / m.dy) - 1;
+            if (r != row0 + b || o != orow0 - b) regular = 0;
+            rowMax = row0 + b;
+        }
+        if (!(gx >= m.b0 && gx <= m.b1 && gy >= m.b2 && gy <= m.b3)) regular = 0;
+        if (colMin < 0 || colMax > m.S || rowMin < 0 || rowMax > m.Sy + 1) regular = 0;
+        s.col0 = col0; s.row0 = row0; s.orow0 = orow0; s.colMin = colMin; s.colMax = colMax; s.rowMin = rowMin; s.rowMax = rowMax;
+        s.alias = (colMax == m.S) ? 1 : 0;
+        s.goal_id = (int64_t)col0 + (int64_t)row0 * m.S;
+        s.regular = regular;
+        if (!regular) s.status = 6;
+    }
+    __syncthreads();
+    if (s.status == 0 && tid < 8) {
+        const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
+        const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
+        const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
+        pl_relax(m, w, s, s.col0 + dc[tid], s.row0 + dr[tid], cost[tid], 0, s.goal_id, tid);
+    }
+    __syncthreads();
+}
+
+// Test hook: the heuristic field alone. One workgroup runs the reference's query sequence
+// (Dijkstra.compute_path calls, compute_h.py:198-214, preceded by the closed-list lookup of
+// hybrid_a_star.py:272-280 unless force[i]) and dumps the distances, terminator flags and the closed frontier.
+__global__ __launch_bounds__(PL_THREADS) void hfield_kernel(DevMap m, double gx, double gy, const double* __restrict__ queries,
+                                                            const int32_t* __restrict__ force, int32_t nq, int32_t maxNodes,
+                                                            char* __restrict__ workspace, int32_t* __restrict__ out_d,
+                                                            int32_t* __restrict__ out_miss, uint32_t* __restrict__ out_dist,
+                                                            uint8_t* __restrict__ out_flags, int64_t* __restrict__ out_info)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
+    const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
+    const PlanWs w = plan_carve(workspace, dims);
+    if (threadIdx.x == 0) { s.status = 0; for (int k = 0; k < 10; k++) s.phase[k] = 0; }
+    __syncthreads();
+    pl_sweep_init(m, w, s, dims, gx, gy);
+    for (int i = 0; i < nq && s.status == 0; i++) {
+        const int64_t id = avp_pos_to_index(m, queries[2 * i], queries[2 * i + 1]);
+        uint32_t hd = PL_UNSEEN;
+        const uint32_t d0 = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
+        const bool hit = !force[i] && pl_hquery_hit(m, s, id, d0, hd);
+        if (!hit) { pl_hquery_miss(m, w, s, id); hd = s.hq_d; }
+        if (threadIdx.x == 0) { out_d[i] = hd == PL_UNSEEN ? -1 : (int32_t)hd; out_miss[i] = hit ? 0 : 1; }
+        __syncthreads();
+    }
+    for (int64_t i = threadIdx.x; i < dims.idCap; i += PL_THREADS) { out_dist[i] = w.dist[i]; out_flags[i] = w.flags[i]; }
+    if (threadIdx.x == 0) {
+        out_info[0] = s.status; out_info[1] = s.hasF ? (int64_t)s.dF : -1; out_info[2] = s.idF; out_info[3] = s.goal_id;
+        out_info[4] = s.E; out_info[5] = s.h_cells; out_info[6] = s.h_misses; out_info[7] = dims.idCap;
+    }
+}
+
 // hybrid_a_star.py:243-259
 AVP_D double pl_node_cost(const avp_params& p, int node_forward, double node_theta, double father_theta, int father_gear)
 {
@@ -687,60 +773,18 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
         // ---- init ------------------------------------------------------------------------------
         const long long t_init0 = clock64();
-        for (int64_t i = tid; i < dims.idCap; i += PL_THREADS) { w.dist[i] = PL_UNSEEN; w.flags[i] = 0; }
-        for (int64_t i = tid; i < dims.rowCap; i += PL_THREADS) w.aliasKey[i] = ~0ull;
         for (int64_t i = tid; i < dims.hashCap; i += PL_THREADS) w.hash[i] = 0;
         if (tid == 0) {
-            s.status = 0; s.done = 0; s.E = 0; s.qover = 0; s.hasF = 0; s.dF = 0; s.idF = 0;
-            for (int q = 0; q < PL_NQ; q++) s.qcount[q] = 0;
-            s.h_cells = 0; s.h_misses = 0; s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0;
+            s.status = 0; s.done = 0;
+            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0;
             s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
             for (int k = 0; k < 10; k++) s.phase[k] = 0;
             s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
             s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
-            // lattice anchored at the goal: columns/rows reachable by repeated +-pitch (compute_h.py:89-186)
-            const int col0 = (int)floor((gx - m.b0) / m.dx);
-            const int row0 = (int)floor((m.b3 - gy) / m.dy);
-            const int orow0 = (int)floor((gy - m.b2) / m.dy) - 1;
-            int regular = 1;
-            int colMin = col0, colMax = col0, rowMin = row0, rowMax = row0;
-            double v = gx;
-            for (int a = 1;; a++) { v = v + m.dx; if (!(v <= m.b1)) break; const int c = (int)floor((v - m.b0) / m.dx); if (c != col0 + a) regular = 0; colMax = col0 + a; }
-            v = gx;
-            for (int a = 1;; a++) { v = v - m.dx; if (!(v >= m.b0)) break; const int c = (int)floor((v - m.b0) / m.dx); if (c != col0 - a) regular = 0; colMin = col0 - a; }
-            v = gy;
-            for (int b = 1;; b++) {
-                v = v + m.dy; if (!(v <= m.b3)) break;
-                const int r = (int)floor((m.b3 - v) / m.dy), o = (int)floor((v - m.b2) / m.dy) - 1;
-                if (r != row0 - b || o != orow0 + b) regular = 0;
-                rowMin = row0 - b;
-            }
-            v = gy;
-            for (int b = 1;; b++) {
-                v = v - m.dy; if (!(v >= m.b2)) break;
-                const int r = (int)floor((m.b3 - v) / m.dy), o = (int)floor((v - m.b2) / m.dy) - 1;
-                if (r != row0 + b || o != orow0 - b) regular = 0;
-                rowMax = row0 + b;
-            }
-            if (!(gx >= m.b0 && gx <= m.b1 && gy >= m.b2 && gy <= m.b3)) regular = 0;
-            if (colMin < 0 || colMax > m.S || rowMin < 0 || rowMax > m.Sy + 1) regular = 0;
-            s.col0 = col0; s.row0 = row0; s.orow0 = orow0; s.colMin = colMin; s.colMax = colMax; s.rowMin = rowMin; s.rowMax = rowMax;
-            s.alias = (colMax == m.S) ? 1 : 0;
-            s.goal_id = (int64_t)col0 + (int64_t)row0 * m.S;
-            s.regular = regular;
-            if (!regular) s.status = 6;
         }
-        __syncthreads();
+        pl_sweep_init(m, w, s, dims, gx, gy);
 
         if (s.status == 0) {
-            // first update_openlist(initial_grid): the goal's 8 neighbours at 10/14 (compute_h.py:207-210)
-            if (tid < 8) {
-                const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
-                const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
-                const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
-                pl_relax(m, w, s, s.col0 + dc[tid], s.row0 + dr[tid], cost[tid], 0, s.goal_id, tid);
-            }
-            __syncthreads();
             // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
             const int64_t sid = avp_pos_to_index(m, sx, sy);
             pl_hquery_miss(m, w, s, sid);

@@ -164,6 +164,22 @@ int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, 
                        int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
                        double* paths, int32_t max_path, double* trace, int32_t max_trace);
 
+/*
+ * Replaces: Dijkstra.compute_path / the closed-list lookup of calc_node_heuristic
+ * (path_plan/compute_h.py:198-214, hybrid_a_star.py:268-283) for ONE goal and a sequence of queries
+ * (test / diagnostic entry; avp_plan_batch runs the same sweep inside the planner). goal_xy: host.
+ * queries: device nq x 2 positions; force[i] != 0 skips the closed-list lookup (the initial
+ * compute_path(x0, y0) of hybrid_a_star.__init__). Outputs (device): out_dist_q[i] distance (-1
+ * unreachable), out_miss[i] 1 if the sweep was extended, out_dist/out_flags: avp_hfield_id_capacity()
+ * entries, distance (0x7fffffff unseen) and terminator flag per grid id; out_info[8]: status, frontier
+ * distance, frontier id, goal id, expanded buckets, cells expanded, sweep extensions, id capacity.
+ * workspace: avp_plan_workspace_bytes(map, 1, 16) bytes.
+ */
+int64_t avp_hfield_id_capacity(avp_map* map);
+int32_t avp_hfield_queries(avp_map* map, const double goal_xy[2], const double* queries, const int32_t* force,
+                           int32_t nq, void* workspace, int64_t workspace_bytes, int32_t* out_dist_q,
+                           int32_t* out_miss, uint32_t* out_dist, uint8_t* out_flags, int64_t* out_info);
+
 /* Device evaluation of the shared scalar maths (test hook): out_sin/out_cos = avp_sin/avp_cos(x). */
 int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos);
 /* Device IEEE check hook: q = a / b, r = sqrt(|a|), h = hypot(a, b) as the kernels compute them. */
