@@ -47,7 +47,12 @@ def _run(k, goal, queries, vehicle, cfg):
     # and the device's closed set (key <= frontier) is the same set of ids
     dF, idF = int(r["info"][1]), int(r["info"][2])
     seen = np.where(gd != 0x7fffffff)[0]
-    closed_dev = {int(i_) for i_ in seen if (int(gd[i_]), int(i_)) <= (dF, idF)}
+    if want_d[-1] < 0:
+        # unreachable query: the reference swept every reachable cell before blocking (compute_h.py:77)
+        closed_dev = {int(i_) for i_ in seen}
+        dF, idF = 1 << 40, 0
+    else:
+        closed_dev = {int(i_) for i_ in seen if (int(gd[i_]), int(i_)) <= (dF, idF)}
     closed_ref = set(first.keys())
     closed_ref.discard(goal_id) if int(gd[goal_id]) == 0x7fffffff or (int(gd[goal_id]), goal_id) > (dF, idF) else None
     diff = closed_dev ^ closed_ref
