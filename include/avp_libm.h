@@ -12,10 +12,11 @@
  * written out), so GPU == CPU-port exactly, and the port-vs-glibc difference is confined to the
  * last ulp of these four functions (tests/test_oracle_portable.py quantifies it).
  *
- * Algorithms: the classic fdlibm argument reductions and minimax kernels (atan: 4 breakpoints +
- * odd polynomial; asin/acos: rational R(x^2) with sqrt reduction near 1; tan: Cody-Waite pi/2
- * reduction + odd kernel with 1/tan for odd quadrants). Accuracy < 1 ulp on the ranges the RS words
- * use (checked against libm in tests/test_math_host.py).
+ * Algorithms: atan2/asin/acos go through one double-double atan core (65-entry table of atan(k/64),
+ * double-double argument reduction, one final rounding) and are correctly rounded except within
+ * ~2^-15 ulp of a rounding boundary; they differ from glibc essentially only where glibc itself is
+ * not correctly rounded (~0.05-0.2 % of calls). tan is the fdlibm kernel (< 1 ulp; used by the two SLS
+ * words only). Special cases use the classic fdlibm plumbing. Checked in tests/test_math_host.py.
  */
 #ifndef AVP_LIBM_H
 #define AVP_LIBM_H
@@ -30,6 +31,15 @@
 #define AVP_LIBM_FN static inline
 #endif
 #endif
+
+#ifndef AVP_LIBM_TAB
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AVP_LIBM_TAB static __device__ const
+#else
+#define AVP_LIBM_TAB static const
+#endif
+#endif
+#include "avp_atan_tab.h"
 
 AVP_LIBM_FN uint32_t avpm_hi(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); }
 AVP_LIBM_FN uint32_t avpm_lo(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; }
@@ -74,8 +84,123 @@ AVP_LIBM_FN double avp_atan(double x)
     return neg ? -z : z;
 }
 
-/* ---- atan2 ----------------------------------------------------------------------------------- */
+/* ---- nearly correctly rounded atan2 / asin / acos (double-double core) ----------------------------
+ * avpm_atan_dd: atan(u), u = uh + ul >= 0, as an unevaluated sum zh + zl with relative error ~2^-68.
+ *   u <= 1: k = round(64 u), c = k/64, t = (u - c)/(1 + u c) in double-double (|t| <= 2^-7),
+ *           atan u = atan c (table, double-double) + t - t^3/3 + ... - t^11/11
+ *   u  > 1: atan u = pi/2 - atan(1/u), 1/u in double-double.
+ * The callers keep double-double until one final rounding, so results differ from the correctly
+ * rounded value only when the exact value lies within ~2^-15 ulp of a rounding boundary. */
+AVP_LIBM_FN double avp_atan2_fd(double y, double x);
+AVP_LIBM_FN double avp_asin_fd(double x);
+AVP_LIBM_FN double avp_acos_fd(double x);
+AVP_LIBM_FN void avpm_two_sum(double a, double b, double* s, double* e)
+{
+    const double t = a + b;
+    const double bb = t - a;
+    *e = (a - (t - bb)) + (b - bb);
+    *s = t;
+}
+AVP_LIBM_FN void avpm_div_dd(double nh, double nl, double dh, double dl, double* qh, double* ql)
+{
+    const double q1 = nh / dh;
+    const double r = __builtin_fma(-q1, dh, nh);
+    const double q2 = ((r + nl) - q1 * dl) / dh;
+    const double t = q1 + q2;
+    *ql = q2 - (t - q1);
+    *qh = t;
+}
+AVP_LIBM_FN void avpm_atan_dd(double uh, double ul, double* zh, double* zl)
+{
+    const double pio2_hi = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54;
+    int inv = 0;
+    if (uh > 1.0) { double rh, rl; avpm_div_dd(1.0, 0.0, uh, ul, &rh, &rl); uh = rh; ul = rl; inv = 1; }
+    const double kf = floor(uh * 64.0 + 0.5);
+    const int k = (int)kf;
+    const double c = kf * 0.015625;
+    /* t = (u - c) / (1 + u c) */
+    double nh = uh - c, nl = ul;                       /* uh - c is exact */
+    { const double t_ = nh + nl; nl = nl - (t_ - nh); nh = t_; }
+    const double ph = uh * c;
+    const double pl = __builtin_fma(uh, c, -ph) + ul * c;
+    const double dh = 1.0 + ph;
+    const double dl = ((1.0 - dh) + ph) + pl;
+    double th, tl;
+    avpm_div_dd(nh, nl, dh, dl, &th, &tl);
+    const double z = th * th;
+    const double P = z * (-0x1.5555555555555p-2 + z * (0x1.999999999999ap-3 + z * (-0x1.2492492492492p-3 + z * (0x1.c71c71c71c71cp-4 + z * -0x1.745d1745d1746p-4))));
+    const double corr = th * P;
+    double sh, se;
+    avpm_two_sum(AVP_ATAN_TAB[k][0], th, &sh, &se);
+    double low = ((se + AVP_ATAN_TAB[k][1]) + tl) + corr;
+    if (inv) {
+        double vh, ve;
+        avpm_two_sum(pio2_hi, -sh, &vh, &ve);
+        low = (ve + pio2_lo) - low;
+        sh = vh;
+    }
+    const double r_ = sh + low;
+    *zl = low - (r_ - sh);
+    *zh = r_;
+}
+
 AVP_LIBM_FN double avp_atan2(double y, double x)
+{
+    const double pi_hi = 0x1.921fb54442d18p+1, pi_lo_ = 0x1.1a62633145c07p-53;
+    if (x == x && y == y && x != 0.0 && y != 0.0 && fabs(x) < 0x1p1000 && fabs(y) < 0x1p1000 && fabs(x) > 0x1p-1000 && fabs(y) > 0x1p-1000) {
+        const double ax = fabs(x), ay = fabs(y);
+        const int ey = (int)((avpm_hi(ay) >> 20) & 0x7ff), ex = (int)((avpm_hi(ax) >> 20) & 0x7ff);
+        if (ey - ex <= 60 && ex - ey <= 60) {
+            double uh, ul, zh, zl;
+            avpm_div_dd(ay, 0.0, ax, 0.0, &uh, &ul);
+            avpm_atan_dd(uh, ul, &zh, &zl);
+            double r;
+            if (x < 0) { double vh, ve; avpm_two_sum(pi_hi, -zh, &vh, &ve); r = vh + ((ve + pi_lo_) - zl); }
+            else r = zh + zl;
+            return y < 0 ? -r : r;
+        }
+    }
+    return avp_atan2_fd(y, x);      /* zeros, infinities, NaN, extreme ratios: the classic special-case plumbing */
+}
+
+/* asin x = atan2(x, sqrt(1 - x^2)), acos x = atan2(sqrt(1 - x^2), x), with 1 - x^2 and its root in double-double */
+AVP_LIBM_FN void avpm_sqrt1mx2_dd(double x, double* sh, double* sl)
+{
+    const double p = x * x, e = __builtin_fma(x, x, -p);
+    double wh, we;
+    avpm_two_sum(1.0, -p, &wh, &we);
+    const double wl = we - e;
+    const double s = sqrt(wh);
+    const double rem = __builtin_fma(-s, s, wh) + wl;
+    *sh = s;
+    *sl = rem / (2.0 * s);
+}
+AVP_LIBM_FN double avp_asin(double x)
+{
+    const double ax = fabs(x);
+    if (!(ax < 1.0) || ax < 0x1p-26) return avp_asin_fd(x);
+    double sh, sl, uh, ul, zh, zl;
+    avpm_sqrt1mx2_dd(ax, &sh, &sl);
+    avpm_div_dd(ax, 0.0, sh, sl, &uh, &ul);
+    avpm_atan_dd(uh, ul, &zh, &zl);
+    const double r = zh + zl;
+    return x < 0 ? -r : r;
+}
+AVP_LIBM_FN double avp_acos(double x)
+{
+    const double pi_hi = 0x1.921fb54442d18p+1, pi_lo_ = 0x1.1a62633145c07p-53;
+    const double ax = fabs(x);
+    if (!(ax < 1.0) || ax < 0x1p-26) return avp_acos_fd(x);
+    double sh, sl, uh, ul, zh, zl;
+    avpm_sqrt1mx2_dd(ax, &sh, &sl);
+    avpm_div_dd(sh, sl, ax, 0.0, &uh, &ul);
+    avpm_atan_dd(uh, ul, &zh, &zl);
+    if (x < 0) { double vh, ve; avpm_two_sum(pi_hi, -zh, &vh, &ve); return vh + ((ve + pi_lo_) - zl); }
+    return zh + zl;
+}
+
+/* ---- fdlibm-form atan2 / asin / acos: special cases (zeros, infinities, NaN, |x| >= 1, tiny x) ---------- */
+AVP_LIBM_FN double avp_atan2_fd(double y, double x)
 {
     const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
     const double pi_o_2 = 1.5707963267948965580E+00, pi_o_4 = 7.8539816339744827900E-01;
@@ -136,7 +261,7 @@ AVP_LIBM_FN double avpm_asin_R(double t)
     return p / q;
 }
 
-AVP_LIBM_FN double avp_asin(double x)
+AVP_LIBM_FN double avp_asin_fd(double x)
 {
     const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pio4_hi = 7.85398163397448278999e-01;
     double t, w, p, q, c, r, s;
@@ -166,7 +291,7 @@ AVP_LIBM_FN double avp_asin(double x)
     return (hx >> 31) ? -t : t;
 }
 
-AVP_LIBM_FN double avp_acos(double x)
+AVP_LIBM_FN double avp_acos_fd(double x)
 {
     const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
     double z, r, s, w, c, df;

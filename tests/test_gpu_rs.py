@@ -52,7 +52,7 @@ def test_rs_vs_reference_golden(vehicle, cfg):
     assert (r["status"] == 0).all()
     assert np.abs(r["L"] - g4["L"]).max() < 1e-12
     same = (r["types"] == g4["types"]).all(axis=1)
-    assert same.mean() > 0.97
+    assert same.mean() > 0.999
     sm = same[:ns]
     d = np.abs(r["pts"][:ns][sm][:, :k] - g4["pts"][sm])
     d[..., 2] = np.minimum(d[..., 2], np.abs(d[..., 2] - 2 * np.pi))

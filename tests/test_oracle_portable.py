@@ -20,7 +20,8 @@ def test_rs_portable_vs_reference(vehicle, cfg):
     assert (r["status"] == 0).all()
     assert np.abs(r["L"] - g4["L"]).max() < 1e-12            # the optimum length never changes
     same = (r["types"] == g4["types"]).all(axis=1)
-    assert same.mean() > 0.97, same.mean()
+    assert same.mean() > 0.999, same.mean()          # measured 0.9999: the flips are exact ties decided by glibc's
+                                                     # own misroundings (it is not correctly rounded either)
     ns, k = g4["pts"].shape[:2]
     sm = same[:ns]
     d = np.abs(r["pts"][:ns][sm][:, :k] - g4["pts"][sm])
@@ -38,9 +39,9 @@ def test_rs_portable_vs_reference(vehicle, cfg):
 
 
 # golden problems on which the portable arithmetic resolves a tie differently from glibc (measured; see
-# DESIGN.md "Numerics"): Case18 diverges at pop 466 of 1004 where one straight-ahead child's RS word sits
-# on a validity boundary (t >= 0) decided by the last bit of atan2.
-KNOWN_TIE_DIVERGENCE = {"g6_trace_case18.npz"}
+# DESIGN.md "Numerics"). With the nearly correctly rounded atan2/asin/acos of include/avp_libm.h there is
+# none among the 33 finished golden plans (the first, fdlibm-accuracy version diverged on Case18 at pop 466).
+KNOWN_TIE_DIVERGENCE = set()
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g6_trace_case*.npz")) + glob.glob(os.path.join(GOLD, "g7_random_case*.npz"))))
