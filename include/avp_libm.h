@@ -374,7 +374,7 @@ AVP_LIBM_FN double avpm_ktan(double x, double y, int iy)
 }
 
 /* tan for |x| <= ~1e5 (the RS words use |x| < pi): two-step Cody-Waite reduction by pi/2 */
-AVP_LIBM_FN double avp_tan(double x)
+AVP_LIBM_FN double avp_tan_fd(double x)
 {
     const double invpio2 = 6.36619772367581382433e-01;
     const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
@@ -404,6 +404,27 @@ AVP_LIBM_FN double avp_tan(double x)
     y1 = (r - y0) - w;
     if (avpm_hi(x) >> 31) { y0 = -y0; y1 = -y1; n = -n; }
     return avpm_ktan(y0, y1, 1 - ((n & 1) << 1));
+}
+
+/* tan, nearly correctly rounded on |x| < 3.2 (the SLS words use 0 < x < pi): one Newton step on
+ * atan(t) = x with the double-double atan core: t = t0 + (y - atan t0)(1 + t0^2), y = x reduced by +-pi. */
+AVP_LIBM_FN double avp_tan(double x)
+{
+    const double pi_hi = 0x1.921fb54442d18p+1, pi_lo_ = 0x1.1a62633145c07p-53, pio2 = 0x1.921fb54442d18p+0;
+    const double t0 = avp_tan_fd(x);
+    const double a = fabs(t0);
+    if (!(fabs(x) < 3.2) || !(a > 0x1p-20) || !(a < 0x1p20)) return t0;
+    double zh, zl;
+    avpm_atan_dd(a, 0.0, &zh, &zl);
+    if (t0 < 0) { zh = -zh; zl = -zl; }
+    /* y = x - n*pi with n in {-1, 0, 1} so that y is in (-pi/2, pi/2) */
+    double yh = x, yl = 0.0;
+    if (x > pio2) { double vh, ve; avpm_two_sum(x, -pi_hi, &vh, &ve); yh = vh; yl = ve - pi_lo_; }
+    else if (x < -pio2) { double vh, ve; avpm_two_sum(x, pi_hi, &vh, &ve); yh = vh; yl = ve + pi_lo_; }
+    double eh, ee;
+    avpm_two_sum(yh, -zh, &eh, &ee);
+    const double err = eh + ((ee + yl) - zl);
+    return t0 + err * (1.0 + t0 * t0);
 }
 
 #endif /* AVP_LIBM_H */
