@@ -29,8 +29,7 @@
 #define PL_NQ 4                       // rotating bucket queues
 #define PL_MAXCHILD 32
 #define PL_RSQ 11                     // RS queries evaluated per pass (46 words each): the shot + 10 children
-#define PL_CHK_MAX 160                // poses per cooperative collision pass
-#define PL_CHK_QCAP 12288             // (pose, obstacle point) candidates per pass
+#define PL_CHK_MAX 1280               // poses per collision pass (shot samples + sub-steps)
 #define PL_RS_CAP 1024                // samples of one RS shot
 #define PL_UNSEEN 0x7fffffffu
 #define PL_TRACE_W 11
@@ -186,6 +185,16 @@ struct PlChild {
 };
 enum { CL_SKIP = 0, CL_NEW_CLOSED = 1, CL_NEW_OPEN = 2, CL_IMPROVE = 3, CL_KEEP = 4 };
 
+#define PL_WPOSE 8                    // poses per wave per collision pass
+#define PL_WQCAP 1024                 // (pose, point) candidates per wave
+struct PlWaveChk {
+    Footprint fp[PL_WPOSE];
+    int16_t rng[PL_WPOSE][4];         // ixlo, ncol, iylo, iyhi
+    uint32_t hit[PL_WPOSE];
+    int32_t qn, over;
+    uint32_t q[PL_WQCAP];             // pose << 24 | ix << 12 | iy   (nx, ny < 4096 on this path)
+};
+
 struct PlShared {
     // lattice / id space (compute_h.py lattice anchored at the goal)
     int32_t col0, row0, colMin, colMax, rowMin, rowMax, orow0, alias;   // alias: a lattice column has col == S
@@ -229,13 +238,10 @@ struct PlShared {
     double smp_l[PL_RS_CAP];
     int8_t smp_seg[PL_RS_CAP];
     double seg_o[AVP_RS_MAXSEG][3];
-    // cooperative collision pass
-    int32_t chk_qn, chk_qover;
-    double chk_pose[PL_CHK_MAX][3];
-    Footprint chk_fp[PL_CHK_MAX];
-    int16_t chk_rng[PL_CHK_MAX][4];   // ixlo, ncol, iylo, iyhi
-    uint32_t chk_hit[PL_CHK_MAX];
-    uint32_t chk_q[PL_CHK_QCAP];      // pose << 24 | ix << 12 | iy   (nx, ny < 4096 on this path)
+    // wave-local cooperative collision passes: every wave owns a scratch area (no workgroup barrier inside)
+    int32_t chk_qover;
+    PlWaveChk wchk[PL_THREADS / 64];
+    uint32_t chk_hit[PL_CHK_MAX];     // result per pose of the current pass
 };
 
 static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
@@ -614,55 +620,49 @@ AVP_D int pl_rs_fold(PlShared& s, const avp_params& p, int q, RsPath& out)
     return 0;
 }
 
-// ---- parallel Reeds-Shepp sampling (rs_curve.py:537-594 + :125-131) ---------------------------------
-// Thread 0 replays the index bookkeeping of generate_local_course (which output index each
-// interpolate() call writes; later writes overwrite earlier ones) and chains the segment origins;
-// all threads then evaluate the interpolations, thread 0 trims the trailing px == 0.0 entries and
-// all threads apply the world transform. Results (x, y, pi_2_pi(yaw)) in w.rsbuf, dirs in w.rsdir.
-AVP_D void pl_rs_sample(const PlanWs& w, PlShared& s, const avp_params& p, double q0x, double q0y, double q0t)
+// ---- parallel Reeds-Shepp sampling (rs_curve.py:537-594 + :125-131), in stages -----------------------
+// A (one thread): replay the index bookkeeping of generate_local_course (which output index each
+//   interpolate() call writes; later writes overwrite earlier ones) and chain the segment origins.
+// B (all threads): evaluate the interpolations in the local frame.
+// C (one thread): drop the trailing px == 0.0 entries.  D (all): world transform (fused with the checks).
+AVP_D void pl_rs_sample_replay(PlShared& s, const avp_params& p)
 {
     const double maxc = p.maxc;
-    if (threadIdx.x == 0) {
-        const RsPath& rp = s.rs;
-        const double step = 0.5 * maxc;
-        const int point_num = (int)(rp.L / step) + rp.n + 3;
-        s.smp_point_num = point_num;
-        s.smp_hi = 0;
-        if (point_num > PL_RS_CAP) s.rs_status = 5;
-        else {
-            int ind = 1, hi = 0;
-            double d = rp.l[0] > 0.0 ? step : -step;
-            double pd = d, ll = 0.0;
-            double ox = 0.0, oy = 0.0, oyaw = 0.0;               // px[1] before any write
-            int end_ind = -1;                                     // index holding the previous segment's end
-            for (int i = 0; i < rp.n; i++) {
-                const double l = rp.l[i];
-                d = l > 0.0 ? step : -step;
-                // origin = px[ind]: the previous segment's end point if that is what index `ind` holds
-                s.seg_o[i][0] = ox; s.seg_o[i][1] = oy; s.seg_o[i][2] = oyaw;
-                ind -= 1;
-                if (i >= 1 && (rp.l[i - 1] * rp.l[i]) > 0) pd = -d - ll; else pd = d - ll;
-                while (fabs(pd) <= fabs(l)) {
-                    ind += 1;
-                    s.smp_l[ind] = pd; s.smp_seg[ind] = (int8_t)i;
-                    pd += d;
-                }
-                ll = l - pd - d;
-                ind += 1;
-                s.smp_l[ind] = l; s.smp_seg[ind] = (int8_t)i;
-                if (ind > hi) hi = ind;
-                end_ind = ind;
-                // next origin = this segment's end point
-                double ex, ey, eyaw;
-                rs_interpolate(l, rp.t[i], maxc, ox, oy, oyaw, ex, ey, eyaw);
-                ox = ex; oy = ey; oyaw = eyaw;
-            }
-            (void)end_ind;
-            s.smp_hi = hi;
+    const RsPath& rp = s.rs;
+    const double step = 0.5 * maxc;
+    const int point_num = (int)(rp.L / step) + rp.n + 3;
+    s.smp_point_num = point_num;
+    s.smp_hi = 0;
+    if (point_num > PL_RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) { s.rs_status = 5; return; }
+    int ind = 1, hi = 0;
+    double d = rp.l[0] > 0.0 ? step : -step;
+    double pd = d, ll = 0.0;
+    double ox = 0.0, oy = 0.0, oyaw = 0.0;               // px[1] before any write
+    for (int i = 0; i < rp.n; i++) {
+        const double l = rp.l[i];
+        d = l > 0.0 ? step : -step;
+        s.seg_o[i][0] = ox; s.seg_o[i][1] = oy; s.seg_o[i][2] = oyaw;   // origin = the previous segment's end point
+        ind -= 1;
+        if (i >= 1 && (rp.l[i - 1] * rp.l[i]) > 0) pd = -d - ll; else pd = d - ll;
+        while (fabs(pd) <= fabs(l)) {
+            ind += 1;
+            s.smp_l[ind] = pd; s.smp_seg[ind] = (int8_t)i;
+            pd += d;
+        }
+        ll = l - pd - d;
+        ind += 1;
+        s.smp_l[ind] = l; s.smp_seg[ind] = (int8_t)i;
+        if (ind > hi) hi = ind;
+        if (i + 1 < rp.n) {
+            double ex, ey, eyaw;
+            rs_interpolate(l, rp.t[i], maxc, ox, oy, oyaw, ex, ey, eyaw);
+            ox = ex; oy = ey; oyaw = eyaw;
         }
     }
-    __syncthreads();
-    if (s.rs_status) return;
+    s.smp_hi = hi;
+}
+AVP_D void pl_rs_sample_local(const PlanWs& w, const PlShared& s, const avp_params& p)
+{
     const int point_num = s.smp_point_num, hi = s.smp_hi;
     for (int i = threadIdx.x; i < point_num; i += PL_THREADS) {
         double px = 0.0, py = 0.0, pyaw = 0.0;
@@ -671,80 +671,84 @@ AVP_D void pl_rs_sample(const PlanWs& w, PlShared& s, const avp_params& p, doubl
         else if (i <= hi) {
             const int sg = s.smp_seg[i];
             const double l = s.smp_l[i];
-            rs_interpolate(l, s.rs.t[sg], maxc, s.seg_o[sg][0], s.seg_o[sg][1], s.seg_o[sg][2], px, py, pyaw);
+            rs_interpolate(l, s.rs.t[sg], p.maxc, s.seg_o[sg][0], s.seg_o[sg][1], s.seg_o[sg][2], px, py, pyaw);
             dr = l > 0.0 ? 1 : -1;
         }
         w.rsbuf[3 * i] = px; w.rsbuf[3 * i + 1] = py; w.rsbuf[3 * i + 2] = pyaw; w.rsdir[i] = dr;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int np = point_num;
-        while (np > 0 && w.rsbuf[3 * (np - 1)] == 0.0) np--;
-        s.rs_npts = np;
-    }
-    __syncthreads();
-    const double cm = avp_cos(-q0t), sm = avp_sin(-q0t);
-    for (int i = threadIdx.x; i < s.rs_npts; i += PL_THREADS) {
-        const double ix = w.rsbuf[3 * i], iy = w.rsbuf[3 * i + 1];
-        w.rsbuf[3 * i] = cm * ix + sm * iy + q0x;
-        w.rsbuf[3 * i + 1] = -sm * ix + cm * iy + q0y;
-        w.rsbuf[3 * i + 2] = avp_pi_2_pi(w.rsbuf[3 * i + 2] + q0t);
-    }
-    __syncthreads();
+}
+AVP_D void pl_rs_sample_trim(const PlanWs& w, PlShared& s)
+{
+    int np = s.smp_point_num;
+    while (np > 0 && w.rsbuf[3 * (np - 1)] == 0.0) np--;
+    s.rs_npts = np;
 }
 
-// ---- cooperative collision pass over s.chk_pose[0..N) -> s.chk_hit (all threads) ---------------------
-// distance_checker semantics (collision_check.py:144-240). The work of a pose is spread over the
-// workgroup: one thread per (pose, map column under the AABB) gathers the near obstacle points from
-// the column bitmaps into an LDS queue, then one thread per (pose, point) runs the exact test.
-AVP_D void pl_check_set(const DevMap& m, const avp_params& p, PlShared& s, int N)
+// ---- wave-local cooperative collision pass (distance_checker semantics, collision_check.py:144-240) ----
+// One wave checks up to PL_WPOSE poses without any workgroup barrier: lanes set up the footprints, one
+// lane per (pose, map column under the AABB) gathers the near obstacle points from the column bitmaps into
+// the wave's LDS queue, one lane per (pose, point) runs the exact test. pose(k, x, y, th) supplies pose k of
+// this wave's chunk; hit flags are returned through out_hit[k] (LDS).
+template <typename PoseFn>
+AVP_D void pl_check_wave(const DevMap& m, const avp_params& p, PlShared& s, int count, PoseFn pose, uint32_t* out_hit)
 {
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    PlWaveChk& wc = s.wchk[threadIdx.x >> 6];
+    if (count <= 0) return;
     if (p.checker_kind == 1) {
-        for (int i = tid; i < N; i += PL_THREADS) s.chk_hit[i] = pl_check_pose(m, p, s.chk_pose[i][0], s.chk_pose[i][1], s.chk_pose[i][2]) ? 1u : 0u;
-        __syncthreads();
+        if (lane < count) { double x, y, th; pose(lane, x, y, th); out_hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
+        wave_sync();
         return;
     }
-    if (tid == 0) { s.chk_qn = 0; s.chk_qover = 0; }
-    for (int i = tid; i < N; i += PL_THREADS) {
+    if (lane == 0) { wc.qn = 0; wc.over = 0; }
+    if (lane < count) {
+        double x, y, th;
+        pose(lane, x, y, th);
         Footprint f;
-        avp_footprint_setup(p, s.chk_pose[i][0], s.chk_pose[i][1], s.chk_pose[i][2], f);
+        avp_footprint_setup(p, x, y, th, f);
         double xmin, xmax, ymin, ymax;
         avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
         const int ixlo = avp_first_ge(m.X, m.nx, m.b0, m.dx, xmin), ixhi = avp_last_le(m.X, m.nx, m.b0, m.dx, xmax);
         const int iylo = avp_first_ge(m.Y, m.ny, m.b2, m.dy, ymin), iyhi = avp_last_le(m.Y, m.ny, m.b2, m.dy, ymax);
         int ncol = ixhi - ixlo + 1;
         if (ncol < 0 || iylo > iyhi) ncol = 0;
-        s.chk_fp[i] = f;
-        s.chk_rng[i][0] = (int16_t)ixlo; s.chk_rng[i][1] = (int16_t)ncol; s.chk_rng[i][2] = (int16_t)iylo; s.chk_rng[i][3] = (int16_t)iyhi;
-        s.chk_hit[i] = 0;
+        wc.fp[lane] = f;
+        wc.rng[lane][0] = (int16_t)ixlo; wc.rng[lane][1] = (int16_t)ncol; wc.rng[lane][2] = (int16_t)iylo; wc.rng[lane][3] = (int16_t)iyhi;
+        wc.hit[lane] = 0;
     }
-    __syncthreads();
-    for (int t = tid; t < N * 64; t += PL_THREADS) {
+    wave_sync();
+    for (int t = lane; t < count * 64; t += 64) {
         const int i = t >> 6, c = t & 63;
-        if (c >= s.chk_rng[i][1]) continue;
-        const int ix = s.chk_rng[i][0] + c, iylo = s.chk_rng[i][2], iyhi = s.chk_rng[i][3];
+        if (c >= wc.rng[i][1]) continue;
+        const int ix = wc.rng[i][0] + c, iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
         for (int wd = iylo >> 6; wd <= (iyhi >> 6); wd++) {
             uint64_t bits = m.colBits[(size_t)ix * m.wpc + wd];
             if (wd == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
             if (wd == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
             if (!bits) continue;
             const int cnt = __popcll(bits);
-            int pos = atomicAdd(&s.chk_qn, cnt);
-            if (pos + cnt > PL_CHK_QCAP) { s.chk_qover = 1; continue; }
+            int pos = atomicAdd(&wc.qn, cnt);
+            if (pos + cnt > PL_WQCAP) { wc.over = 1; continue; }
             const uint32_t tag = ((uint32_t)i << 24) | ((uint32_t)ix << 12);
-            while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; s.chk_q[pos++] = tag | (uint32_t)((wd << 6) + bpos); }
+            while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)((wd << 6) + bpos); }
         }
     }
-    __syncthreads();
-    const int qn = min(s.chk_qn, PL_CHK_QCAP);
-    for (int e = tid; e < qn; e += PL_THREADS) {
-        const uint32_t ent = s.chk_q[e];
-        const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
-        if (s.chk_hit[i]) continue;
-        if (avp_footprint_point_hit(s.chk_fp[i], m.X[ix], m.Y[iy])) s.chk_hit[i] = 1;
+    wave_sync();
+    if (wc.over) {
+        // more candidates than the queue holds (dense clutter): every lane checks its own pose serially
+        if (lane < count) { double x, y, th; pose(lane, x, y, th); wc.hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
+    } else {
+        const int qn = wc.qn;
+        for (int e = lane; e < qn; e += 64) {
+            const uint32_t ent = wc.q[e];
+            const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
+            if (wc.hit[i]) continue;
+            if (avp_footprint_point_hit(wc.fp[i], m.X[ix], m.Y[iy])) wc.hit[i] = 1;
+        }
     }
-    __syncthreads();
+    wave_sync();
+    if (lane < count) out_hit[lane] = wc.hit[lane];
+    wave_sync();
 }
 
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
@@ -881,56 +885,73 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
             if (in_radius && s.rs_status) { if (tid == 0) s.status = s.rs_status == 4 ? 5 : 3; __syncthreads(); break; }
 
-            // ---- shot sampling ------------------------------------------------------------------------
-            if (in_radius) {
-                if (tid == 0) s.n_rs += 1;
-                pl_rs_sample(w, s, p, cn.x, cn.y, cn.th);
-                if (s.rs_status) { if (tid == 0) s.status = 5; __syncthreads(); break; }
+            // ---- shot sampling + collision passes -----------------------------------------------------
+            // Thread 0 replays the sampler's index bookkeeping while the other waves already check the
+            // 30 sub-step poses of the children (:185-204), which depend on neither the shot nor the RS words.
+            const int wave = tid >> 6, lane = tid & 63;
+            const int nwave = PL_THREADS / 64;
+            const int nsubs = nchild * p.n_sub;
+            auto substep_pose = [&](int t, double& x, double& y, double& th) {
+                const int ci = t / p.n_sub, j = t - ci * p.n_sub;
+                const int si = ci % p.n_steer;
+                const double td = ci < p.n_steer ? p.travel_ddt[j] : -p.travel_ddt[j];
+                th = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
+                x = cn.x + td * avp_cos(th);
+                y = cn.y + td * avp_sin(th);
+            };
+            if (in_radius && tid == 0) { s.n_rs += 1; pl_rs_sample_replay(s, p); }
+            {
+                // sub-steps: waves 1.. (all waves when there is no shot), PL_WPOSE poses per wave and round
+                const int w0 = in_radius ? 1 : 0, nw = nwave - w0;
+                const int per = min(PL_WPOSE, (nsubs + nw - 1) / nw);      // spread the poses evenly over the waves
+                if (wave >= w0) {
+                    for (int base = (wave - w0) * per; base < nsubs; base += nw * per) {
+                        const int cnt = min(per, nsubs - base);
+                        pl_check_wave(m, p, s, cnt, [&](int k, double& x, double& y, double& th) { substep_pose(base + k, x, y, th); },
+                                      &s.chk_hit[base]);
+                    }
+                }
             }
+            __syncthreads();
+            if (in_radius && s.rs_status) { if (tid == 0) s.status = 5; __syncthreads(); break; }
+            for (int t = tid; t < nsubs; t += PL_THREADS)
+                if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
             const long long t_g = clock64();
             if (tid == 0) s.phase[PH_SHOT_SAMPLE] += t_g - t_f0;
-
-            // ---- collision pass: shot samples (:335-345) then the sub-steps of every child (:185-204) ----
-            {
-                const int np = in_radius ? s.rs_npts : 0;
-                const int nsubs = nchild * p.n_sub;
-                const int total = np + nsubs;
-                for (int base = 0; base < total; base += PL_CHK_MAX) {
-                    const int cnt = min(PL_CHK_MAX, total - base);
-                    for (int k = tid; k < cnt; k += PL_THREADS) {
-                        const int g = base + k;
-                        if (g < np) {
-                            s.chk_pose[k][0] = w.rsbuf[3 * g]; s.chk_pose[k][1] = w.rsbuf[3 * g + 1];
-                            s.chk_pose[k][2] = avp_pi_2_pi(w.rsbuf[3 * g + 2]);        // :339
-                        } else {
-                            const int t = g - np;
-                            const int ci = t / p.n_sub, j = t - ci * p.n_sub;
-                            const int si = ci % p.n_steer;
-                            const double td = ci < p.n_steer ? p.travel_ddt[j] : -p.travel_ddt[j];
-                            const double th_i = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
-                            s.chk_pose[k][0] = cn.x + td * avp_cos(th_i);
-                            s.chk_pose[k][1] = cn.y + td * avp_sin(th_i);
-                            s.chk_pose[k][2] = th_i;
-                        }
+            if (in_radius) {
+                pl_rs_sample_local(w, s, p);
+                __syncthreads();
+                if (tid == 0) pl_rs_sample_trim(w, s);
+                __syncthreads();
+                // world transform (:125-131) fused with the collision pass over the samples (:335-345)
+                const int np = s.rs_npts;
+                const double cm = avp_cos(-cn.th), sm = avp_sin(-cn.th);
+                const int per = max(1, min(PL_WPOSE, (np + nwave - 1) / nwave));
+                for (int base = wave * per; base < np; base += nwave * per) {
+                    const int cnt = min(per, np - base);
+                    double tx = 0.0, ty = 0.0, tth = 0.0;
+                    if (lane < cnt) {
+                        const int g = base + lane;
+                        const double ix = w.rsbuf[3 * g], iy = w.rsbuf[3 * g + 1];
+                        tx = cm * ix + sm * iy + cn.x;
+                        ty = -sm * ix + cm * iy + cn.y;
+                        tth = avp_pi_2_pi(w.rsbuf[3 * g + 2] + cn.th);
+                        w.rsbuf[3 * g] = tx; w.rsbuf[3 * g + 1] = ty; w.rsbuf[3 * g + 2] = tth;
                     }
-                    __syncthreads();
-                    pl_check_set(m, p, s, cnt);
-                    if (s.chk_qover) { if (tid == 0) s.status = 5; }
-                    for (int k = tid; k < cnt; k += PL_THREADS) {
-                        if (!s.chk_hit[k]) continue;
-                        const int g = base + k;
-                        if (g < np) atomicMin(&s.rs_first_coll, g);
-                        else { const int t = g - np; const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
-                    }
-                    __syncthreads();
+                    // pose k is only ever requested by lane k: hand back the lane's own registers
+                    pl_check_wave(m, p, s, cnt, [&](int, double& x, double& y, double& th) { x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
+                    }, &s.chk_hit[nsubs + base]);
                 }
-                if (tid == 0 && in_radius) {
+                __syncthreads();
+                for (int g = tid; g < np; g += PL_THREADS) if (s.chk_hit[nsubs + g]) atomicMin(&s.rs_first_coll, g);
+                __syncthreads();
+                if (tid == 0) {
                     if (s.rs_first_coll != 0x7fffffff) { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
                     else s.n_checks += np;
                     if (!s.collision) s.done = 1;
                 }
-                __syncthreads();
             }
+            __syncthreads();
             const long long t_f = clock64();
             if (tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
             if (s.status != 0 || s.done) break;
