@@ -185,6 +185,9 @@ struct PlChild {
 };
 enum { CL_SKIP = 0, CL_NEW_CLOSED = 1, CL_NEW_OPEN = 2, CL_IMPROVE = 3, CL_KEEP = 4 };
 
+// Map tables used by the collision passes: either the HBM/L2 copies or the LDS-staged copies.
+struct MapTabs { const double* X; const double* Y; const uint64_t* bits; };
+
 #define PL_WPOSE 8                    // poses per wave per collision pass
 #define PL_WQCAP 1024                 // (pose, point) candidates per wave
 struct PlWaveChk {
@@ -245,6 +248,8 @@ struct PlShared {
 };
 
 static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
+static inline __host__ __device__ size_t pl_lds_tables_offset() { return (sizeof(PlShared) + 15) & ~(size_t)15; }
+static inline size_t pl_lds_tables_bytes(const DevMap& m) { return ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8; }
 
 AVP_D int32_t pl_bucket(uint32_t d) { return (int32_t)(d / 10u); }
 
@@ -599,24 +604,30 @@ AVP_D void pl_rs_accept(PlShared& s, const avp_params& p, int nq)
     __syncthreads();
 }
 
-// arg-min over the accepted words of query q with "<=" (the last of equal minima wins, rs_curve.py:103-108)
-AVP_D int pl_rs_fold(PlShared& s, const avp_params& p, int q, RsPath& out)
+// arg-min over the accepted words of query q with "<=" (the last of equal minima wins, rs_curve.py:103-108):
+// one wave per query, lane = word, butterfly reduction on (length, word index). All lanes of the wave call it;
+// the result is valid on every lane.
+AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
 {
+    const int lane = threadIdx.x & 63;
+    int acc = 0, wd = lane;
+    double Lm = 0.0;
+    if (lane < 46) { acc = s.w_acc[q * 46 + lane]; Lm = s.w_Lm[q * 46 + lane]; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int oacc = __shfl_xor(acc, d, 64), owd = __shfl_xor(wd, d, 64);
+        const double oL = __shfl_xor(Lm, d, 64);
+        const bool take = oacc && (!acc || oL < Lm || (oL == Lm && owd > wd));
+        if (take) { acc = oacc; wd = owd; Lm = oL; }
+    }
     out.n = 0; out.L = 0;
     if (s.w_err[q]) return 2;
-    int best = -1;
-    double bestL = 0;
-    for (int wd = 0; wd < 46; wd++) {
-        const int slot = q * 46 + wd;
-        if (!s.w_acc[slot]) continue;
-        if (best < 0 || s.w_Lm[slot] <= bestL) { best = wd; bestL = s.w_Lm[slot]; }
-    }
-    if (best < 0) return 1;
-    const RsWord W = RS_WORDS[best];
+    if (!acc) return 1;
+    const RsWord W = RS_WORDS[wd];
     const int8_t ty[5] = { W.a, W.b, W.c, W.d, W.e };
     out.n = W.n;
-    for (int i = 0; i < AVP_RS_MAXSEG; i++) { out.t[i] = i < W.n ? ty[i] : (int8_t)-1; out.l[i] = s.w_l[q * 46 + best][i]; }
-    out.L = s.w_Ln[q * 46 + best];
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) { out.t[i] = i < W.n ? ty[i] : (int8_t)-1; out.l[i] = s.w_l[q * 46 + wd][i]; }
+    out.L = s.w_Ln[q * 46 + wd];
     return 0;
 }
 
@@ -690,7 +701,7 @@ AVP_D void pl_rs_sample_trim(const PlanWs& w, PlShared& s)
 // the wave's LDS queue, one lane per (pose, point) runs the exact test. pose(k, x, y, th) supplies pose k of
 // this wave's chunk; hit flags are returned through out_hit[k] (LDS).
 template <typename PoseFn>
-AVP_D void pl_check_wave(const DevMap& m, const avp_params& p, PlShared& s, int count, PoseFn pose, uint32_t* out_hit)
+AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p, PlShared& s, int count, PoseFn pose, uint32_t* out_hit)
 {
     const int lane = threadIdx.x & 63;
     PlWaveChk& wc = s.wchk[threadIdx.x >> 6];
@@ -708,8 +719,8 @@ AVP_D void pl_check_wave(const DevMap& m, const avp_params& p, PlShared& s, int 
         avp_footprint_setup(p, x, y, th, f);
         double xmin, xmax, ymin, ymax;
         avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
-        const int ixlo = avp_first_ge(m.X, m.nx, m.b0, m.dx, xmin), ixhi = avp_last_le(m.X, m.nx, m.b0, m.dx, xmax);
-        const int iylo = avp_first_ge(m.Y, m.ny, m.b2, m.dy, ymin), iyhi = avp_last_le(m.Y, m.ny, m.b2, m.dy, ymax);
+        const int ixlo = avp_first_ge(mt.X, m.nx, m.b0, m.dx, xmin), ixhi = avp_last_le(mt.X, m.nx, m.b0, m.dx, xmax);
+        const int iylo = avp_first_ge(mt.Y, m.ny, m.b2, m.dy, ymin), iyhi = avp_last_le(mt.Y, m.ny, m.b2, m.dy, ymax);
         int ncol = ixhi - ixlo + 1;
         if (ncol < 0 || iylo > iyhi) ncol = 0;
         wc.fp[lane] = f;
@@ -722,7 +733,7 @@ AVP_D void pl_check_wave(const DevMap& m, const avp_params& p, PlShared& s, int 
         if (c >= wc.rng[i][1]) continue;
         const int ix = wc.rng[i][0] + c, iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
         for (int wd = iylo >> 6; wd <= (iyhi >> 6); wd++) {
-            uint64_t bits = m.colBits[(size_t)ix * m.wpc + wd];
+            uint64_t bits = mt.bits[(size_t)ix * m.wpc + wd];
             if (wd == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
             if (wd == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
             if (!bits) continue;
@@ -743,7 +754,7 @@ AVP_D void pl_check_wave(const DevMap& m, const avp_params& p, PlShared& s, int 
             const uint32_t ent = wc.q[e];
             const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
             if (wc.hit[i]) continue;
-            if (avp_footprint_point_hit(wc.fp[i], m.X[ix], m.Y[iy])) wc.hit[i] = 1;
+            if (avp_footprint_point_hit(wc.fp[i], mt.X[ix], mt.Y[iy])) wc.hit[i] = 1;
         }
     }
     wave_sync();
@@ -751,6 +762,7 @@ AVP_D void pl_check_wave(const DevMap& m, const avp_params& p, PlShared& s, int 
     wave_sync();
 }
 
+template <bool STAGE>
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                           const double* __restrict__ goals, int64_t n, int32_t maxNodes,
                                                           char* __restrict__ workspace, unsigned int* __restrict__ counter,
@@ -763,6 +775,19 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
     const int tid = threadIdx.x;
+    // STAGE: the column bitmaps and node coordinates of the map live in LDS behind PlShared for the whole
+    // (persistent) lifetime of the workgroup; otherwise they are read through L1/L2
+    MapTabs mt;
+    if (STAGE) {
+        uint64_t* lb = reinterpret_cast<uint64_t*>(pl_smem + pl_lds_tables_offset());
+        double* lx = reinterpret_cast<double*>(lb + (size_t)m.nx * m.wpc);
+        double* ly = lx + m.nx;
+        for (int i = tid; i < m.nx * m.wpc; i += PL_THREADS) lb[i] = m.colBits[i];
+        for (int i = tid; i < m.nx; i += PL_THREADS) lx[i] = m.X[i];
+        for (int i = tid; i < m.ny; i += PL_THREADS) ly[i] = m.Y[i];
+        mt.X = lx; mt.Y = ly; mt.bits = lb;
+        __syncthreads();
+    } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
     const int nchild = 2 * p.n_steer;
     const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
 
@@ -871,12 +896,14 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
                     });
                     pl_rs_accept(s, p, cnt);
-                    if (tid < cnt) {
-                        const int g = base + tid;
+                    for (int q = tid >> 6; q < cnt; q += PL_THREADS / 64) {
+                        const int g = base + q;
                         RsPath rp;
-                        const int st = pl_rs_fold(s, p, tid, rp);
-                        if (g == 0) { s.rs_status = in_radius ? st : 0; if (!st) s.rs = rp; }
-                        else { s.child[g - 1].rs_err = (int8_t)st; s.child[g - 1].L = st ? 0.0 : rp.L / p.maxc; }
+                        const int st = pl_rs_fold_wave(s, q, rp);
+                        if ((tid & 63) == 0) {
+                            if (g == 0) { s.rs_status = in_radius ? st : 0; if (!st) s.rs = rp; }
+                            else { s.child[g - 1].rs_err = (int8_t)st; s.child[g - 1].L = st ? 0.0 : rp.L / p.maxc; }
+                        }
                     }
                     __syncthreads();
                 }
@@ -907,7 +934,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (wave >= w0) {
                     for (int base = (wave - w0) * per; base < nsubs; base += nw * per) {
                         const int cnt = min(per, nsubs - base);
-                        pl_check_wave(m, p, s, cnt, [&](int k, double& x, double& y, double& th) { substep_pose(base + k, x, y, th); },
+                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th) { substep_pose(base + k, x, y, th); },
                                       &s.chk_hit[base]);
                     }
                 }
@@ -939,7 +966,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         w.rsbuf[3 * g] = tx; w.rsbuf[3 * g + 1] = ty; w.rsbuf[3 * g + 2] = tth;
                     }
                     // pose k is only ever requested by lane k: hand back the lane's own registers
-                    pl_check_wave(m, p, s, cnt, [&](int, double& x, double& y, double& th) { x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
+                    pl_check_wave(m, mt, p, s, cnt, [&](int, double& x, double& y, double& th) { x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
                     }, &s.chk_hit[nsubs + base]);
                 }
                 __syncthreads();
