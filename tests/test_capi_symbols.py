@@ -49,3 +49,28 @@ def test_no_gpu_fails_loudly(cfg, vehicle):
     chk = collision_check.distance_checker(case_map_from_gold(1), vehicle, cfg)
     with pytest.raises(RuntimeError):
         chk.check(0.0, 0.0, 0.0)
+
+
+def test_map_create_without_gpu_reports_error(cfg, vehicle):
+    """No exception crosses the C-ABI: a missing device is a status code + message."""
+    import ctypes as C
+    import numpy as np
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from automatedvaletparking_amd import _native
+    from conftest import case_map_from_gold
+    L = _native.lib()
+    pk = case_map_from_gold(1).pack()
+    p = _native.make_params(cfg, vehicle)
+    h = C.c_void_p()
+    bnd = np.ascontiguousarray(pk["boundary"], dtype=np.float64)
+    rc = L.avp_map_create(C.byref(p), pk["occ"].ctypes.data_as(C.c_void_p), C.c_int32(pk["nx"]), C.c_int32(pk["ny"]),
+                          pk["xs"].ctypes.data_as(C.c_void_p), pk["ys"].ctypes.data_as(C.c_void_p), bnd.ctypes.data_as(C.c_void_p),
+                          pk["obs_ix"].ctypes.data_as(C.c_void_p), pk["obs_iy"].ctypes.data_as(C.c_void_p),
+                          C.c_int32(len(pk["obs_ix"])), C.c_int32(0), C.byref(h))
+    assert rc == -3 and "HIP device" in _native.last_error()
+    rc = L.avp_map_create(None, None, 0, 0, None, None, None, None, None, 0, 0, C.byref(h))
+    assert rc == -1
+    assert L.avp_check_batch(None, 0, None, None, None, C.c_int64(4), None, 0) == -1
