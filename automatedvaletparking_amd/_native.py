@@ -95,6 +95,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the hot path)")
+        # Load order matters: PyTorch-ROCm ships its own libamdhip64; if libavp_hip.so is loaded first it pulls
+        # the system copy and the process ends up with two HIP runtimes (the second one sees no device).
+        # Importing torch first lets our DT_NEEDED entry resolve to the runtime torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(L, name).restype = C.c_int32
