@@ -193,6 +193,18 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
     return AVP_OK;
 }
 
+AVP_EXPORT int32_t avp_corridor_batch(avp_map* map, double expand_dis, const double* x, const double* y, const double* th,
+                                      int64_t n, double* out)
+{
+    if (!map || n < 0 || !(expand_dis >= 0.0) || (n > 0 && (!x || !y || !th || !out))) return set_err(AVP_ERR_ARG, "avp_corridor_batch: bad argument");
+    if (n == 0) return AVP_OK;
+    HIPCHK(hipSetDevice(map->device));
+    hipLaunchKernelGGL(corridor_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, map->stream, map->dev, map->params, expand_dis,
+                       x, y, th, n, out);
+    HIPCHK(hipGetLastError());
+    return AVP_OK;
+}
+
 AVP_EXPORT int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos)
 {
     if (!map || n <= 0 || !x || !out_sin || !out_cos) return set_err(AVP_ERR_ARG, "avp_trig_batch: bad argument");

@@ -210,6 +210,75 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
     out[i] = hit ? 1 : 0;
 }
 
+// ---- corridor bounds (path_opti.compute_collision_H, optimization/path_optimazition.py:221-409) -------
+// One lane = one way-point. Near points = obstacle cells inside the footprint AABB grown by expand_dis
+// (inclusive, :254-280), enumerated through the column bitmaps. Each point is assigned to the first of the
+// four edge areas (right, front, left, rear) whose grown box contains it (strictly); the 4 heading cases x 4
+// areas of the reference collapse to: area k in heading case c faces quadrant (k + c - 1) mod 4 of
+// [(x+,y-), (x+,y+), (x-,y+), (x-,y-)]. out[i] = {x_max + x, y_max + y, x - x_min, y - y_min}.
+__global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, double expand, const double* __restrict__ x,
+                                                       const double* __restrict__ y, const double* __restrict__ th, int64_t n,
+                                                       double* __restrict__ out)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const double px = x[q], py = y[q], theta = th[q];
+    Footprint f;
+    avp_footprint_setup(p, px, py, theta, f);
+    double xlo, xhi, ylo, yhi;
+    avp_footprint_aabb(f, xlo, xhi, ylo, yhi);
+    xhi = xhi + expand; xlo = xlo - expand; yhi = yhi + expand; ylo = ylo - expand;
+    double area[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = (i + 1) & 3;
+        area[i][0] = f.cx[i] < f.cx[j] ? f.cx[i] : f.cx[j];
+        area[i][1] = f.cx[i] > f.cx[j] ? f.cx[i] : f.cx[j];
+        area[i][2] = f.cy[i] < f.cy[j] ? f.cy[i] : f.cy[j];
+        area[i][3] = f.cy[i] > f.cy[j] ? f.cy[i] : f.cy[j];
+    }
+    int cs = 0;
+    if (theta >= -AVP_PI && theta < -AVP_PI / 2) cs = 3;
+    else if (theta >= -AVP_PI / 2 && theta < 0) cs = 4;
+    else if (theta >= 0 && theta < AVP_PI / 2) cs = 1;
+    else if (theta >= AVP_PI / 2 && theta <= AVP_PI) cs = 2;
+    double x_min = expand, x_max = expand, y_min = expand, y_max = expand;
+    const double ac = fabs(avp_cos(theta)), as = fabs(avp_sin(theta));
+    if (cs) {
+        const int ixlo = avp_first_ge(m.X, m.nx, m.b0, m.dx, xlo), ixhi = avp_last_le(m.X, m.nx, m.b0, m.dx, xhi);
+        const int iylo = avp_first_ge(m.Y, m.ny, m.b2, m.dy, ylo), iyhi = avp_last_le(m.Y, m.ny, m.b2, m.dy, yhi);
+        if (iylo <= iyhi) {
+            for (int ix = ixlo; ix <= ixhi; ix++) {
+                const double ox = m.X[ix];
+                for (int w = iylo >> 6; w <= (iyhi >> 6); w++) {
+                    uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+                    if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
+                    if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
+                    while (bits) {
+                        const int bpos = __ffsll((unsigned long long)bits) - 1;
+                        bits &= bits - 1;
+                        const double oy = m.Y[(w << 6) + bpos];
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int quad = (kk + cs - 1) & 3;
+                            const bool xpos = quad == 0 || quad == 1, ypos = quad == 1 || quad == 2;
+                            const double ax0 = xpos ? area[kk][0] : area[kk][0] - expand, ax1 = xpos ? area[kk][1] + expand : area[kk][1];
+                            const double ay0 = ypos ? area[kk][2] : area[kk][2] - expand, ay1 = ypos ? area[kk][3] + expand : area[kk][3];
+                            if (ox > ax0 && ox < ax1 && oy > ay0 && oy < ay1) {
+                                const double sd = fabs(f.k[kk] * ox + f.b[kk] - oy) / f.den[kk];
+                                const double ver = sd / ac, hor = sd / as;
+                                if (xpos) { if (hor < x_max) x_max = hor; } else { if (hor < x_min) x_min = hor; }
+                                if (ypos) { if (ver < y_max) y_max = ver; } else { if (ver < y_min) y_min = ver; }
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    out[4 * q] = x_max + px; out[4 * q + 1] = y_max + py; out[4 * q + 2] = px - x_min; out[4 * q + 3] = py - y_min;
+}
+
 // ---- test hooks -------------------------------------------------------------------------------
 __global__ void trig_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ s, double* __restrict__ c)
 {

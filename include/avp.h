@@ -105,6 +105,15 @@ int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, const doubl
                         int64_t n, uint8_t* out, int32_t variant);
 
 /*
+ * Replaces: the per-way-point body of path_opti.compute_collision_H (optimization/path_optimazition.py:
+ * 221-409; the same scan is duplicated in optimization/ocp_optimization.py:36-480): corridor bounds used
+ * by the downstream QP / OCP stages. x, y, th: device, n way-points; expand_dis = config['expand_dis'].
+ * out: device n x 4 = {x_max + x, y_max + y, x - x_min, y - y_min}, i.e. the rows of H_max and H_min.
+ */
+int32_t avp_corridor_batch(avp_map* map, double expand_dis, const double* x, const double* y, const double* th,
+                           int64_t n, double* out);
+
+/*
  * Replaces: rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-134), one call per (start, goal)
  * pair in the reference. All pointers device. q0, q1: n x 3 (x, y, yaw) row-major; maxc = 1 /
  * min turning radius. Outputs per query i: status[i] (0 ok, 1 no candidate word, 2 the reference's

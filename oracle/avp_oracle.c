@@ -1304,6 +1304,69 @@ ORC_API int32_t orc_split_path(const orc_ctx *c, const double *fp, int32_t n, do
     return npts;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Corridor bounds: path_opti.compute_collision_H, optimization/path_optimazition.py:221-409.   */
+/* Per way-point: free distance (capped at expand_dis) to the nearest obstacle point in +x, +y,  */
+/* -x, -y, measured along the axes from the vehicle edge the point faces. The 4 heading cases x */
+/* 4 areas of the reference are one rotation pattern: area k (0 right, 1 front, 2 left, 3 rear)  */
+/* in heading case c looks towards quadrant (k + c - 1) mod 4 of [(x+,y-), (x+,y+), (x-,y+),     */
+/* (x-,y-)]. out[i] = {x_max + x, y_max + y, x - x_min, y - y_min} (H_max / H_min rows).          */
+ORC_API void orc_corridor_batch(const orc_ctx *c, double expand, const double *px_, const double *py_, const double *pt_,
+                                int64_t n, double *out)
+{
+    for (int64_t q = 0; q < n; q++) {
+        const double x = px_[q], y = py_[q], theta = pt_[q];
+        double vb[8];
+        orc_corners(c, x, y, theta, vb);
+        double xhi = vb[0], xlo = vb[0], yhi = vb[1], ylo = vb[1];
+        for (int i = 1; i < 4; i++) {
+            if (vb[2 * i] > xhi) xhi = vb[2 * i];
+            if (vb[2 * i] < xlo) xlo = vb[2 * i];
+            if (vb[2 * i + 1] > yhi) yhi = vb[2 * i + 1];
+            if (vb[2 * i + 1] < ylo) ylo = vb[2 * i + 1];
+        }
+        xhi = xhi + expand; xlo = xlo - expand; yhi = yhi + expand; ylo = ylo - expand;      /* :254-257 */
+        double k[4], b[4], area[4][4];
+        for (int i = 0; i < 4; i++) {
+            const int j = (i + 1) & 3;
+            k[i] = (vb[2 * j + 1] - vb[2 * i + 1]) / (vb[2 * j] - vb[2 * i]);
+            b[i] = vb[2 * i + 1] - k[i] * vb[2 * i];
+            area[i][0] = vb[2 * i] < vb[2 * j] ? vb[2 * i] : vb[2 * j];                      /* get_area_boundary :287-292 */
+            area[i][1] = vb[2 * i] > vb[2 * j] ? vb[2 * i] : vb[2 * j];
+            area[i][2] = vb[2 * i + 1] < vb[2 * j + 1] ? vb[2 * i + 1] : vb[2 * j + 1];
+            area[i][3] = vb[2 * i + 1] > vb[2 * j + 1] ? vb[2 * i + 1] : vb[2 * j + 1];
+        }
+        int cs = 0;                                                                          /* :341-348 */
+        if (theta >= -PI && theta < -PI / 2) cs = 3;
+        else if (theta >= -PI / 2 && theta < 0) cs = 4;
+        else if (theta >= 0 && theta < PI / 2) cs = 1;
+        else if (theta >= PI / 2 && theta <= PI) cs = 2;
+        double x_min = expand, x_max = expand, y_min = expand, y_max = expand;
+        const double ac = fabs(cos(theta)), as = fabs(sin(theta));
+        if (cs) {
+            for (int32_t o = 0; o < c->P; o++) {
+                const double ox = c->ox[o], oy = c->oy[o];
+                if (!(ox >= xlo && ox <= xhi)) continue;
+                if (!(oy >= ylo && oy <= yhi)) continue;
+                for (int kk = 0; kk < 4; kk++) {
+                    const int quad = (kk + cs - 1) & 3;
+                    const int xpos = quad == 0 || quad == 1, ypos = quad == 1 || quad == 2;
+                    const double ax0 = xpos ? area[kk][0] : area[kk][0] - expand, ax1 = xpos ? area[kk][1] + expand : area[kk][1];
+                    const double ay0 = ypos ? area[kk][2] : area[kk][2] - expand, ay1 = ypos ? area[kk][3] + expand : area[kk][3];
+                    if (ox > ax0 && ox < ax1 && oy > ay0 && oy < ay1) {
+                        const double sd = fabs(k[kk] * ox + b[kk] - oy) / sqrt(1 + k[kk] * k[kk]);   /* :294-296 */
+                        const double ver = sd / ac, hor = sd / as;                                    /* :299-303 */
+                        if (xpos) { if (hor < x_max) x_max = hor; } else { if (hor < x_min) x_min = hor; }
+                        if (ypos) { if (ver < y_max) y_max = ver; } else { if (ver < y_min) y_min = ver; }
+                        break;
+                    }
+                }
+            }
+        }
+        out[4 * q] = x_max + x; out[4 * q + 1] = y_max + y; out[4 * q + 2] = x - x_min; out[4 * q + 3] = y - y_min;
+    }
+}
+
 ORC_API int32_t orc_sizeof_ctx(void) { return (int32_t)sizeof(orc_ctx); }
 ORC_API int32_t orc_sizeof_plan_out(void) { return (int32_t)sizeof(orc_plan_out); }
 ORC_API double orc_py_hypot(double a, double b) { return py_hypot(a, b); }

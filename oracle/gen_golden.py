@@ -476,6 +476,40 @@ def gen_synth():
         save(f"g8_synth_c5_plan{i}.npz", r)
 
 
+def gen_corridor(cases=(1, 4, 5, 9, 13)):
+    """G9: corridor bounds compute_collision_H (optimization/path_optimazition.py:221-409) on the gear
+    segments of finished golden plans. cvxopt is only needed by the QP solve, not by this method: stub it."""
+    stub = types.ModuleType("cvxopt")
+    stub.matrix = lambda *a, **k: None
+    stub.solvers = types.SimpleNamespace(options={}, qp=None)
+    sys.modules.setdefault("cvxopt", stub)
+    from optimization import path_optimazition as ref_po
+    cfg = config()
+    veh = ref_costmap.Vehicle()
+    out = {"expand_dis": float(cfg["expand_dis"])}
+    for k in cases:
+        g = np.load(os.path.join(GOLD, f"g6_trace_case{k}.npz"))
+        m = load_map(os.path.join(CASES, f"Case{k}.csv"), cfg)
+        po = ref_po.path_opti(m, veh, cfg)
+        seg_len = g["split_len"]
+        pts = g["split_concat"]
+        # extra poses: exactly axis-aligned headings and all four heading quadrants on the same positions
+        extra = pts[: min(40, len(pts))].copy()
+        extra[:, 2] = np.resize([0.0, np.pi / 2, -np.pi / 2, np.pi, -np.pi, 2.5, -2.5, -0.7, 0.7, 1.9], len(extra))
+        allp = np.concatenate([pts, extra], 0)
+        po.original_path = [list(map(float, q)) for q in allp]
+        H, Hs = po.compute_collision_H()
+        n = len(allp)
+        H = np.asarray(H).reshape(-1)
+        out[f"c{k}_poses"] = allp
+        out[f"c{k}_Hmax"] = H[: 2 * n].reshape(n, 2)
+        out[f"c{k}_Hmin"] = -H[2 * n:].reshape(n, 2)
+        out[f"c{k}_slack_shape"] = np.array(np.asarray(Hs).shape)
+        out[f"c{k}_slack"] = np.asarray(Hs).reshape(-1)
+        print("G9 case", k, n, "points", flush=True)
+    save("g9_corridor.npz", out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     if what == "micro":
@@ -488,3 +522,5 @@ if __name__ == "__main__":
         gen_random(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif what == "synth":
         gen_synth()
+    elif what == "corridor":
+        gen_corridor()

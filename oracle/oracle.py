@@ -165,6 +165,13 @@ class Oracle:
         self.L.orc_check_batch(self.ref, C.c_int32(kind), _p(x), _p(y), _p(th), C.c_int64(len(x)), _p(out), _p(near))
         return (out, near) if want_near else out
 
+    def corridor_batch(self, poses, expand):
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        x, y, th = [np.ascontiguousarray(poses[:, i]) for i in range(3)]
+        out = np.zeros((len(x), 4))
+        self.L.orc_corridor_batch(self.ref, C.c_double(expand), _p(x), _p(y), _p(th), C.c_int64(len(x)), _p(out))
+        return out
+
     # -- Reeds-Shepp -------------------------------------------------------------------------
     def rs_candidates(self, q0, q1, maxc=None):
         q0 = np.ascontiguousarray(q0, dtype=np.float64)

@@ -1,0 +1,40 @@
+"""HIP corridor-bound kernel (path_opti.compute_collision_H) vs the reference's golden matrices and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import gold, case_map_from_gold
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [1, 4, 5, 9, 13])
+def test_corridor_golden_and_class_api(k, vehicle, cfg):
+    from automatedvaletparking_amd import path_optimization
+    g = gold("g9_corridor.npz")
+    m = case_map_from_gold(k)
+    po = path_optimization.path_opti(m, vehicle, cfg)
+    poses = g[f"c{k}_poses"]
+    po.original_path = [list(map(float, q)) for q in poses]
+    H, Hs = po.compute_collision_H()
+    n = len(poses)
+    assert H.shape == (4 * n, 1) and tuple(Hs.shape) == tuple(g[f"c{k}_slack_shape"])
+    assert np.array_equal(H[:2 * n, 0].reshape(n, 2), g[f"c{k}_Hmax"], equal_nan=True)
+    assert np.array_equal(-H[2 * n:, 0].reshape(n, 2), g[f"c{k}_Hmin"], equal_nan=True)
+    assert np.array_equal(Hs.reshape(-1), g[f"c{k}_slack"], equal_nan=True)
+
+
+def test_corridor_random_vs_oracle(vehicle, cfg):
+    from automatedvaletparking_amd import _native
+    from oracle import oracle
+    for k in (1, 19):
+        m = case_map_from_gold(k)
+        dm = _native.DeviceMap(m, vehicle, cfg)
+        o = oracle.Oracle(m, vehicle, cfg)
+        rng = np.random.default_rng(k)
+        b = m.boundary
+        n = 50_000 if k == 1 else 10_000
+        poses = np.stack([rng.uniform(b[0] + 1, b[1] - 1, n), rng.uniform(b[2] + 1, b[3] - 1, n), rng.uniform(-np.pi, np.pi, n)], 1)
+        poses[:500, 2] = rng.choice([0.0, np.pi / 2, -np.pi / 2, np.pi, -np.pi], 500)
+        poses[500:520, 2] = 4.0            # outside [-pi, pi]: no heading case applies, bounds stay at expand_dis
+        for e in (0.8, 0.3):
+            assert np.array_equal(dm.corridor_batch(poses, e), o.corridor_batch(poses, e), equal_nan=True)

@@ -145,3 +145,13 @@ def test_recorded_checks_case1(vehicle, cfg):
     o = _oracle(case_map_from_gold(1), vehicle, cfg)
     c = g["checks"]
     assert np.array_equal(o.check_batch(c[:, :3], kind=0), c[:, 3].astype(np.uint8))
+
+
+@pytest.mark.parametrize("k", [1, 4, 5, 9, 13])
+def test_corridor_bounds(k, vehicle, cfg):
+    """compute_collision_H (optimization/path_optimazition.py:221-409) on golden gear segments + axis-aligned headings."""
+    g = gold("g9_corridor.npz")
+    o = _oracle(case_map_from_gold(k), vehicle, cfg)
+    r = o.corridor_batch(g[f"c{k}_poses"], float(g["expand_dis"]))
+    assert np.array_equal(r[:, :2], g[f"c{k}_Hmax"], equal_nan=True)
+    assert np.array_equal(r[:, 2:], g[f"c{k}_Hmin"], equal_nan=True)
