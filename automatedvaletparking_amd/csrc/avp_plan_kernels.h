@@ -28,7 +28,7 @@
 #define PL_QCAP 32768                 // entries per rotating bucket queue
 #define PL_NQ 4                       // rotating bucket queues
 #define PL_MAXCHILD 32
-#define PL_RSQ 11                     // RS queries evaluated per pass (46 words each): the shot + 10 children
+#define PL_RSQ 11                     // RS queries evaluated per pass (46 words each): the shot + 10 children (<= 16)
 #define PL_CHK_MAX 1280               // poses per collision pass (shot samples + sub-steps)
 #define PL_RS_CAP 1024                // samples of one RS shot
 #define PL_UNSEEN 0x7fffffffu
@@ -230,6 +230,8 @@ struct PlShared {
     PlChild child[PL_MAXCHILD];
     // RS word results: [query][word] ok + 5 lengths; kept candidates per query
     RsFrame frame[PL_RSQ];
+    int32_t sched_cnt, sched_n;       // lane schedule of the (word, query) items for sched_cnt queries
+    uint16_t sched[4 * PL_THREADS];   // [round][wave][lane] -> word << 4 | query, 0xffff = idle lane
     uint8_t w_ok[PL_RSQ * 46];        // word valid
     uint8_t w_acc[PL_RSQ * 46];       // word accepted by set_path
     uint8_t w_err[PL_RSQ];            // assertion L >= 0.01 failed for an accepted word
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(PL_THREADS) void hfield_kernel(DevMap m, double gx,
     PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace, dims);
-    if (threadIdx.x == 0) { s.status = 0; for (int k = 0; k < 10; k++) s.phase[k] = 0; }
+    if (threadIdx.x == 0) { s.status = 0; s.sched_cnt = -1; s.sched_n = 0; for (int k = 0; k < 10; k++) s.phase[k] = 0; }
     __syncthreads();
     pl_sweep_init(m, w, s, dims, gx, gy);
     for (int i = 0; i < nq && s.status == 0; i++) {
@@ -544,6 +546,45 @@ AVP_D double pl_node_cost(const avp_params& p, int node_forward, double node_the
 
 // Evaluate RS words for queries [0, nq): query 0 = current node (the shot), 1.. = children.
 // One thread per (query, word); then one thread per query folds the 46 results in source order.
+// Lane schedule for the (word, query) items of one RS pass. A wave pays the full instruction stream of
+// every word solver any of its lanes runs, so the items are grouped into chunks of <= 64 lanes of ONE solver
+// and the chunks are spread over the waves (longest-processing-time first, measured solver costs), each
+// chunk in its own round of its wave: sched[round][wave][lane].
+AVP_D void pl_rs_build_schedule(PlShared& s, int nq)
+{
+    // solvers by descending cost (k-cycles per call measured on MI355X): SLS (two nearly-CR tan), LRL (asin),
+    // LRSL, LRSLR, LRLRn, LRLRp, LSR, LRSR, LSL
+    const int8_t words[9][8] = { { 0, 1, -1, -1, -1, -1, -1, -1 }, { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 },
+                                 { 42, 43, 44, 45, -1, -1, -1, -1 }, { 18, 19, 20, 21, -1, -1, -1, -1 }, { 22, 23, 24, 25, -1, -1, -1, -1 },
+                                 { 6, 7, 8, 9, -1, -1, -1, -1 }, { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 } };
+    const int cost[9] = { 100, 70, 70, 60, 55, 55, 50, 50, 40 };
+    const int nwave = PL_THREADS / 64;
+    int load[PL_THREADS / 64], rounds[PL_THREADS / 64];
+    for (int w = 0; w < nwave; w++) { load[w] = 0; rounds[w] = 0; }
+    for (int i = 0; i < 4 * PL_THREADS; i++) s.sched[i] = 0xffff;
+    int maxround = 0;
+    for (int sv = 0; sv < 9; sv++) {
+        int nw = 0;
+        while (nw < 8 && words[sv][nw] >= 0) nw++;
+        const int items = nw * nq;
+        for (int base = 0; base < items; base += 64) {
+            const int cnt = items - base < 64 ? items - base : 64;
+            int best = 0;
+            for (int w = 1; w < nwave; w++) if (load[w] < load[best]) best = w;
+            const int r = rounds[best]++;
+            load[best] += cost[sv];
+            if (r >= 4) continue;                         // cannot happen for nq <= 16
+            if (r + 1 > maxround) maxround = r + 1;
+            for (int k = 0; k < cnt; k++) {
+                const int it = base + k;
+                s.sched[r * PL_THREADS + best * 64 + k] = (uint16_t)((words[sv][it / nq] << 4) | (it % nq));
+            }
+        }
+    }
+    s.sched_n = maxround * PL_THREADS;
+    s.sched_cnt = nq;
+}
+
 template <typename PoseFn>
 AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
 {
@@ -553,11 +594,12 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
         pose((int)threadIdx.x, x, y, th);
         s.frame[threadIdx.x] = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
     }
+    if (threadIdx.x == PL_THREADS - 1 && s.sched_cnt != nq) pl_rs_build_schedule(s, nq);
     __syncthreads();
-    // word-major mapping: consecutive lanes evaluate the SAME word for different queries, so a wave
-    // runs one or two of the nine word solvers instead of all of them
-    for (int t = threadIdx.x; t < nq * 46; t += PL_THREADS) {
-        const int wd = t / nq, q = t - wd * nq;
+    for (int t = threadIdx.x; t < s.sched_n; t += PL_THREADS) {
+        const uint16_t it = s.sched[t];
+        if (it == 0xffff) continue;
+        const int wd = it >> 4, q = it & 15;
         double l[5];
         const int slot = q * 46 + wd;
         s.w_ok[slot] = rs_word(wd, s.frame[q], l) ? 1 : 0;
@@ -565,6 +607,7 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
     }
     __syncthreads();
 }
+
 // set_path (rs_curve.py:137-156) for all queries at once: one thread per (query, type group); a
 // candidate is only ever compared with kept candidates of the same type sequence, so the groups are
 // independent and the within-group order is the source order.
@@ -575,29 +618,27 @@ AVP_D void pl_rs_accept(PlShared& s, const avp_params& p, int nq)
     __syncthreads();
     for (int t = threadIdx.x; t < nq * 20; t += PL_THREADS) {
         const int g = t / nq, q = t - g * nq;
-        double kept[4][5];
-        int nk = 0;
+        unsigned accmask = 0;                     // accepted words of this group so far (bit j = RS_GROUPS[g][j])
         for (int j = 0; j < 4; j++) {
             const int wd = RS_GROUPS[g][j];
             if (wd < 0) break;
             const int slot = q * 46 + wd;
             if (!s.w_ok[slot]) continue;
             const int n = RS_WORDS[wd].n;
-            double l[5];
-            for (int i = 0; i < 5; i++) l[i] = s.w_l[slot][i];
             bool dup = false;
-            for (int e = 0; e < nk && !dup; e++) {
+            for (int e = 0; e < j && !dup; e++) {
+                if (!(accmask & (1u << e))) continue;
+                const int eslot = q * 46 + RS_GROUPS[g][e];
                 double sum = 0;
-                for (int i = 0; i < n; i++) sum = sum + (kept[e][i] - l[i]);
+                for (int i = 0; i < n; i++) sum = sum + (s.w_l[eslot][i] - s.w_l[slot][i]);
                 if (sum <= 0.01) dup = true;
             }
             if (dup) continue;
             double L = 0;
-            for (int i = 0; i < n; i++) L = L + fabs(l[i]);
+            for (int i = 0; i < n; i++) L = L + fabs(s.w_l[slot][i]);
             if (L >= 1000.0) continue;
             if (!(L >= 0.01)) { s.w_err[q] = 1; continue; }
-            for (int i = 0; i < 5; i++) kept[nk][i] = l[i];
-            nk++;
+            accmask |= 1u << j;
             s.w_acc[slot] = 1; s.w_Ln[slot] = L; s.w_Lm[slot] = L / p.maxc;
         }
     }
@@ -775,6 +816,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
     const int tid = threadIdx.x;
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; }
     // STAGE: the column bitmaps and node coordinates of the map live in LDS behind PlShared for the whole
     // (persistent) lifetime of the workgroup; otherwise they are read through L1/L2
     MapTabs mt;
