@@ -22,6 +22,7 @@
 // See DESIGN.md for the equivalence argument and the measured agreement with the heapq-exact oracle.
 #pragma once
 #include "avp_device.h"
+#include "avp_check_kernels.h"   // wave_sync
 #include "avp_rs_kernels.h"
 
 #define PL_THREADS 512

@@ -137,6 +137,7 @@ def main():
                        "batch_per_gpu": BATCH, "pop_cap": POP_CAP, "obstacle_points": dm.P, "parallelism": f"shard{world}"},
             "expansions_per_s": pops_total * a.steps / elapsed,
             "solved_frac": float((rec["status"] == 0).mean()), "iter_limit_frac": float((rec["status"] == 4).mean()),
+            "solved_plans_per_s": value * float((rec["status"] == 0).mean()),
             "roofline": {"kernel": "plan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launch_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg},

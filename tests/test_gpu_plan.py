@@ -189,3 +189,30 @@ def test_config_variants_vs_oracle(over, vehicle, cfg):
     with oracle.portable_libm():
         for i, r in enumerate(res):
             _assert_same_as_oracle(r, o.plan(starts[i], goals[i], max_trace=cap))
+
+
+def test_large_map_tables_not_in_lds(vehicle, cfg, tmp_path):
+    """A 1200 x 1200 map: column bitmaps + node tables (190 KB) exceed the 160 KB LDS, so the planner and the
+    collision kernel run their L2-backed variants (plan_kernel<false>, check_distance_kernel<false>)."""
+    from automatedvaletparking_amd import costmap, sampling, _native, path_planner
+    from oracle import oracle
+    polys = sampling.synthetic_polygon_map(seed=11, size=100.0, n_obs=70)
+    polys = [p + 8.0 for p in polys]
+    csv = tmp_path / "big.csv"
+    sampling.write_tpcap_csv(str(csv), (10.0, 10.0, 0.0), (106.0, 106.0, 0.0), polys)
+    m = costmap.Map(file=str(csv), discrete_size=cfg["map_discrete_size"])
+    assert m.cost_map.shape == (1200, 1200)
+    cap = 120
+    o = oracle.Oracle(m, vehicle, cfg, max_pops=cap)
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
+    rng = np.random.default_rng(3)
+    poses = np.stack([rng.uniform(20, 100, 4000), rng.uniform(20, 100, 4000), rng.uniform(-np.pi, np.pi, 4000)], 1)
+    hit = dm.check_batch(poses)
+    assert np.array_equal(hit, o.check_batch(poses))
+    free = poses[hit == 0]
+    starts = free[0:12:2]
+    goals = starts + np.stack([rng.uniform(-9, 9, 6), rng.uniform(-9, 9, 6), rng.uniform(-1, 1, 6)], 1)
+    res = path_planner.BatchPlanner(dm, max_nodes=4096, n_slots=3).plan(starts, goals, max_trace=cap)
+    with oracle.portable_libm():
+        for i, r in enumerate(res):
+            _assert_same_as_oracle(r, o.plan(starts[i], goals[i], max_trace=cap))
