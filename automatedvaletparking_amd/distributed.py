@@ -115,6 +115,24 @@ def gather_records(local_idx: np.ndarray, local_rec: np.ndarray, n_total: int, d
     return out
 
 
+def all_gather_rows(local, out=None):
+    """All-gather equally shaped row blocks (any dtype) from every rank: returns (world, *local.shape).
+    nccl/RCCL: one all_gather_into_tensor; gloo (CPU tests): list form. `out` may be a preallocated buffer."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.unsqueeze(0)
+    world = dist.get_world_size()
+    local = local.contiguous()
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, local)
+    else:
+        dist.all_gather(list(out.unbind(0)), local)
+    return out
+
+
 def plan_sharded(plan_fn: Callable[[np.ndarray, np.ndarray], np.ndarray], starts, goals, dst: int = 0, device=None):
     """Run `plan_fn(starts_shard, goals_shard) -> (k, stride) float64 records` on this rank's shard
     and gather to rank dst. The result is identical for every world size (shard invariance)."""

@@ -88,7 +88,7 @@ def main():
         if i is not None:
             ev[i][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, res[:BATCH].contiguous())   # final gather of the solved records
+            avd.all_gather_rows(res[:BATCH], out=gathered)   # final gather of the solved records (RCCL all-gather)
         return res, paths
 
     for _ in range(a.warmup):

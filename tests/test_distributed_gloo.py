@@ -50,6 +50,11 @@ def _worker(rank, world, port, q):
         return out
 
     rec = avd.plan_sharded(plan_fn, starts, goals, dst=0, device="cpu")
+    # the bench's per-step collective: equally shaped uint8 record blocks from every rank
+    import torch
+    blk = torch.full((5, 7), rank + 1, dtype=torch.uint8)
+    allb = avd.all_gather_rows(blk)
+    assert allb.shape == (world, 5, 7) and all(int(allb[r].min()) == r + 1 == int(allb[r].max()) for r in range(world))
     if rank == 0:
         q.put((rec, avd.pack_map_blob(m)))
     dist.barrier()
