@@ -59,7 +59,7 @@ def broadcast_map(m: Optional[Map], src: int = 0, device=None) -> Map:
     """Rank `src` passes its Map; every rank returns an identical Map (one size + one payload broadcast)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return m
     rank = dist.get_rank()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -120,7 +120,7 @@ def all_gather_rows(local, out=None):
     nccl/RCCL: one all_gather_into_tensor; gloo (CPU tests): list form. `out` may be a preallocated buffer."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local.unsqueeze(0)
     world = dist.get_world_size()
     local = local.contiguous()

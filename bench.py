@@ -46,8 +46,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("AVP_BENCH_FORCE_DIST") == "1"     # the env var exercises RCCL with world 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
@@ -77,7 +79,7 @@ def main():
     st_t, go_t = dm.dev_tensor(starts), dm.dev_tensor(goals)
 
     rec_stride = path_planner.RESULT_DTYPE.itemsize
-    gathered = torch.empty((world, BATCH, rec_stride), dtype=torch.uint8, device=f"cuda:{local}") if world > 1 else None
+    gathered = torch.empty((world, BATCH, rec_stride), dtype=torch.uint8, device=f"cuda:{local}") if use_dist else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
@@ -87,32 +89,32 @@ def main():
         res, paths, _ = bp.plan_dev(st_t, go_t, want_paths=True)
         if i is not None:
             ev[i][1].record()
-        if world > 1:
+        if use_dist:
             avd.all_gather_rows(res[:BATCH], out=gathered)   # final gather of the solved records (RCCL all-gather)
         return res, paths
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         res, paths = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     rec = res.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:BATCH]
     pops_local = int(rec["n_pops"].sum())
-    if world > 1:
+    if use_dist:
         pt = torch.tensor([pops_local], dtype=torch.int64, device=f"cuda:{local}")
         dist.all_reduce(pt)
         pops_total = int(pt.item())
@@ -183,7 +185,7 @@ def main():
         except Exception:
             pass
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
