@@ -39,3 +39,20 @@ class path_opti:
         H_collision = np.vstack((H_max, -H_min))
         slack_H_collision = np.vstack((H_max, 999 * np.ones((n - 2, 1)), -H_min, np.zeros((n - 2, 1))))
         return H_collision, slack_H_collision
+
+
+class ocp_optimization:
+    """The corridor scan of the reference's OCP stage (`optimization/ocp_optimization.py:36-480`): the same
+    per-way-point computation as `path_opti.compute_collision_H` (verified identical on the golden poses),
+    returned as four lists. The Pyomo/IPOPT model itself is outside this package."""
+
+    def __init__(self, park_map: Map, vehicle: Vehicle, config: dict) -> None:
+        self.config = config
+        self.map = park_map
+        self.vehicle = vehicle
+        self.expand_dis = config['expand_dis']
+
+    def compute_collision_H(self, path):
+        poses = np.array([[p[0], p[1], p[2]] for p in path], dtype=np.float64).reshape(-1, 3)
+        b = _native.device_map(self.map, self.vehicle, self.config).corridor_batch(poses, self.expand_dis)
+        return ([float(v) for v in b[:, 0]], [float(v) for v in b[:, 1]], [float(v) for v in b[:, 2]], [float(v) for v in b[:, 3]])

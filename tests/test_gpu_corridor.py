@@ -38,3 +38,15 @@ def test_corridor_random_vs_oracle(vehicle, cfg):
         poses[500:520, 2] = 4.0            # outside [-pi, pi]: no heading case applies, bounds stay at expand_dis
         for e in (0.8, 0.3):
             assert np.array_equal(dm.corridor_batch(poses, e), o.corridor_batch(poses, e), equal_nan=True)
+
+
+def test_ocp_copy_of_the_scan(vehicle, cfg):
+    """optimization/ocp_optimization.py:36-480 returns the same numbers as four lists (checked against the
+    reference with pyomo stubbed when the fixture was made)."""
+    from automatedvaletparking_amd import path_optimization
+    g = gold("g9_corridor.npz")
+    oc = path_optimization.ocp_optimization(case_map_from_gold(13), vehicle, cfg)
+    X_max, Y_max, X_min, Y_min = oc.compute_collision_H([list(map(float, q)) for q in g["c13_poses"]])
+    assert isinstance(X_max, list) and isinstance(X_max[0], float)
+    assert np.array_equal(np.array(X_max), g["c13_Hmax"][:, 0], equal_nan=True) and np.array_equal(np.array(Y_max), g["c13_Hmax"][:, 1], equal_nan=True)
+    assert np.array_equal(np.array(X_min), g["c13_Hmin"][:, 0], equal_nan=True) and np.array_equal(np.array(Y_min), g["c13_Hmin"][:, 1], equal_nan=True)
