@@ -174,6 +174,15 @@ def main():
             out["cpu_baseline"] = {"value": BATCH / tc, "unit": "plans/s", "cores": 1, "kind": "port",
                                    "sample": f"the same {BATCH} problems, pop cap {POP_CAP}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s",
                                    "expansions_per_s": pops_cpu / tc}
+            # the same port on every host core: one problem per thread (ctypes releases the GIL; the C code has no shared state)
+            from concurrent.futures import ThreadPoolExecutor
+            ncore = os.cpu_count() or 1
+            t2 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=ncore) as ex:
+                list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=1)["n_pops"], zip(starts, goals)))
+            tm = time.perf_counter() - t2
+            out["cpu_baseline_all_cores"] = {"value": BATCH / tm, "unit": "plans/s", "cores": ncore, "kind": "port",
+                                             "sample": f"the same {BATCH} problems, one per thread, {tm:.1f} s"}
         # HBM traffic per launch from the committed PMC passes of this same command (profiles/README.md)
         try:
             import glob
