@@ -146,7 +146,7 @@ def test_reference_api_no_path_case20(vehicle, cfg):
         pl.a_star_plan()
 
 
-@pytest.mark.parametrize("k", [2, 5, 9, 13, 19])
+@pytest.mark.parametrize("k", list(range(2, 21)))
 def test_random_pairs_other_maps_vs_oracle(k, vehicle, cfg):
     """Slices of BASELINE config 3 (all maps x random pairs): other grid sizes, both id-stride variants
     (S = nx-1 and nx-2, i.e. with and without aliased ids), coordinates up to 4.5e9 (Case13)."""
@@ -156,7 +156,7 @@ def test_random_pairs_other_maps_vs_oracle(k, vehicle, cfg):
     cap = 300
     o = oracle.Oracle(m, vehicle, cfg, max_pops=cap)
     rng = np.random.default_rng(20260927 + k)
-    poses = sampling.sample_free_poses(m.boundary, m.case.obs, 32, rng, margin=6.0,
+    poses = sampling.sample_free_poses(m.boundary, m.case.obs, 32 if k in (2, 5, 9, 13, 19) else 12, rng, margin=6.0,
                                        check=lambda x, y, t: bool(o.check_batch(np.array([[x, y, t]]))[0]))
     starts, goals = poses[0::2], poses[1::2]
     dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
