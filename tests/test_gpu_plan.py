@@ -15,7 +15,7 @@ from conftest import CASES, GOLD, gold, case_map_from_gold
 
 pytestmark = pytest.mark.gpu
 GOLDENS = sorted(glob.glob(os.path.join(GOLD, "g6_trace_case*.npz")) + glob.glob(os.path.join(GOLD, "g7_random_case*.npz"))
-                 + glob.glob(os.path.join(GOLD, "g8_synth_c4_plan*.npz")))
+                 + glob.glob(os.path.join(GOLD, "g8_synth_c*_plan*.npz")))
 
 
 def _gold_problem(g):
@@ -76,6 +76,11 @@ def test_golden_problems(path, vehicle, cfg):
         assert res.final_path.shape == g["final_path"].shape and np.abs(res.final_path - g["final_path"]).max() < 1e-6
     if str(g["status"]) == "AttributeError":
         assert res.status == 1 and not res.rs_types and res.n_pops == len(g["pops"])
+    if str(g["status"]) == "timeout" and len(g["pops"]) and os.path.basename(path) not in KNOWN_TIE_DIVERGENCE:
+        # unfinished reference run: its first N pops still pin the popped grid ids
+        n = min(len(g["pops"]), res.n_pops)
+        assert n == len(g["pops"]) or res.status == 0
+        assert np.array_equal(res.trace[:n, 2], g["pops"][:n, 2])
 
 
 def test_batch_256_case1_vs_oracle(vehicle, cfg):
