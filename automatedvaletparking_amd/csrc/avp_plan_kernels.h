@@ -587,16 +587,18 @@ AVP_D void pl_rs_build_schedule(PlShared& s, int nq)
 }
 
 template <typename PoseFn>
-AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose)
+AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose, bool frames_ready)
 {
-    // start-frame normalisation once per query
-    if ((int)threadIdx.x < nq) {
-        double x, y, th;
-        pose((int)threadIdx.x, x, y, th);
-        s.frame[threadIdx.x] = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+    // start-frame normalisation once per query (already done by the caller when frames_ready)
+    if (!frames_ready) {
+        if ((int)threadIdx.x < nq) {
+            double x, y, th;
+            pose((int)threadIdx.x, x, y, th);
+            s.frame[threadIdx.x] = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+        }
+        if (threadIdx.x == PL_THREADS - 1 && s.sched_cnt != nq) pl_rs_build_schedule(s, nq);
+        __syncthreads();
     }
-    if (threadIdx.x == PL_THREADS - 1 && s.sched_cnt != nq) pl_rs_build_schedule(s, nq);
-    __syncthreads();
     for (int t = threadIdx.x; t < s.sched_n; t += PL_THREADS) {
         const uint16_t it = s.sched[t];
         if (it == 0xffff) continue;
@@ -714,8 +716,10 @@ AVP_D void pl_rs_sample_replay(PlShared& s, const avp_params& p)
     }
     s.smp_hi = hi;
 }
-AVP_D void pl_rs_sample_local(const PlanWs& w, const PlShared& s, const avp_params& p)
+AVP_D void pl_rs_sample_local(const PlanWs& w, PlShared& s, const avp_params& p)
 {
+    // s.rs_npts must be 0 on entry; it ends as 1 + the last index whose local px is not 0.0, i.e. the list
+    // length after the reference's "while px[-1] == 0.0: pop()" (rs_curve.py:588-592)
     const int point_num = s.smp_point_num, hi = s.smp_hi;
     for (int i = threadIdx.x; i < point_num; i += PL_THREADS) {
         double px = 0.0, py = 0.0, pyaw = 0.0;
@@ -728,13 +732,8 @@ AVP_D void pl_rs_sample_local(const PlanWs& w, const PlShared& s, const avp_para
             dr = l > 0.0 ? 1 : -1;
         }
         w.rsbuf[3 * i] = px; w.rsbuf[3 * i + 1] = py; w.rsbuf[3 * i + 2] = pyaw; w.rsdir[i] = dr;
+        if (px != 0.0) atomicMax(&s.rs_npts, i + 1);
     }
-}
-AVP_D void pl_rs_sample_trim(const PlanWs& w, PlShared& s)
-{
-    int np = s.smp_point_num;
-    while (np > 0 && w.rsbuf[3 * (np - 1)] == 0.0) np--;
-    s.rs_npts = np;
 }
 
 // ---- wave-local cooperative collision pass (distance_checker semantics, collision_check.py:144-240) ----
@@ -903,6 +902,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
             // ---- children poses (expand_node :134-151) + try_reach_goal radius test (:308-312) ----------
             const long long t_d = clock64();
+            const bool one_pass = nchild + 1 <= PL_RSQ;          // shot + all children fit one RS pass
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
             const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
             const bool in_radius = distance < p.flag_radius;
@@ -923,7 +923,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 c.first_coll = 0x7fffffff;
                 c.rs_err = 0;
                 c.L = 0;
-            }
+                if (one_pass) s.frame[tid + 1] = rs_frame(c.x, c.y, c.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            } else if (one_pass && tid == 64) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1);
             __syncthreads();
             const long long t_e = clock64();
             if (tid == 0) s.phase[PH_CHILD] += t_e - t_d;
@@ -937,7 +939,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         const int g = base + q;
                         if (g == 0) { x = cn.x; y = cn.y; th = cn.th; }
                         else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
-                    });
+                    }, one_pass);
                     pl_rs_accept(s, p, cnt);
                     for (int q = tid >> 6; q < cnt; q += PL_THREADS / 64) {
                         const int g = base + q;
@@ -990,8 +992,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (tid == 0) s.phase[PH_SHOT_SAMPLE] += t_g - t_f0;
             if (in_radius) {
                 pl_rs_sample_local(w, s, p);
-                __syncthreads();
-                if (tid == 0) pl_rs_sample_trim(w, s);
                 __syncthreads();
                 // world transform (:125-131) fused with the collision pass over the samples (:335-345)
                 const int np = s.rs_npts;
