@@ -22,7 +22,7 @@ EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
     "avp_check_batch", "avp_corridor_batch", "avp_trig_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
     "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch",
-    "avp_hfield_id_capacity", "avp_hfield_queries",
+    "avp_hfield_id_capacity", "avp_hfield_queries", "avp_rasterize_edges",
 ]
 
 
@@ -122,6 +122,33 @@ def last_error() -> str:
 def chk(status: int, what: str = ""):
     if status != 0:
         raise RuntimeError(f"{what or 'libavp_hip'}: status {status}: {last_error()}")
+
+
+def rasterize_edges(xs: np.ndarray, ys: np.ndarray, edges: np.ndarray, device=None, stream=None):
+    """Device rasteriser (include/avp.h: avp_rasterize_edges): returns the uint8 occupancy [nx, ny] as a
+    CUDA tensor and the number of samples that matched more than one node. No CPU fallback."""
+    torch = torch_cuda()
+    dev = torch.device(device if device is not None else "cuda")
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    edges = np.ascontiguousarray(edges, dtype=np.float64).reshape(-1, 6)
+    nx, ny = len(xs), len(ys)
+    d_xs, d_ys = torch.as_tensor(xs, device=dev), torch.as_tensor(ys, device=dev)
+    occ = torch.zeros((nx, ny), dtype=torch.uint8, device=dev)
+    multi = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = stream if stream is not None else torch.cuda.current_stream(dev)
+    # the C-ABI takes at most 65535 edges per call (grid.y)
+    for lo in range(0, len(edges), 65535):
+        part = edges[lo:lo + 65535]
+        d_e = torch.as_tensor(part, device=dev)
+        chk(lib().avp_rasterize_edges(C.c_int32(dev.index if dev.index is not None else torch.cuda.current_device()),
+                                      C.c_void_p(st.cuda_stream), C.c_void_p(d_xs.data_ptr()), C.c_void_p(d_ys.data_ptr()),
+                                      C.c_int32(nx), C.c_int32(ny), C.c_double(float(xs[0])), C.c_double(float(xs[1] - xs[0])),
+                                      C.c_double(float(ys[0])), C.c_double(float(ys[1] - ys[0])),
+                                      C.c_void_p(d_e.data_ptr()), C.c_int64(len(part)), C.c_int32(int(part[:, 5].max()) if len(part) else 0),
+                                      C.c_void_p(occ.data_ptr()), C.c_void_p(multi.data_ptr())), "avp_rasterize_edges")
+        st.synchronize()        # d_e must outlive the launch
+    return occ, int(multi.item())
 
 
 def torch_cuda():

@@ -102,7 +102,10 @@ class Case:
 class Map:
     """Obstacle-edge costmap over floor(bounds) with pitch = linspace step."""
 
-    def __init__(self, discrete_size: float = 0.1, file: Optional[str] = None, case: Optional[Case] = None):
+    def __init__(self, discrete_size: float = 0.1, file: Optional[str] = None, case: Optional[Case] = None,
+                 device=None):
+        """device=None: host rasteriser (numpy, the reference's own arithmetic); device="cuda[:k]": the
+        per-sample stage runs in libavp_hip.so (avp_rasterize_edges), bit-identical cells, no CPU fallback."""
         self.discrete_size = discrete_size
         self.grid_index = None
         self.cost_map = np.array([], dtype=np.float64)
@@ -113,7 +116,10 @@ class Map:
         self._discrete_x = 0
         self._discrete_y = 0
         self._packed = None
-        self.detect_obstacle_edge()
+        if device is None:
+            self.detect_obstacle_edge()
+        else:
+            self.detect_obstacle_edge_device(device)
 
     # -- grid -------------------------------------------------------------------------------
     def discrete_map(self):
@@ -138,9 +144,28 @@ class Map:
         return int(hit[0])
 
     def detect_obstacle_edge(self):
+        """Host rasteriser: edge table, then per edge the samples of map/costmap.py:236-261 in numpy."""
         self.discrete_map()
         xs, ys = self.map_position
         dx, dy = self._discrete_x, self._discrete_y
+        for p1x, p1y, ca, sa, length, count in self.edge_table():
+            count = int(count)
+            rot = np.array([[ca, sa], [-sa, ca]])
+            along = np.vstack((np.linspace(0, length, count), np.zeros(count)))
+            pts = np.dot(rot.transpose(), along)
+            for q in range(count):
+                i = self._node_below(xs, pts[0][q] + p1x, dx)
+                jj = self._node_below(ys, pts[1][q] + p1y, dy)
+                if i >= 0 and jj >= 0:
+                    self.cost_map[i][jj] = 255
+        self._packed = None
+
+    def edge_table(self) -> np.ndarray:
+        """Host half of detect_obstacle_edge (map/costmap.py:203-236): np.unique, centroid-angle sort and, per
+        polygon edge, [p1x, p1y, cos, sin, rotated length, count = floor(length / dx)] -> float64 [E, 6].
+        Requires discrete_map() to have run."""
+        dx = self._discrete_x
+        rows = []
         for k in range(self.case.obs_num):
             poly = np.unique(self.case.obs[k], axis=0)
             nv = len(poly[:, 0])
@@ -154,16 +179,18 @@ class Map:
                 a = np.arctan2(edge[1], edge[0])
                 rot = np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]])
                 length = np.dot(rot, np.array(edge).reshape([2, 1]))[0].tolist()[0]
-                count = math.floor(length / dx)
-                along = np.vstack((np.linspace(0, length, count), np.zeros(count)))
-                pts = np.dot(rot.transpose(), along)
-                for q in range(count):
-                    px = pts[0][q] + p1[0]
-                    py = pts[1][q] + p1[1]
-                    i = self._node_below(xs, px, dx)
-                    jj = self._node_below(ys, py, dy)
-                    if i >= 0 and jj >= 0:
-                        self.cost_map[i][jj] = 255
+                rows.append([p1[0], p1[1], rot[0, 0], rot[0, 1], length, float(math.floor(length / dx))])
+        return np.array(rows, dtype=np.float64).reshape(-1, 6)
+
+    def detect_obstacle_edge_device(self, device="cuda"):
+        """detect_obstacle_edge with the per-sample stage (map/costmap.py:236-261) on the GPU."""
+        from . import _native
+        self.discrete_map()
+        xs, ys = self.map_position
+        occ, multi = _native.rasterize_edges(xs, ys, self.edge_table(), device=device)
+        if multi:
+            raise TypeError("only length-1 arrays can be converted to Python scalars")      # map/costmap.py:260
+        self.cost_map = occ.cpu().numpy().astype(np.float64)
         self._packed = None
 
     def convert_position_to_index(self, grid_x, grid_y):

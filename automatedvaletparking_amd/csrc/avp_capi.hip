@@ -10,6 +10,7 @@
 #include "avp_check_kernels.h"
 #include "avp_rs_kernels.h"
 #include "avp_plan_kernels.h"
+#include "avp_raster_kernels.h"
 
 static thread_local char g_err[512] = "";
 static int32_t set_err(int32_t code, const char* fmt, const char* a = "", const char* b = "")
@@ -219,6 +220,23 @@ AVP_EXPORT int32_t avp_ieee_batch(avp_map* map, const double* a, const double* b
     if (!map || n <= 0 || !a || !b || !q || !r || !h) return set_err(AVP_ERR_ARG, "avp_ieee_batch: bad argument");
     HIPCHK(hipSetDevice(map->device));
     hipLaunchKernelGGL(ieee_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, map->stream, a, b, n, q, r, h);
+    HIPCHK(hipGetLastError());
+    return AVP_OK;
+}
+
+AVP_EXPORT int32_t avp_rasterize_edges(int32_t device, void* stream, const double* xs, const double* ys, int32_t nx, int32_t ny,
+                                       double x0, double dx, double y0, double dy, const double* edges, int64_t n_edges,
+                                       int32_t max_count, uint8_t* occ, int32_t* multi)
+{
+    if (!xs || !ys || nx < 2 || ny < 2 || !(dx > 0) || !(dy > 0) || n_edges < 0 || (n_edges > 0 && !edges) || !occ || !multi)
+        return set_err(AVP_ERR_ARG, "avp_rasterize_edges: bad argument");
+    if (n_edges == 0 || max_count <= 0) return AVP_OK;
+    if (n_edges > 65535) return set_err(AVP_ERR_ARG, "avp_rasterize_edges: more than 65535 edges in one call");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    RasterGrid g;
+    g.X = xs; g.Y = ys; g.nx = nx; g.ny = ny; g.dx = dx; g.dy = dy; g.b0 = x0; g.b2 = y0;
+    hipLaunchKernelGGL(rasterize_kernel, dim3((unsigned)((max_count + 63) / 64), (unsigned)n_edges), dim3(64), 0, (hipStream_t)stream,
+                       g, edges, n_edges, occ, multi);
     HIPCHK(hipGetLastError());
     return AVP_OK;
 }

@@ -16,6 +16,7 @@ import numpy as np
 
 from . import config as cfgmod
 from . import costmap, path_planner, sampling
+from .record_solution import DataRecorder, waypoints_to_trajectory
 
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "BenchmarkCases")
 
@@ -39,10 +40,14 @@ def main(argv=None) -> int:
     ap.add_argument("--batch", type=int, default=0, help="plan this many random start/goal pairs instead of the case's own")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max_pops", type=int, default=0)
+    ap.add_argument("--solution_dir", type=str, default=None,
+                    help="also write the way-points in the reference's Solution_<case>.csv layout (v, a, sigma, omega, t = 0)")
+    ap.add_argument("--host_raster", action="store_true", help="rasterise the obstacle edges with numpy instead of on the GPU")
     a = ap.parse_args(argv)
 
     cfg = cfgmod.read_config(a.config_name, a.config_dir)
-    park_map = costmap.Map(file=os.path.join(a.case_dir, a.case_name + ".csv"), discrete_size=cfg["map_discrete_size"])
+    park_map = costmap.Map(file=os.path.join(a.case_dir, a.case_name + ".csv"), discrete_size=cfg["map_discrete_size"],
+                           device=None if a.host_raster else "cuda")
     ego = costmap.Vehicle()
     planner = path_planner.PathPlanner(config=cfg, map=park_map, vehicle=ego)
     os.makedirs(a.out_dir, exist_ok=True)
@@ -51,6 +56,8 @@ def main(argv=None) -> int:
         original_path, info, split = planner.path_planning()
         out = os.path.join(a.out_dir, f"Planned_{a.case_name}.tsv")
         write_segments(out, split)
+        if a.solution_dir:
+            DataRecorder.record(save_path=a.solution_dir, save_name=a.case_name + ".csv", trajectory=waypoints_to_trajectory(original_path))
         print(f"{a.case_name}: {len(original_path)} way-points, {info['change_gear']} gear changes, "
               f"RS tail {''.join(info['rs_path'].ctypes)} L={info['rs_path'].L:.4f} m, {time.perf_counter() - t0:.3f} s -> {out}")
         return 0

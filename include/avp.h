@@ -189,6 +189,20 @@ int32_t avp_hfield_queries(avp_map* map, const double goal_xy[2], const double* 
                            int32_t nq, void* workspace, int64_t workspace_bytes, int32_t* out_dist_q,
                            int32_t* out_miss, uint32_t* out_dist, uint8_t* out_flags, int64_t* out_info);
 
+/* Obstacle-edge rasteriser: replaces the per-sample part of Map.detect_obstacle_edge (map/costmap.py:236-261;
+ * SURVEY.md section 8(f) rank 3). The host keeps np.unique / the centroid-angle argsort / arctan2, cos, sin of the
+ * edge angle (map/costmap.py:203-233, numpy SIMD-dispatch sensitive) and passes one row per polygon edge:
+ * edges[e] = {p1x, p1y, cos, sin, rotated length, count = floor(length / dx)}. The device evaluates
+ * np.linspace(0, length, count), rotates back, adds p1 and marks occ[ix * ny + iy] = 255 for the unique node with
+ * X[ix] < px < X[ix] + dx (strict, :253-257), likewise y. All pointers are device pointers; occ must be zeroed by
+ * the caller (it may already hold other obstacles' cells); *multi is incremented for every sample that matches
+ * more than one node on an axis (the reference raises TypeError there, :260). No avp_map is needed: this runs
+ * before avp_map_create. x0 = xs[0], dx = xs[1] - xs[0], y0 = ys[0], dy = ys[1] - ys[0] (host values of the device
+ * tables); max_count = largest count in the table; device < 0 = current device; stream = hipStream_t or NULL. */
+int32_t avp_rasterize_edges(int32_t device, void* stream, const double* xs, const double* ys, int32_t nx, int32_t ny,
+                            double x0, double dx, double y0, double dy, const double* edges, int64_t n_edges,
+                            int32_t max_count, uint8_t* occ, int32_t* multi);
+
 /* Device evaluation of the shared scalar maths (test hook): out_sin/out_cos = avp_sin/avp_cos(x). */
 int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos);
 /* Device IEEE check hook: q = a / b, r = sqrt(|a|), h = hypot(a, b) as the kernels compute them. */

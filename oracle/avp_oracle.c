@@ -1370,3 +1370,42 @@ ORC_API void orc_corridor_batch(const orc_ctx *c, double expand, const double *p
 ORC_API int32_t orc_sizeof_ctx(void) { return (int32_t)sizeof(orc_ctx); }
 ORC_API int32_t orc_sizeof_plan_out(void) { return (int32_t)sizeof(orc_plan_out); }
 ORC_API double orc_py_hypot(double a, double b) { return py_hypot(a, b); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Per-sample stage of Map.detect_obstacle_edge, map/costmap.py:236-261. */
+/* edges[e] = {p1x, p1y, cos, sin, length, count}: the host (numpy) half of the function (np.unique, */
+/* argsort of centroid angles, arctan2/cos/sin of the edge, np.dot for the length) stays in numpy. */
+/* For q < count: t = np.linspace(0, length, count)[q]; np.dot(rot.T, [[t],[0]]) = (cos*t, sin*t)   */
+/* (the second product of each 2-term dot is an exact zero); + p1; np.where((X < p) & (X > p - dx)) */
+/* scanned over the whole axis as the reference does. Returns the number of samples that matched   */
+/* more than one node on an axis (the reference raises TypeError there, :260).                      */
+ORC_API int orc_rasterize_edges(const double *xs, const double *ys, int nx, int ny, double dx, double dy,
+                                const double *edges, long n_edges, unsigned char *occ /* nx*ny */)
+{
+    int multi = 0;
+    for (long e = 0; e < n_edges; e++) {
+        const double *r = edges + 6 * e;
+        const int count = (int)r[5];
+        for (int q = 0; q < count; q++) {
+            /* numpy.linspace (numpy/_core/function_base.py:linspace) with start = 0 */
+            double t = (double)q;
+            const int div = count - 1;
+            if (div > 0) {
+                const double step = r[4] / (double)div;
+                if (step == 0.0) { t = t / (double)div; t = t * r[4]; }
+                else t = t * step;
+            } else t = t * r[4];
+            t = t + 0.0;
+            if (count > 1 && q == count - 1) t = r[4];
+            const double lx = r[2] * t, ly = r[3] * t;
+            const double px = lx + r[0], py = ly + r[1];
+            int ni = 0, nj = 0, i0 = -1, j0 = -1;
+            for (int i = 0; i < nx; i++) if (xs[i] < px && xs[i] > px - dx) { if (!ni) i0 = i; ni++; }
+            for (int j = 0; j < ny; j++) if (ys[j] < py && ys[j] > py - dy) { if (!nj) j0 = j; nj++; }
+            if (ni == 0 || nj == 0) continue;
+            if (ni > 1 || nj > 1) { multi++; continue; }
+            occ[(long)i0 * ny + j0] = 255;
+        }
+    }
+    return multi;
+}

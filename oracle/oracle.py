@@ -246,6 +246,20 @@ class Oracle:
         return pts[:r].copy(), seg[:nseg.value].copy(), cg.value
 
 
+def rasterize_edges(xs, ys, edges):
+    """Per-sample stage of Map.detect_obstacle_edge on the CPU (orc_rasterize_edges): returns
+    (uint8 occupancy [nx, ny], number of multi-match samples)."""
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    edges = np.ascontiguousarray(edges, dtype=np.float64).reshape(-1, 6)
+    occ = np.zeros((len(xs), len(ys)), dtype=np.uint8)
+    f = lib().orc_rasterize_edges
+    f.restype = C.c_int
+    multi = f(_p(xs), _p(ys), C.c_int(len(xs)), C.c_int(len(ys)), C.c_double(float(xs[1] - xs[0])), C.c_double(float(ys[1] - ys[0])),
+              _p(edges), C.c_long(len(edges)), _p(occ))
+    return occ, int(multi)
+
+
 class OracleDijkstra:
     def __init__(self, orc: Oracle, gx, gy):
         self.o = orc

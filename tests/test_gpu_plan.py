@@ -221,3 +221,18 @@ def test_large_map_tables_not_in_lds(vehicle, cfg, tmp_path):
     with oracle.portable_libm():
         for i, r in enumerate(res):
             _assert_same_as_oracle(r, o.plan(starts[i], goals[i], max_trace=cap))
+
+
+def test_main_driver_case1(tmp_path, capsys):
+    """Planning-only driver (main.py:28-66,143-171 of the reference): device rasteriser -> planner -> segment
+    file + Solution_<case>.csv in the reference's recorder layout; way-points equal the golden run's."""
+    from automatedvaletparking_amd import main as drv
+    from automatedvaletparking_amd.record_solution import DataRecorder
+    g = gold("g6_trace_case1.npz")
+    out, sol = tmp_path / "pre", tmp_path / "solution"
+    assert drv.main(["--case_name", "Case1", "--out_dir", str(out), "--solution_dir", str(sol)]) == 0
+    rows = np.loadtxt(str(out / "Planned_Case1.tsv"), skiprows=1)
+    assert np.abs(rows[:, 1:4] - g["split_concat"]).max() < 1e-6
+    assert [int((rows[:, 0] == k).sum()) for k in range(int(rows[:, 0].max()) + 1)] == list(g["split_len"])
+    traj = DataRecorder.read(str(sol / "Solution_Case1.csv"))
+    assert traj.shape[1] == 8 and np.abs(traj[:, :3] - g["split_concat"]).max() < 1e-6 and not traj[:, 3:].any()

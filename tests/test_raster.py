@@ -1,0 +1,111 @@
+"""Obstacle-edge rasteriser, SURVEY.md section 8(f) rank 3 (map/costmap.py:197-261).
+
+CPU: the oracle's per-sample stage (oracle/avp_oracle.c: orc_rasterize_edges) fed with the host edge table
+reproduces the reference's costmap cells (golden G1) for all 20 cases. GPU: avp_rasterize_edges does too,
+bit-exact (cell sets are integers), through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CASES, gold
+
+
+def _case_map(k, cfg, **kw):
+    from automatedvaletparking_amd import costmap
+    return costmap.Map(file=os.path.join(CASES, f"Case{k}.csv"), discrete_size=cfg["map_discrete_size"], **kw)
+
+
+def _cells(occ):
+    ix, iy = np.where(np.asarray(occ) == 255)
+    return np.stack([ix, iy], 1)
+
+
+@pytest.mark.parametrize("k", list(range(1, 21)))
+def test_oracle_rasteriser_matches_reference(k, cfg):
+    from oracle import oracle
+    g1 = gold("g1_costmaps.npz")
+    m = _case_map(k, cfg)
+    occ, multi = oracle.rasterize_edges(m.map_position[0], m.map_position[1], m.edge_table())
+    assert multi == 0
+    assert np.array_equal(_cells(occ), g1[f"c{k}_cells"])
+
+
+def test_linspace_restatement_edge_counts():
+    """count 0 / 1 / 2 and a zero-length edge follow numpy.linspace (endpoint overwrite, div == 0 branch)."""
+    from oracle import oracle
+    xs = np.linspace(0.0, 10.0, 101)
+    ys = np.linspace(0.0, 5.0, 51)
+    dx = xs[1] - xs[0]
+    rows = []
+    for length, count in [(0.05, 0), (0.15, 1), (0.25, 2), (0.35, 3), (0.0, 0), (7.3, 73)]:
+        rows.append([1.03, 1.07, np.cos(0.3), np.sin(0.3), length, float(count)])
+    edges = np.array(rows)
+    occ, multi = oracle.rasterize_edges(xs, ys, edges)
+    want = np.zeros_like(occ)
+    for p1x, p1y, ca, sa, length, count in edges:
+        t = np.linspace(0, length, int(count))
+        pts = np.dot(np.array([[ca, sa], [-sa, ca]]).transpose(), np.vstack((t, np.zeros(int(count)))))
+        for q in range(int(count)):
+            px, py = pts[0][q] + p1x, pts[1][q] + p1y
+            i = np.where((xs < px) & (xs > px - dx))[0]
+            j = np.where((ys < py) & (ys > py - (ys[1] - ys[0])))[0]
+            if len(i) and len(j):
+                want[int(i[0]), int(j[0])] = 255
+    assert multi == 0 and np.array_equal(occ, want) and want.sum() > 0
+
+
+def test_edge_table_shape(cfg):
+    m = _case_map(1, cfg)
+    e = m.edge_table()
+    assert e.shape[1] == 6 and len(e) == sum(len(np.unique(o, axis=0)) for o in m.case.obs)
+    assert np.all(e[:, 5] == np.floor(e[:, 4] / m._discrete_x))
+
+
+# ---------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", list(range(1, 21)))
+def test_device_rasteriser_matches_reference(k, cfg):
+    from automatedvaletparking_amd import _native
+    from oracle import oracle
+    g1 = gold("g1_costmaps.npz")
+    m = _case_map(k, cfg)
+    edges = m.edge_table()
+    occ, multi = _native.rasterize_edges(m.map_position[0], m.map_position[1], edges)
+    occ = occ.cpu().numpy()
+    assert multi == 0
+    assert np.array_equal(_cells(occ), g1[f"c{k}_cells"])
+    ref, _ = oracle.rasterize_edges(m.map_position[0], m.map_position[1], edges)
+    assert np.array_equal(occ, ref)
+
+
+@pytest.mark.gpu
+def test_device_rasteriser_synthetic_maps(cfg, tmp_path):
+    """C4 / C5 style maps (configs 4, 5): Map(device=...) equals the host Map cell for cell."""
+    from automatedvaletparking_amd import costmap, sampling
+    for name, polys, size in [("c4", sampling.synthetic_polygon_map(seed=4), 0.12), ("c5", sampling.parking_lot_map()[0], 0.1)]:
+        p = tmp_path / f"{name}.csv"
+        sampling.write_tpcap_csv(str(p), (12.0, 12.0, 0.0), (12.0, 12.0, 0.5), polys)
+        host = costmap.Map(file=str(p), discrete_size=size)
+        dev = costmap.Map(file=str(p), discrete_size=size, device="cuda")
+        assert np.array_equal(host.cost_map, dev.cost_map) and host.cost_map.sum() > 0
+        assert np.array_equal(host.pack()["obs_ix"], dev.pack()["obs_ix"])
+
+
+@pytest.mark.gpu
+def test_device_rasteriser_degenerate_edges():
+    from automatedvaletparking_amd import _native
+    from oracle import oracle
+    xs = np.linspace(0.0, 10.0, 101)
+    ys = np.linspace(0.0, 5.0, 51)
+    rng = np.random.default_rng(7)
+    rows = []
+    for _ in range(300):
+        a = rng.uniform(-np.pi, np.pi)
+        length = rng.choice([0.0, 0.05, 0.11, 0.21, rng.uniform(0, 6)])
+        # starts outside the grid too: samples without a node are skipped (:259)
+        rows.append([rng.uniform(-1, 11), rng.uniform(-1, 6), np.cos(a), np.sin(a), length, float(np.floor(length / (xs[1] - xs[0])))])
+    edges = np.array(rows)
+    occ, multi = _native.rasterize_edges(xs, ys, edges)
+    ref, rmulti = oracle.rasterize_edges(xs, ys, edges)
+    assert multi == rmulti and np.array_equal(occ.cpu().numpy(), ref) and ref.sum() > 0
