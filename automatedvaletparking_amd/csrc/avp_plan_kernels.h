@@ -222,6 +222,7 @@ struct PlShared {
     int32_t rs_status, rs_npts, rs_first_coll, in_radius, collision;
     RsPath rs;                        // normalised winner of the shot
     int64_t n_checks, n_rs;
+    int64_t snap[5];                  // counters saved before a speculative resolution
     long long phase[10];
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
@@ -803,6 +804,88 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
     wave_sync();
 }
 
+// ---- fast path of the child resolution (expand_node :153-232), run by WAVE 0 alone (wave-level syncs only) ----
+// Preconditions (caller): closed list non-empty and the arena has room for every child. Lanes classify and cost
+// their child in parallel; if every heuristic query hits the closed frontier, lane 0 then applies, in child
+// order, only what is order dependent: arena slots, in-place improvements of open nodes and heap pushes.
+// s.fast (preset to 1) reports whether the pop was resolved here; when it is 0 nothing has been modified.
+AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const PlanWs& w, PlShared& s, const PlanDims& dims,
+                                const PlNode& cn, int nchild)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < nchild) {
+        PlChild& c = s.child[lane];
+        c.pre_d = pl_id_in_range(m, c.id) ? w.dist[c.id] : PL_UNSEEN;
+        const int is_forward = lane < p.n_steer ? 1 : 0;
+        const bool found_closed = c.found >= 0 && c.found_state == 2;
+        const bool found_open = c.found >= 0 && c.found_state == 1;
+        int cls;
+        if (found_closed || c.oob) cls = CL_SKIP;
+        else if (!found_open && c.first_coll != 0x7fffffff) cls = CL_NEW_CLOSED;
+        else {
+            uint32_t hd = PL_UNSEEN;
+            const bool hit = pl_hquery_hit(m, s, c.id, c.pre_d, hd);
+            if (!hit || hd == PL_UNSEEN || c.rs_err) { s.fast = 0; cls = CL_SKIP; }
+            else {
+                const double hv1 = (double)hd / 100, hv2 = c.L;
+                const double hval = hv2 > hv1 ? hv2 : hv1;
+                if (!found_open) {
+                    c.g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
+                    c.h = hval; c.f = c.g + hval;
+                    cls = CL_NEW_OPEN;
+                } else {
+                    const PlNode& ch = w.nodes[c.found];
+                    c.g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
+                    c.h = hval; c.f = hval + c.g;
+                    c.old_f = ch.f; c.old_heap_pos = ch.heap_pos;
+                    cls = c.f < ch.f ? CL_IMPROVE : CL_KEEP;
+                }
+            }
+        }
+        c.cls = cls;
+    }
+    wave_sync();
+    if (!s.fast) return;
+    if (lane == 0) {
+        for (int i = 0; i < nchild; i++) {
+            PlChild& c = s.child[i];
+            if (c.cls == CL_NEW_CLOSED) { c.pos = s.nnodes++; s.n_checks += c.first_coll + 1; s.nclosed++; }
+            else if (c.cls == CL_NEW_OPEN) { c.pos = s.nnodes++; s.n_checks += p.n_sub; s.n_rs += 1; }
+            else if (c.cls == CL_IMPROVE || c.cls == CL_KEEP) s.n_rs += 1;
+        }
+    }
+    wave_sync();
+    if (lane < nchild) {
+        const PlChild& c = s.child[lane];
+        if (c.cls == CL_NEW_CLOSED || c.cls == CL_NEW_OPEN) {
+            const bool open = c.cls == CL_NEW_OPEN;
+            PlNode& nd = w.nodes[c.pos];
+            nd.x = c.x; nd.y = c.y; nd.th = c.th;
+            nd.g = open ? c.g : 0.0; nd.h = open ? c.h : 0.0; nd.f = open ? c.f : 0.0;
+            nd.index = (int32_t)(s.global_index + lane + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+            nd.forward = (int8_t)(lane < p.n_steer ? 1 : 0); nd.steer_i = (int8_t)(lane % p.n_steer);
+            nd.state = open ? 1 : 2; nd.heap_pos = -1;
+            pl_hash_put_atomic(w, dims.hashCap, c.pos, c.x, c.y, c.th);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_sync();
+    if (lane == 0) {
+        for (int i = 0; i < nchild; i++) {
+            const PlChild& c = s.child[i];
+            if (c.cls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)c.pos);
+            else if (c.cls == CL_IMPROVE) {
+                PlNode& ch = w.nodes[c.found];
+                ch.f = c.f; ch.g = c.g; ch.h = c.h;
+                ch.parent_index = cn.index; ch.parent_pos = s.cur;
+                ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
+                w.heap[ch.heap_pos].f = c.f;      // current slot: earlier pushes of this pop may have moved it
+            }
+        }
+    }
+    wave_sync();
+}
+
 template <bool STAGE>
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                           const double* __restrict__ goals, int64_t n, int32_t maxNodes,
@@ -990,35 +1073,51 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
             const long long t_g = clock64();
             if (tid == 0) s.phase[PH_SHOT_SAMPLE] += t_g - t_f0;
+            // The outcome of the shot is not an input of the child resolution, so when the resolution can take its
+            // fast path, wave 0 runs it SPECULATIVELY while the other waves check the shot's samples; if the shot
+            // then turns out collision free (the search ends at this pop, before expand_node), the counters are
+            // rolled back -- the arena / heap / hash side effects touch no node of the final path's parent chain.
+            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
             if (in_radius) {
                 pl_rs_sample_local(w, s, p);
+                if (tid == 0) {
+                    s.fast = can_fast ? 1 : 0;
+                    s.snap[0] = s.nnodes; s.snap[1] = s.n_checks; s.snap[2] = s.n_rs; s.snap[3] = s.nclosed; s.snap[4] = s.nheap;
+                }
                 __syncthreads();
-                // world transform (:125-131) fused with the collision pass over the samples (:335-345)
                 const int np = s.rs_npts;
-                const double cm = avp_cos(-cn.th), sm = avp_sin(-cn.th);
-                const int per = max(1, min(PL_WPOSE, (np + nwave - 1) / nwave));
-                for (int base = wave * per; base < np; base += nwave * per) {
-                    const int cnt = min(per, np - base);
-                    double tx = 0.0, ty = 0.0, tth = 0.0;
-                    if (lane < cnt) {
-                        const int g = base + lane;
-                        const double ix = w.rsbuf[3 * g], iy = w.rsbuf[3 * g + 1];
-                        tx = cm * ix + sm * iy + cn.x;
-                        ty = -sm * ix + cm * iy + cn.y;
-                        tth = avp_pi_2_pi(w.rsbuf[3 * g + 2] + cn.th);
-                        w.rsbuf[3 * g] = tx; w.rsbuf[3 * g + 1] = ty; w.rsbuf[3 * g + 2] = tth;
+                const int w0 = can_fast ? 1 : 0, nw = nwave - w0;
+                if (can_fast && wave == 0) pl_resolve_fast_wave(m, p, w, s, dims, cn, nchild);
+                if (wave >= w0) {
+                    // world transform (:125-131) fused with the collision pass over the samples (:335-345)
+                    const double cm = avp_cos(-cn.th), sm = avp_sin(-cn.th);
+                    const int per = max(1, min(PL_WPOSE, (np + nw - 1) / nw));
+                    for (int base = (wave - w0) * per; base < np; base += nw * per) {
+                        const int cnt = min(per, np - base);
+                        double tx = 0.0, ty = 0.0, tth = 0.0;
+                        if (lane < cnt) {
+                            const int g = base + lane;
+                            const double ix = w.rsbuf[3 * g], iy = w.rsbuf[3 * g + 1];
+                            tx = cm * ix + sm * iy + cn.x;
+                            ty = -sm * ix + cm * iy + cn.y;
+                            tth = avp_pi_2_pi(w.rsbuf[3 * g + 2] + cn.th);
+                            w.rsbuf[3 * g] = tx; w.rsbuf[3 * g + 1] = ty; w.rsbuf[3 * g + 2] = tth;
+                        }
+                        // pose k is only ever requested by lane k: hand back the lane's own registers
+                        pl_check_wave(m, mt, p, s, cnt, [&](int, double& x, double& y, double& th) { x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
+                        }, &s.chk_hit[nsubs + base]);
                     }
-                    // pose k is only ever requested by lane k: hand back the lane's own registers
-                    pl_check_wave(m, mt, p, s, cnt, [&](int, double& x, double& y, double& th) { x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
-                    }, &s.chk_hit[nsubs + base]);
                 }
                 __syncthreads();
                 for (int g = tid; g < np; g += PL_THREADS) if (s.chk_hit[nsubs + g]) atomicMin(&s.rs_first_coll, g);
                 __syncthreads();
                 if (tid == 0) {
-                    if (s.rs_first_coll != 0x7fffffff) { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
-                    else s.n_checks += np;
-                    if (!s.collision) s.done = 1;
+                    if (s.rs_first_coll == 0x7fffffff) {
+                        // success: the reference returns before expand_node -- undo the speculative bookkeeping
+                        s.nnodes = (int32_t)s.snap[0]; s.n_checks = s.snap[1]; s.n_rs = s.snap[2]; s.nclosed = (int32_t)s.snap[3]; s.nheap = (int32_t)s.snap[4];
+                        s.n_checks += np;
+                        s.done = 1;
+                    } else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
                 }
             }
             __syncthreads();
@@ -1028,83 +1127,16 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
             // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
-            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes); }
-            if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
+            const bool tried = in_radius && can_fast;               // the speculative attempt above
+            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; if (!tried) s.fast = can_fast ? 1 : 0; }
+            if (!can_fast && tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
-            // ---- fast path: closed list non-empty and every heuristic query hits the closed frontier.
-            // Lanes classify and cost their child in parallel; thread 0 then applies, in child order, only
-            // what is order dependent: arena slots, in-place improvements of open nodes and heap pushes.
-            if (s.fast) {
-                if (tid < nchild) {
-                    PlChild& c = s.child[tid];
-                    const int is_forward = tid < p.n_steer ? 1 : 0;
-                    const bool found_closed = c.found >= 0 && c.found_state == 2;
-                    const bool found_open = c.found >= 0 && c.found_state == 1;
-                    int cls;
-                    if (found_closed || c.oob) cls = CL_SKIP;
-                    else if (!found_open && c.first_coll != 0x7fffffff) cls = CL_NEW_CLOSED;
-                    else {
-                        uint32_t hd = PL_UNSEEN;
-                        const bool hit = pl_hquery_hit(m, s, c.id, c.pre_d, hd);
-                        if (!hit || hd == PL_UNSEEN || c.rs_err) { s.fast = 0; cls = CL_SKIP; }
-                        else {
-                            const double hv1 = (double)hd / 100, hv2 = c.L;
-                            const double hval = hv2 > hv1 ? hv2 : hv1;
-                            if (!found_open) {
-                                c.g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
-                                c.h = hval; c.f = c.g + hval;
-                                cls = CL_NEW_OPEN;
-                            } else {
-                                const PlNode& ch = w.nodes[c.found];
-                                c.g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
-                                c.h = hval; c.f = hval + c.g;
-                                c.old_f = ch.f; c.old_heap_pos = ch.heap_pos;
-                                cls = c.f < ch.f ? CL_IMPROVE : CL_KEEP;
-                            }
-                        }
-                    }
-                    c.cls = cls;
-                }
+            if (!tried && can_fast) {
+                if (wave == 0) pl_resolve_fast_wave(m, p, w, s, dims, cn, nchild);
                 __syncthreads();
             }
             if (s.fast) {
-                if (tid == 0) {
-                    for (int i = 0; i < nchild; i++) {
-                        PlChild& c = s.child[i];
-                        if (c.cls == CL_NEW_CLOSED) { c.pos = s.nnodes++; s.n_checks += c.first_coll + 1; s.nclosed++; }
-                        else if (c.cls == CL_NEW_OPEN) { c.pos = s.nnodes++; s.n_checks += p.n_sub; s.n_rs += 1; }
-                        else if (c.cls == CL_IMPROVE || c.cls == CL_KEEP) s.n_rs += 1;
-                    }
-                }
-                __syncthreads();
-                if (tid < nchild) {
-                    const PlChild& c = s.child[tid];
-                    if (c.cls == CL_NEW_CLOSED || c.cls == CL_NEW_OPEN) {
-                        const bool open = c.cls == CL_NEW_OPEN;
-                        PlNode& nd = w.nodes[c.pos];
-                        nd.x = c.x; nd.y = c.y; nd.th = c.th;
-                        nd.g = open ? c.g : 0.0; nd.h = open ? c.h : 0.0; nd.f = open ? c.f : 0.0;
-                        nd.index = (int32_t)(s.global_index + tid + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
-                        nd.forward = (int8_t)(tid < p.n_steer ? 1 : 0); nd.steer_i = (int8_t)(tid % p.n_steer);
-                        nd.state = open ? 1 : 2; nd.heap_pos = -1;
-                        pl_hash_put_atomic(w, dims.hashCap, c.pos, c.x, c.y, c.th);
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    for (int i = 0; i < nchild; i++) {
-                        const PlChild& c = s.child[i];
-                        if (c.cls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)c.pos);
-                        else if (c.cls == CL_IMPROVE) {
-                            PlNode& ch = w.nodes[c.found];
-                            ch.f = c.f; ch.g = c.g; ch.h = c.h;
-                            ch.parent_index = cn.index; ch.parent_pos = s.cur;
-                            ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
-                            w.heap[ch.heap_pos].f = c.f;      // current slot: earlier pushes of this pop may have moved it
-                        }
-                    }
-                }
-                __syncthreads();
+                // resolved by wave 0 (speculatively above, or just now)
             } else
             for (;;) {
                 if (tid == 0) {
