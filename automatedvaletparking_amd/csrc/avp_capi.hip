@@ -174,7 +174,7 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
             hipLaunchKernelGGL(check_distance_naive_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
         } else {
             const size_t lds_full = check_distance_lds_bytes(d, true);
-            const bool stage = lds_full <= 160 * 1024;
+            const bool stage = lds_full + AVP_LDS_TABLE_BYTES <= 160 * 1024;     // static LDS: the trig tables
             const size_t lds = stage ? lds_full : check_distance_lds_bytes(d, false);
             const int64_t tiles = (n + 63) / 64;
             int64_t blocks = (tiles + CHK_WAVES - 1) / CHK_WAVES;

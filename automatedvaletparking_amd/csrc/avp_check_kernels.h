@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void check_distance_naive_kernel(DevMap m, avp
                                                                    const double* __restrict__ th, int64_t n,
                                                                    uint8_t* __restrict__ out)
 {
+    avp_lds_tables_fill<false>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Footprint f;
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
                                                                         const double* __restrict__ th, int64_t n,
                                                                         uint8_t* __restrict__ out)
 {
+    avp_lds_tables_fill<false>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve: [bitmap words][X][Y][per-wave: footprints 64*24 doubles | queue | hit flags]
     // STAGE: map tables live in LDS; otherwise (map too large for 160 KB) they are read through L1/L2
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
                                                            const double* __restrict__ y, const double* __restrict__ th,
                                                            int64_t n, uint8_t* __restrict__ out)
 {
+    avp_lds_tables_fill<false>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double cs = avp_cos(th[i]), sn = avp_sin(th[i]);
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
                                                        const double* __restrict__ y, const double* __restrict__ th, int64_t n,
                                                        double* __restrict__ out)
 {
+    avp_lds_tables_fill<false>();
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const double px = x[q], py = y[q], theta = th[q];
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
 // ---- test hooks -------------------------------------------------------------------------------
 __global__ void trig_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ s, double* __restrict__ c)
 {
+    avp_lds_tables_fill<false>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { s[i] = avp_sin(x[i]); c[i] = avp_cos(x[i]); }
 }

@@ -4,6 +4,27 @@
 #include <hip/hip_runtime.h>
 #include "../../include/avp.h"
 #include "avp_math.h"
+#include "../../include/avp_libm.h"
+
+// static LDS taken by the trig tables in every kernel that evaluates trig
+#define AVP_LDS_TABLE_BYTES (sizeof(AVP_SINCOS_TAB) + sizeof(AVP_ATAN_TAB))
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Copy the sin/cos and atan tables into LDS; all threads of the workgroup, once, before any trig call.
+template <bool WITH_ATAN>
+__device__ __forceinline__ void avp_lds_tables_fill()
+{
+    const int n1 = (int)(sizeof(AVP_SINCOS_TAB) / sizeof(double));
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) (&AVP_SINCOS_LDS[0][0])[i] = (&AVP_SINCOS_TAB[0][0])[i];
+    if (WITH_ATAN) {
+        const int n2 = (int)(sizeof(AVP_ATAN_TAB) / sizeof(double));
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) (&AVP_ATAN_LDS[0][0])[i] = (&AVP_ATAN_TAB[0][0])[i];
+    }
+    __syncthreads();
+}
+#else
+template <bool WITH_ATAN> __device__ inline void avp_lds_tables_fill() {}       // host pass of hipcc: declaration only
+#endif
 
 // Costmap resident in HBM. Column-major occupancy in two forms:
 //  - obstacle points in np.where(cost_map == 255) order (sorted by ix, then iy): ox/oy + colStart

@@ -33,6 +33,16 @@
 
 #include "avp_sincos_tab.h"
 
+// Device code reads the trig tables from LDS: a lookup sits on the dependent chain of every sin/cos/atan
+// (dozens per expanded node), and an LDS read costs ~1/10 of a global one whose L1 line the kernel's scratch
+// traffic keeps evicting. Every kernel that evaluates trig calls avp_lds_tables_fill() first (avp_device.h).
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ double AVP_SINCOS_LDS[sizeof(AVP_SINCOS_TAB) / sizeof(AVP_SINCOS_TAB[0])][4];
+#define AVP_SCT AVP_SINCOS_LDS
+#else
+#define AVP_SCT AVP_SINCOS_TAB
+#endif
+
 #define AVP_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define AVP_PI 3.141592653589793
 
@@ -83,8 +93,8 @@ AVP_HD double do_sin(double x, double dx)
     const double xx = x * x;
     const double s = x + AVP_FMA(x * xx, AVP_FMA(xx, sn5, sn3), dx);
     const double c = AVP_FMA(x, dx, xx * AVP_FMA(xx, AVP_FMA(xx, cs6, cs4), cs2));
-    const double sn = AVP_SINCOS_TAB[k][0], ssn = AVP_SINCOS_TAB[k][1];
-    const double cs = AVP_SINCOS_TAB[k][2], ccs = AVP_SINCOS_TAB[k][3];
+    const double sn = AVP_SCT[k][0], ssn = AVP_SCT[k][1];
+    const double cs = AVP_SCT[k][2], ccs = AVP_SCT[k][3];
     const double cor = AVP_FMA(cs, s, AVP_FMA(-sn, c, AVP_FMA(s, ccs, ssn)));
     return copysign(sn + cor, xold);
 }
@@ -98,8 +108,8 @@ AVP_HD double do_cos(double x, double dx)
     const double xx = x * x;
     const double s = AVP_FMA(x * xx, AVP_FMA(xx, sn5, sn3), x);
     const double c = xx * AVP_FMA(xx, AVP_FMA(xx, cs6, cs4), cs2);
-    const double sn = AVP_SINCOS_TAB[k][0], ssn = AVP_SINCOS_TAB[k][1];
-    const double cs = AVP_SINCOS_TAB[k][2], ccs = AVP_SINCOS_TAB[k][3];
+    const double sn = AVP_SCT[k][0], ssn = AVP_SCT[k][1];
+    const double cs = AVP_SCT[k][2], ccs = AVP_SCT[k][3];
     const double cor = AVP_FMA(-sn, s, AVP_FMA(-cs, c, AVP_FMA(-s, ssn, ccs)));
     return cs + cor;
 }

@@ -193,7 +193,7 @@ struct MapTabs { const double* X; const double* Y; const uint64_t* bits; };
 #define PL_WQCAP 1024                 // (pose, point) candidates per wave
 struct PlWaveChk {
     Footprint fp[PL_WPOSE];
-    int16_t rng[PL_WPOSE][4];         // ixlo, ncol, iylo, iyhi
+    int16_t rng[PL_WPOSE][4];         // ixlo, ixhi, iylo, iyhi
     uint32_t hit[PL_WPOSE];
     int32_t qn, over;
     uint32_t q[PL_WQCAP];             // pose << 24 | ix << 12 | iy   (nx, ny < 4096 on this path)
@@ -754,26 +754,67 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
         return;
     }
     if (lane == 0) { wc.qn = 0; wc.over = 0; }
-    if (lane < count) {
-        double x, y, th;
-        pose(lane, x, y, th);
-        Footprint f;
-        avp_footprint_setup(p, x, y, th, f);
-        double xmin, xmax, ymin, ymax;
-        avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
-        const int ixlo = avp_first_ge(mt.X, m.nx, m.b0, m.dx, xmin), ixhi = avp_last_le(mt.X, m.nx, m.b0, m.dx, xmax);
-        const int iylo = avp_first_ge(mt.Y, m.ny, m.b2, m.dy, ymin), iyhi = avp_last_le(mt.Y, m.ny, m.b2, m.dy, ymax);
-        int ncol = ixhi - ixlo + 1;
-        if (ncol < 0 || iylo > iyhi) ncol = 0;
-        wc.fp[lane] = f;
-        wc.rng[lane][0] = (int16_t)ixlo; wc.rng[lane][1] = (int16_t)ncol; wc.rng[lane][2] = (int16_t)iylo; wc.rng[lane][3] = (int16_t)iyhi;
-        wc.hit[lane] = 0;
+    // Footprint set-up, 8 lanes per pose: every lane of a group evaluates the pose and the corners, then the
+    // group's lanes split what is data parallel: 4 edges (slope / intercept / norm: the divisions and square
+    // roots), 2 side lengths, and the 4 index searches (2 code paths x 2 axes). Same arithmetic per value as
+    // avp_footprint_setup / avp_footprint_aabb -- only who computes it changes.
+    {
+        const int grp = lane >> 3, sub = lane & 7;
+        if (grp < count) {
+            double x, y, th;
+            pose(grp, x, y, th);
+            const double cs = avp_cos(th), sn = avp_sin(th);
+            const double lx[4] = { p.fp_xr, p.fp_xf, p.fp_xf, p.fp_xr };
+            const double ly[4] = { p.fp_yr, p.fp_yr, p.fp_yl, p.fp_yl };
+            double cx[4], cy[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                cx[i] = AVP_FMA(-sn, ly[i], cs * lx[i]) + x;
+                cy[i] = AVP_FMA(cs, ly[i], sn * lx[i]) + y;
+            }
+            Footprint& f = wc.fp[grp];
+            if (sub < 4) {
+                // edge sub: corner sub -> corner (sub + 1) & 3
+                const double x1 = sub == 0 ? cx[0] : sub == 1 ? cx[1] : sub == 2 ? cx[2] : cx[3];
+                const double y1 = sub == 0 ? cy[0] : sub == 1 ? cy[1] : sub == 2 ? cy[2] : cy[3];
+                const double x2 = sub == 0 ? cx[1] : sub == 1 ? cx[2] : sub == 2 ? cx[3] : cx[0];
+                const double y2 = sub == 0 ? cy[1] : sub == 1 ? cy[2] : sub == 2 ? cy[3] : cy[0];
+                const double k = (y2 - y1) / (x2 - x1);          // +-inf / NaN when axis aligned, as numpy
+                f.cx[sub] = x1; f.cy[sub] = y1;
+                f.k[sub] = k;
+                f.b[sub] = y1 - k * x1;
+                f.den[sub] = sqrt(1 + k * k);
+            } else if (sub < 6) {
+                // sub 4: |rr - lr| (width), sub 5: |lr - lf| (length)
+                const double t0 = sub == 4 ? cx[0] - cx[3] : cx[3] - cx[2];
+                const double t1 = sub == 4 ? cy[0] - cy[3] : cy[3] - cy[2];
+                const double thr = sqrt(t0 * t0 + t1 * t1) - 0.01;
+                if (sub == 4) f.wthr = thr; else f.lthr = thr;
+            }
+            double xmin = cx[0], xmax = cx[0], ymin = cy[0], ymax = cy[0];
+#pragma unroll
+            for (int i = 1; i < 4; i++) {
+                if (cx[i] > xmax) xmax = cx[i];
+                if (cx[i] < xmin) xmin = cx[i];
+                if (cy[i] > ymax) ymax = cy[i];
+                if (cy[i] < ymin) ymin = cy[i];
+            }
+            if (sub == 0 || sub == 2) {          // first node >= lower bound: x (sub 0), y (sub 2)
+                const bool ax = sub == 0;
+                wc.rng[grp][sub] = (int16_t)avp_first_ge(ax ? mt.X : mt.Y, ax ? m.nx : m.ny, ax ? m.b0 : m.b2, ax ? m.dx : m.dy, ax ? xmin : ymin);
+            } else if (sub == 1 || sub == 3) {   // last node <= upper bound: x (sub 1), y (sub 3)
+                const bool ax = sub == 1;
+                wc.rng[grp][sub] = (int16_t)avp_last_le(ax ? mt.X : mt.Y, ax ? m.nx : m.ny, ax ? m.b0 : m.b2, ax ? m.dx : m.dy, ax ? xmax : ymax);
+            }
+            if (sub == 7) wc.hit[grp] = 0;
+        }
     }
     wave_sync();
     for (int t = lane; t < count * 64; t += 64) {
         const int i = t >> 6, c = t & 63;
-        if (c >= wc.rng[i][1]) continue;
-        const int ix = wc.rng[i][0] + c, iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
+        const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];    // ixlo, ixhi, iylo, iyhi
+        if (iylo > iyhi || c > ixhi - ixlo) continue;
+        const int ix = ixlo + c;
         for (int wd = iylo >> 6; wd <= (iyhi >> 6); wd++) {
             uint64_t bits = mt.bits[(size_t)ix * m.wpc + wd];
             if (wd == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
@@ -894,6 +935,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                                           double* __restrict__ paths, int32_t max_path,
                                                           double* __restrict__ trace, int32_t max_trace)
 {
+    avp_lds_tables_fill<true>();
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
     PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
@@ -1103,8 +1145,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             tth = avp_pi_2_pi(w.rsbuf[3 * g + 2] + cn.th);
                             w.rsbuf[3 * g] = tx; w.rsbuf[3 * g + 1] = ty; w.rsbuf[3 * g + 2] = tth;
                         }
-                        // pose k is only ever requested by lane k: hand back the lane's own registers
-                        pl_check_wave(m, mt, p, s, cnt, [&](int, double& x, double& y, double& th) { x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
+                        // lane k holds pose k: broadcast it to whichever lanes ask for it
+                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th) {
+                            x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
                         }, &s.chk_hit[nsubs + base]);
                     }
                 }

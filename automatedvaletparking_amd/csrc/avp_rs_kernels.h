@@ -436,6 +436,7 @@ __global__ __launch_bounds__(64) void rs_optimal_kernel(const double* __restrict
                                                         double* __restrict__ lens, int32_t* __restrict__ npts,
                                                         double* __restrict__ xyyaw, int8_t* __restrict__ dir)
 {
+    avp_lds_tables_fill<true>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     RsPath p;

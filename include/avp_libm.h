@@ -41,6 +41,14 @@
 #endif
 #include "avp_atan_tab.h"
 
+/* the device build redirects the lookups to an LDS copy of the table (csrc/avp_device.h) */
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ double AVP_ATAN_LDS[65][2];
+#define AVP_ATAN_TAB_REF AVP_ATAN_LDS
+#else
+#define AVP_ATAN_TAB_REF AVP_ATAN_TAB
+#endif
+
 AVP_LIBM_FN uint32_t avpm_hi(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); }
 AVP_LIBM_FN uint32_t avpm_lo(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; }
 AVP_LIBM_FN double avpm_with_lo0(double x) { uint64_t u; memcpy(&u, &x, 8); u &= 0xffffffff00000000ull; memcpy(&x, &u, 8); return x; }
@@ -131,8 +139,8 @@ AVP_LIBM_FN void avpm_atan_dd(double uh, double ul, double* zh, double* zl)
     const double P = z * (-0x1.5555555555555p-2 + z * (0x1.999999999999ap-3 + z * (-0x1.2492492492492p-3 + z * (0x1.c71c71c71c71cp-4 + z * -0x1.745d1745d1746p-4))));
     const double corr = th * P;
     double sh, se;
-    avpm_two_sum(AVP_ATAN_TAB[k][0], th, &sh, &se);
-    double low = ((se + AVP_ATAN_TAB[k][1]) + tl) + corr;
+    avpm_two_sum(AVP_ATAN_TAB_REF[k][0], th, &sh, &se);
+    double low = ((se + AVP_ATAN_TAB_REF[k][1]) + tl) + corr;
     if (inv) {
         double vh, ve;
         avpm_two_sum(pio2_hi, -sh, &vh, &ve);
