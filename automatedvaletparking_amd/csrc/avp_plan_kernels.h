@@ -297,9 +297,10 @@ AVP_D void pl_hash_put_atomic(const PlanWs& w, int64_t hashCap, int32_t pos, dou
 // The key is stored next to the position (one load per comparison); an in-place improvement of an
 // open node updates both copies and, like the reference (:224-230), does NOT restore the heap order.
 AVP_D void pl_heap_set(const PlanWs& w, int32_t pos, PlHeapEnt e) { w.heap[pos] = e; w.nodes[e.node].heap_pos = pos; }
-AVP_D void pl_siftdown(const PlanWs& w, int32_t startpos, int32_t pos)
+// (the item being moved is passed in registers: re-reading a slot this thread has just written would put
+// two global round trips on the serial path of every push / pop)
+AVP_D void pl_siftdown(const PlanWs& w, int32_t startpos, int32_t pos, const PlHeapEnt newitem)
 {
-    const PlHeapEnt newitem = w.heap[pos];
     while (pos > startpos) {
         const int32_t parentpos = (pos - 1) >> 1;
         const PlHeapEnt parent = w.heap[parentpos];
@@ -308,10 +309,9 @@ AVP_D void pl_siftdown(const PlanWs& w, int32_t startpos, int32_t pos)
     }
     pl_heap_set(w, pos, newitem);
 }
-AVP_D void pl_siftup(const PlanWs& w, int32_t pos, int32_t endpos)
+AVP_D void pl_siftup(const PlanWs& w, int32_t pos, int32_t endpos, const PlHeapEnt newitem)
 {
     const int32_t startpos = pos;
-    const PlHeapEnt newitem = w.heap[pos];
     int32_t childpos = 2 * pos + 1;
     while (childpos < endpos) {
         const int32_t rightpos = childpos + 1;
@@ -324,23 +324,20 @@ AVP_D void pl_siftup(const PlanWs& w, int32_t pos, int32_t endpos)
         pos = childpos;
         childpos = 2 * pos + 1;
     }
-    pl_heap_set(w, pos, newitem);
-    pl_siftdown(w, startpos, pos);
+    pl_siftdown(w, startpos, pos, newitem);
 }
-AVP_D void pl_heap_push(const PlanWs& w, PlShared& s, uint32_t node)
+AVP_D void pl_heap_push(const PlanWs& w, PlShared& s, uint32_t node, double f)
 {
-    PlHeapEnt e; e.f = w.nodes[node].f; e.node = node; e.pad = 0;
-    w.heap[s.nheap] = e;
+    PlHeapEnt e; e.f = f; e.node = node; e.pad = 0;
     s.nheap++;
-    pl_siftdown(w, 0, s.nheap - 1);
+    pl_siftdown(w, 0, s.nheap - 1, e);
 }
 AVP_D uint32_t pl_heap_pop(const PlanWs& w, PlShared& s)
 {
     const PlHeapEnt lastelt = w.heap[--s.nheap];
     if (s.nheap) {
         const PlHeapEnt ret = w.heap[0];
-        w.heap[0] = lastelt;
-        pl_siftup(w, 0, s.nheap);
+        pl_siftup(w, 0, s.nheap, lastelt);
         return ret.node;
     }
     return lastelt.node;
@@ -737,6 +734,28 @@ AVP_D void pl_rs_sample_local(const PlanWs& w, PlShared& s, const avp_params& p)
     }
 }
 
+// Sample i of the shot, straight to the world frame (generate_local_course's interpolation :537-624 followed by
+// calc_all_paths' rotation :125-131): the same arithmetic as pl_rs_sample_local + the transform, per sample, so
+// that a wave can produce exactly the samples it is about to check. Also maintains the trim bound s.rs_npts.
+AVP_D void pl_rs_sample_world(const PlanWs& w, PlShared& s, const avp_params& p, const PlNode& cn, double cm, double sm,
+                              int i, double& tx, double& ty, double& tth)
+{
+    double px = 0.0, py = 0.0, pyaw = 0.0;
+    int8_t dr = 0;
+    if (i == 0) dr = s.rs.l[0] > 0.0 ? 1 : -1;
+    else if (i <= s.smp_hi) {
+        const int sg = s.smp_seg[i];
+        const double l = s.smp_l[i];
+        rs_interpolate(l, s.rs.t[sg], p.maxc, s.seg_o[sg][0], s.seg_o[sg][1], s.seg_o[sg][2], px, py, pyaw);
+        dr = l > 0.0 ? 1 : -1;
+    }
+    tx = cm * px + sm * py + cn.x;
+    ty = -sm * px + cm * py + cn.y;
+    tth = avp_pi_2_pi(pyaw + cn.th);
+    w.rsbuf[3 * i] = tx; w.rsbuf[3 * i + 1] = ty; w.rsbuf[3 * i + 2] = tth; w.rsdir[i] = dr;
+    if (px != 0.0) atomicMax(&s.rs_npts, i + 1);
+}
+
 // ---- wave-local cooperative collision pass (distance_checker semantics, collision_check.py:144-240) ----
 // One wave checks up to PL_WPOSE poses without any workgroup barrier: lanes set up the footprints, one
 // lane per (pose, map column under the AABB) gathers the near obstacle points from the column bitmaps into
@@ -914,7 +933,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     if (lane == 0) {
         for (int i = 0; i < nchild; i++) {
             const PlChild& c = s.child[i];
-            if (c.cls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)c.pos);
+            if (c.cls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)c.pos, c.f);
             else if (c.cls == CL_IMPROVE) {
                 PlNode& ch = w.nodes[c.found];
                 ch.f = c.f; ch.g = c.g; ch.h = c.h;
@@ -991,7 +1010,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     nd.x = sx; nd.y = sy; nd.th = avp_pi_2_pi(sth); nd.g = 0; nd.h = 0; nd.f = 0;
                     nd.index = 0; nd.parent_index = -1; nd.parent_pos = -1; nd.forward = 1; nd.steer_i = -1; nd.state = 1;
                     s.nnodes = 1;
-                    pl_heap_push(w, s, 0);
+                    pl_heap_push(w, s, 0, 0.0);
                     pl_hash_put(w, dims.hashCap, 0);
                 }
             }
@@ -1096,6 +1115,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 x = cn.x + td * avp_cos(th);
                 y = cn.y + td * avp_sin(th);
             };
+            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);   // stable until the resolution
             if (in_radius && tid == 0) { s.n_rs += 1; pl_rs_sample_replay(s, p); }
             {
                 // sub-steps: waves 1.. (all waves when there is no shot), PL_WPOSE poses per wave and round
@@ -1116,49 +1136,47 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const long long t_g = clock64();
             if (tid == 0) s.phase[PH_SHOT_SAMPLE] += t_g - t_f0;
             // The outcome of the shot is not an input of the child resolution, so when the resolution can take its
-            // fast path, wave 0 runs it SPECULATIVELY while the other waves check the shot's samples; if the shot
+            // fast path, wave 0 runs it SPECULATIVELY while the other waves sample and check the shot; if the shot
             // then turns out collision free (the search ends at this pop, before expand_node), the counters are
             // rolled back -- the arena / heap / hash side effects touch no node of the final path's parent chain.
-            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
+            // The samples are produced by the wave that checks them (no hand-over through memory, no barrier), in
+            // path order, and a wave stops as soon as a collision is known before its next chunk: the reference
+            // stops at the first colliding sample (:335-345), typically among the first few.
+            if (nsubs > 64) __syncthreads();                    // (the reduction above ran outside wave 0 as well)
             if (in_radius) {
-                pl_rs_sample_local(w, s, p);
-                if (tid == 0) {
-                    s.fast = can_fast ? 1 : 0;
-                    s.snap[0] = s.nnodes; s.snap[1] = s.n_checks; s.snap[2] = s.n_rs; s.snap[3] = s.nclosed; s.snap[4] = s.nheap;
-                }
-                __syncthreads();
-                const int np = s.rs_npts;
+                const int total = s.smp_hi + 1;                 // entries past smp_hi are unset = popped by the trim
                 const int w0 = can_fast ? 1 : 0, nw = nwave - w0;
-                if (can_fast && wave == 0) pl_resolve_fast_wave(m, p, w, s, dims, cn, nchild);
+                if (wave == 0) {
+                    if (lane == 0) {
+                        s.fast = can_fast ? 1 : 0;
+                        s.snap[0] = s.nnodes; s.snap[1] = s.n_checks; s.snap[2] = s.n_rs; s.snap[3] = s.nclosed; s.snap[4] = s.nheap;
+                    }
+                    wave_sync();
+                    if (can_fast) pl_resolve_fast_wave(m, p, w, s, dims, cn, nchild);
+                }
                 if (wave >= w0) {
-                    // world transform (:125-131) fused with the collision pass over the samples (:335-345)
                     const double cm = avp_cos(-cn.th), sm = avp_sin(-cn.th);
-                    const int per = max(1, min(PL_WPOSE, (np + nw - 1) / nw));
-                    for (int base = (wave - w0) * per; base < np; base += nw * per) {
-                        const int cnt = min(per, np - base);
+                    const int per = max(1, min(PL_WPOSE, (total + nw - 1) / nw));
+                    for (int base = (wave - w0) * per; base < total; base += nw * per) {
+                        if (*(volatile int32_t*)&s.rs_first_coll < base) break;
+                        const int cnt = min(per, total - base);
                         double tx = 0.0, ty = 0.0, tth = 0.0;
-                        if (lane < cnt) {
-                            const int g = base + lane;
-                            const double ix = w.rsbuf[3 * g], iy = w.rsbuf[3 * g + 1];
-                            tx = cm * ix + sm * iy + cn.x;
-                            ty = -sm * ix + cm * iy + cn.y;
-                            tth = avp_pi_2_pi(w.rsbuf[3 * g + 2] + cn.th);
-                            w.rsbuf[3 * g] = tx; w.rsbuf[3 * g + 1] = ty; w.rsbuf[3 * g + 2] = tth;
-                        }
+                        if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, base + lane, tx, ty, tth);
                         // lane k holds pose k: broadcast it to whichever lanes ask for it
                         pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th) {
                             x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
                         }, &s.chk_hit[nsubs + base]);
+                        if (lane < cnt && s.chk_hit[nsubs + base + lane]) atomicMin(&s.rs_first_coll, base + lane);
                     }
                 }
                 __syncthreads();
-                for (int g = tid; g < np; g += PL_THREADS) if (s.chk_hit[nsubs + g]) atomicMin(&s.rs_first_coll, g);
-                __syncthreads();
                 if (tid == 0) {
+                    // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
+                    if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
                     if (s.rs_first_coll == 0x7fffffff) {
                         // success: the reference returns before expand_node -- undo the speculative bookkeeping
                         s.nnodes = (int32_t)s.snap[0]; s.n_checks = s.snap[1]; s.n_rs = s.snap[2]; s.nclosed = (int32_t)s.snap[3]; s.nheap = (int32_t)s.snap[4];
-                        s.n_checks += np;
+                        s.n_checks += s.rs_npts;
                         s.done = 1;
                     } else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
                 }
@@ -1222,7 +1240,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = g; nd.h = hval; nd.f = g + hval;
                             nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
                             nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
-                            pl_heap_push(w, s, (uint32_t)pos);
+                            pl_heap_push(w, s, (uint32_t)pos, g + hval);
                             pl_hash_put(w, dims.hashCap, pos);
                         } else {
                             PlNode& ch = w.nodes[c.found];
@@ -1257,6 +1275,14 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         }
         __syncthreads();
         const long long t_fin = clock64();
+        if (s.status == 1 && s.cur >= 0 && s.in_radius && s.rs.n > 0 && s.rs_status == 0 && s.collision) {
+            // the reference hands back the last (colliding) shot when the open list runs empty
+            // (path_planner.py:100-108): the early exit above may have left samples unproduced
+            const PlNode cl = w.nodes[s.cur];
+            const double cm = avp_cos(-cl.th), sm = avp_sin(-cl.th);
+            for (int i = tid; i <= s.smp_hi; i += PL_THREADS) { double a, b, c; pl_rs_sample_world(w, s, p, cl, cm, sm, i, a, b, c); }
+            __syncthreads();
+        }
 
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
         if (tid == 0) {

@@ -30,3 +30,10 @@ for k, n in enumerate(names):
     print(f"  {n:12s} {ph[cap, k].mean() / 1000:10.1f} cyc/pop   one-pop problems total: {ph[one, k].mean():12.0f} cyc")
 print("total cycles capped mean", ph[cap][:, [0,1,2,3,4,5,6,7,9]].sum(axis=1).mean(), " one-pop mean", ph[one][:, [0,1,2,3,4,5,6,7,9]].sum(axis=1).mean())
 print("h_cells one-pop mean", rec["h_cells"][one].mean(), "misses", rec["h_misses"][one].mean())
+mid = (rec["status"] == 0) & (rec["n_pops"] > 1)
+for name, sel in (("capped", cap), ("solved >1 pop", mid)):
+    if sel.any():
+        pops = rec["n_pops"][sel].astype(np.float64)
+        print(f"{name}: n_rs/pop {np.mean(rec['n_rs'][sel] / pops):.2f}  n_checks/pop {np.mean(rec['n_checks'][sel] / pops):.2f}  "
+              f"nodes/pop {np.mean(rec['n_nodes'][sel] / pops):.2f}  closed/pop {np.mean(rec['n_closed'][sel] / pops):.2f}  "
+              f"h_misses/pop {np.mean(rec['h_misses'][sel] / pops):.3f}  mean pops {pops.mean():.0f}")
