@@ -190,6 +190,7 @@ enum { CL_SKIP = 0, CL_NEW_CLOSED = 1, CL_NEW_OPEN = 2, CL_IMPROVE = 3, CL_KEEP 
 struct MapTabs { const double* X; const double* Y; const uint64_t* bits; };
 
 #define PL_WPOSE 8                    // poses per wave per collision pass
+#define PL_WPOSE0 3                   // ... in the first round over the shot's samples
 #define PL_WQCAP 1024                 // (pose, point) candidates per wave
 struct PlWaveChk {
     Footprint fp[PL_WPOSE];
@@ -223,6 +224,7 @@ struct PlShared {
     RsPath rs;                        // normalised winner of the shot
     int64_t n_checks, n_rs;
     int64_t snap[5];                  // counters saved before a speculative resolution
+    uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
     long long phase[10];
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
@@ -1050,7 +1052,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
             const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
             const bool in_radius = distance < p.flag_radius;
-            if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
+            if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; }
             if (tid < nchild) {
                 PlChild& c = s.child[tid];
                 const int si = tid % p.n_steer;
@@ -1156,10 +1158,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 }
                 if (wave >= w0) {
                     const double cm = avp_cos(-cn.th), sm = avp_sin(-cn.th);
-                    const int per = max(1, min(PL_WPOSE, (total + nw - 1) / nw));
-                    for (int base = (wave - w0) * per; base < total; base += nw * per) {
-                        if (*(volatile int32_t*)&s.rs_first_coll < base) break;
-                        const int cnt = min(per, total - base);
+                    auto do_chunk = [&](int base, int cnt) {
                         double tx = 0.0, ty = 0.0, tth = 0.0;
                         if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, base + lane, tx, ty, tth);
                         // lane k holds pose k: broadcast it to whichever lanes ask for it
@@ -1167,6 +1166,30 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
                         }, &s.chk_hit[nsubs + base]);
                         if (lane < cnt && s.chk_hit[nsubs + base + lane]) atomicMin(&s.rs_first_coll, base + lane);
+                    };
+                    // Round 0: PL_WPOSE0 samples per wave. On the bench workload 88 % of the colliding shots hit within
+                    // their first 21 samples (all within 32), which lie next to the node and are cheap; the later
+                    // chunks (towards the goal, next to obstacles: many candidate points) then never run. The
+                    // checking waves meet at a software barrier so that the decision sees every round-0 result.
+                    const int head = min(total, nw * PL_WPOSE0);
+                    {
+                        const int base = (wave - w0) * PL_WPOSE0;
+                        if (base < head) do_chunk(base, min(PL_WPOSE0, head - base));
+                    }
+                    if (head < total) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            atomicAdd(&s.chk_arrived, 1u);
+                            while (*(volatile uint32_t*)&s.chk_arrived < (uint32_t)nw) __builtin_amdgcn_s_sleep(1);
+                        }
+                        wave_sync();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int rest = total - head;
+                        const int per = max(1, min(PL_WPOSE, (rest + nw - 1) / nw));
+                        for (int base = head + (wave - w0) * per; base < total; base += nw * per) {
+                            if (*(volatile int32_t*)&s.rs_first_coll < base) break;
+                            do_chunk(base, min(per, total - base));
+                        }
                     }
                 }
                 __syncthreads();
