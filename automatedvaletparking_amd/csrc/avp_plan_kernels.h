@@ -553,12 +553,12 @@ AVP_D double pl_node_cost(const avp_params& p, int node_forward, double node_the
 // chunk in its own round of its wave: sched[round][wave][lane].
 AVP_D void pl_rs_build_schedule(PlShared& s, int nq)
 {
-    // solvers by descending cost (k-cycles per call measured on MI355X): SLS (two nearly-CR tan), LRL (asin),
-    // LRSL, LRSLR, LRLRn, LRLRp, LSR, LRSR, LSL
-    const int8_t words[9][8] = { { 0, 1, -1, -1, -1, -1, -1, -1 }, { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 },
-                                 { 42, 43, 44, 45, -1, -1, -1, -1 }, { 18, 19, 20, 21, -1, -1, -1, -1 }, { 22, 23, 24, 25, -1, -1, -1, -1 },
-                                 { 6, 7, 8, 9, -1, -1, -1, -1 }, { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 } };
-    const int cost[9] = { 100, 70, 70, 60, 55, 55, 50, 50, 40 };
+    // solvers by descending cost (x100 cycles per call of one wave, scripts/microbench/rs_words.hip on MI355X):
+    // LRLRn, LRLRp (tauOmega: 5 sin/cos + acos + atan2), SLS (two nearly-CR tan), LRL, LRSL, LSR, LRSR, LSL, LRSLR
+    const int8_t words[9][8] = { { 18, 19, 20, 21, -1, -1, -1, -1 }, { 22, 23, 24, 25, -1, -1, -1, -1 }, { 0, 1, -1, -1, -1, -1, -1, -1 },
+                                 { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 }, { 6, 7, 8, 9, -1, -1, -1, -1 },
+                                 { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 }, { 42, 43, 44, 45, -1, -1, -1, -1 } };
+    const int cost[9] = { 106, 85, 78, 60, 60, 59, 45, 43, 30 };
     const int nwave = PL_THREADS / 64;
     int load[PL_THREADS / 64], rounds[PL_THREADS / 64];
     for (int w = 0; w < nwave; w++) { load[w] = 0; rounds[w] = 0; }

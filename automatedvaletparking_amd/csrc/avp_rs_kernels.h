@@ -110,30 +110,27 @@ AVP_D bool rs_LRL(double x, double y, double phi, double sp, double cp, double& 
 // rs_curve.py:213-229
 AVP_D bool rs_SLS(double x, double y, double phi, double& t, double& u, double& v)
 {
+    // rs_curve.py:213-229: the y > 0 and y < 0 branches differ only in the sign of the square root, and each
+    // evaluates tan(phi) once and tan(phi / 2) twice: one evaluation of each serves both (same values).
     phi = avp_M(phi);
-    if (y > 0.0 && 0.0 < phi && phi < AVP_PI * 0.99) {
-        const double xd = -y / avp_tan(phi) + x;
-        t = xd - avp_tan(phi / 2.0);
-        u = phi;
-        v = sqrt((x - xd) * (x - xd) + y * y) - avp_tan(phi / 2.0);
-        return true;
-    } else if (y < 0.0 && 0.0 < phi && phi < AVP_PI * 0.99) {
-        const double xd = -y / avp_tan(phi) + x;
-        t = xd - avp_tan(phi / 2.0);
-        u = phi;
-        v = -sqrt((x - xd) * (x - xd) + y * y) - avp_tan(phi / 2.0);
-        return true;
-    }
-    return false;
+    if (!(0.0 < phi && phi < AVP_PI * 0.99) || !(y > 0.0 || y < 0.0)) return false;
+    const double tan_phi = avp_tan(phi), tan_half = avp_tan(phi / 2.0);
+    const double xd = -y / tan_phi + x;
+    const double r = sqrt((x - xd) * (x - xd) + y * y);
+    t = xd - tan_half;
+    u = phi;
+    v = (y > 0.0 ? r : -r) - tan_half;
+    return true;
 }
 // rs_curve.py:308-323
 AVP_D void rs_tauOmega(double u, double v, double xi, double eta, double phi, double& tau, double& omega)
 {
     const double delta = avp_M(u - v);
+    const double cos_u = avp_cos(u), cos_d = avp_cos(delta);      // each used twice below
     const double A = avp_sin(u) - avp_sin(delta);
-    const double B = avp_cos(u) - avp_cos(delta) - 1.0;
+    const double B = cos_u - cos_d - 1.0;
     const double t1 = avp_atan2(eta * A - xi * B, xi * A + eta * B);
-    const double t2 = 2.0 * (avp_cos(delta) - avp_cos(v) - avp_cos(u)) + 3.0;
+    const double t2 = 2.0 * (cos_d - avp_cos(v) - cos_u) + 3.0;
     tau = t2 < 0 ? avp_M(t1 + AVP_PI) : avp_M(t1);
     omega = avp_M(tau - u + v - phi);
 }
