@@ -146,17 +146,18 @@ def main():
         }
         # secondary: the per-GPU share of north_star's target configuration (4096 poses over 8 GPUs = 512 per GPU):
         # the persistent workgroups keep pulling problems, so a larger batch hides the long searches better
-        big_s = torch.cat([st_t, st_t.flip(0)]).contiguous()
-        big_g = torch.cat([go_t, go_t]).contiguous()
-        bp.plan_dev(big_s, big_g, want_paths=True)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        for _ in range(2):
+        if os.environ.get("AVP_BENCH_SKIP_512") != "1":       # (the PMC passes skip it: per-launch traffic of the 256 batch only)
+            big_s = torch.cat([st_t, st_t.flip(0)]).contiguous()
+            big_g = torch.cat([go_t, go_t]).contiguous()
             bp.plan_dev(big_s, big_g, want_paths=True)
-        torch.cuda.synchronize()
-        tb = (time.perf_counter() - tb) / 2
-        out["batch512"] = {"workload": "512 pairs per GPU on the Case1 map (the 256 starts re-paired with the goals), pop cap 1000",
-                           "plans_per_s": 512 / tb, "ms_per_step": tb * 1e3}
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(2):
+                bp.plan_dev(big_s, big_g, want_paths=True)
+            torch.cuda.synchronize()
+            tb = (time.perf_counter() - tb) / 2
+            out["batch512"] = {"workload": "512 pairs per GPU on the Case1 map (the 256 starts re-paired with the goals), pop cap 1000",
+                               "plans_per_s": 512 / tb, "ms_per_step": tb * 1e3}
         # secondary: the footprint-collision kernel alone (north_star's >= 40 % target), measured live
         n_chk = 1 << 20
         cp = np.stack([rng.uniform(m.boundary[0] + 6, m.boundary[1] - 6, n_chk), rng.uniform(m.boundary[2] + 6, m.boundary[3] - 6, n_chk),
