@@ -225,6 +225,7 @@ struct PlShared {
     int64_t n_checks, n_rs;
     int64_t snap[5];                  // counters saved before a speculative resolution
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
+    int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
     long long phase[10];
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
@@ -606,46 +607,44 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose, bo
         double l[5];
         const int slot = q * 46 + wd;
         s.w_ok[slot] = rs_word(wd, s.frame[q], l) ? 1 : 0;
+        s.w_acc[slot] = 0;
         for (int k = 0; k < 5; k++) s.w_l[slot][k] = l[k];
     }
+    if ((int)threadIdx.x < nq) s.w_err[threadIdx.x] = 0;
     __syncthreads();
 }
 
 // set_path (rs_curve.py:137-156) for all queries at once: one thread per (query, type group); a
 // candidate is only ever compared with kept candidates of the same type sequence, so the groups are
 // independent and the within-group order is the source order.
-AVP_D void pl_rs_accept(PlShared& s, const avp_params& p, int nq)
+// One (query, type group) of set_path (rs_curve.py:137-156): a candidate is only ever compared with kept
+// candidates of the same type sequence, so the groups are independent and the within-group order is the source
+// order. w_acc / w_err were cleared by pl_rs_words.
+AVP_D void pl_rs_accept_group(PlShared& s, const avp_params& p, int q, int g)
 {
-    if ((int)threadIdx.x < nq) s.w_err[threadIdx.x] = 0;
-    for (int t = threadIdx.x; t < nq * 46; t += PL_THREADS) s.w_acc[t] = 0;
-    __syncthreads();
-    for (int t = threadIdx.x; t < nq * 20; t += PL_THREADS) {
-        const int g = t / nq, q = t - g * nq;
-        unsigned accmask = 0;                     // accepted words of this group so far (bit j = RS_GROUPS[g][j])
-        for (int j = 0; j < 4; j++) {
-            const int wd = RS_GROUPS[g][j];
-            if (wd < 0) break;
-            const int slot = q * 46 + wd;
-            if (!s.w_ok[slot]) continue;
-            const int n = RS_WORDS[wd].n;
-            bool dup = false;
-            for (int e = 0; e < j && !dup; e++) {
-                if (!(accmask & (1u << e))) continue;
-                const int eslot = q * 46 + RS_GROUPS[g][e];
-                double sum = 0;
-                for (int i = 0; i < n; i++) sum = sum + (s.w_l[eslot][i] - s.w_l[slot][i]);
-                if (sum <= 0.01) dup = true;
-            }
-            if (dup) continue;
-            double L = 0;
-            for (int i = 0; i < n; i++) L = L + fabs(s.w_l[slot][i]);
-            if (L >= 1000.0) continue;
-            if (!(L >= 0.01)) { s.w_err[q] = 1; continue; }
-            accmask |= 1u << j;
-            s.w_acc[slot] = 1; s.w_Ln[slot] = L; s.w_Lm[slot] = L / p.maxc;
+    unsigned accmask = 0;                     // accepted words of this group so far (bit j = RS_GROUPS[g][j])
+    for (int j = 0; j < 4; j++) {
+        const int wd = RS_GROUPS[g][j];
+        if (wd < 0) break;
+        const int slot = q * 46 + wd;
+        if (!s.w_ok[slot]) continue;
+        const int n = RS_WORDS[wd].n;
+        bool dup = false;
+        for (int e = 0; e < j && !dup; e++) {
+            if (!(accmask & (1u << e))) continue;
+            const int eslot = q * 46 + RS_GROUPS[g][e];
+            double sum = 0;
+            for (int i = 0; i < n; i++) sum = sum + (s.w_l[eslot][i] - s.w_l[slot][i]);
+            if (sum <= 0.01) dup = true;
         }
+        if (dup) continue;
+        double L = 0;
+        for (int i = 0; i < n; i++) L = L + fabs(s.w_l[slot][i]);
+        if (L >= 1000.0) continue;
+        if (!(L >= 0.01)) { s.w_err[q] = 1; continue; }
+        accmask |= 1u << j;
+        s.w_acc[slot] = 1; s.w_Ln[slot] = L; s.w_Lm[slot] = L / p.maxc;
     }
-    __syncthreads();
 }
 
 // arg-min over the accepted words of query q with "<=" (the last of equal minima wins, rs_curve.py:103-108):
@@ -680,7 +679,11 @@ AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
 //   interpolate() call writes; later writes overwrite earlier ones) and chain the segment origins.
 // B (all threads): evaluate the interpolations in the local frame.
 // C (one thread): drop the trailing px == 0.0 entries.  D (all): world transform (fused with the checks).
-AVP_D void pl_rs_sample_replay(PlShared& s, const avp_params& p)
+// generate_local_course (rs_curve.py:537-592) split in two independent serial jobs:
+//   pl_rs_sample_book    -- the index bookkeeping: which sample lies at which arc length of which segment;
+//   pl_rs_sample_origins -- the chain of segment origins (end pose of the previous segment).
+// They touch disjoint state, so two waves run them side by side.
+AVP_D void pl_rs_sample_book(PlShared& s, const avp_params& p)
 {
     const double maxc = p.maxc;
     const RsPath& rp = s.rs;
@@ -692,11 +695,9 @@ AVP_D void pl_rs_sample_replay(PlShared& s, const avp_params& p)
     int ind = 1, hi = 0;
     double d = rp.l[0] > 0.0 ? step : -step;
     double pd = d, ll = 0.0;
-    double ox = 0.0, oy = 0.0, oyaw = 0.0;               // px[1] before any write
     for (int i = 0; i < rp.n; i++) {
         const double l = rp.l[i];
         d = l > 0.0 ? step : -step;
-        s.seg_o[i][0] = ox; s.seg_o[i][1] = oy; s.seg_o[i][2] = oyaw;   // origin = the previous segment's end point
         ind -= 1;
         if (i >= 1 && (rp.l[i - 1] * rp.l[i]) > 0) pd = -d - ll; else pd = d - ll;
         while (fabs(pd) <= fabs(l)) {
@@ -708,13 +709,21 @@ AVP_D void pl_rs_sample_replay(PlShared& s, const avp_params& p)
         ind += 1;
         s.smp_l[ind] = l; s.smp_seg[ind] = (int8_t)i;
         if (ind > hi) hi = ind;
+    }
+    s.smp_hi = hi;
+}
+AVP_D void pl_rs_sample_origins(PlShared& s, const avp_params& p)
+{
+    const RsPath& rp = s.rs;
+    double ox = 0.0, oy = 0.0, oyaw = 0.0;               // px[1] before any write
+    for (int i = 0; i < rp.n; i++) {
+        s.seg_o[i][0] = ox; s.seg_o[i][1] = oy; s.seg_o[i][2] = oyaw;   // origin = the previous segment's end point
         if (i + 1 < rp.n) {
             double ex, ey, eyaw;
-            rs_interpolate(l, rp.t[i], maxc, ox, oy, oyaw, ex, ey, eyaw);
+            rs_interpolate(rp.l[i], rp.t[i], p.maxc, ox, oy, oyaw, ex, ey, eyaw);
             ox = ex; oy = ey; oyaw = eyaw;
         }
     }
-    s.smp_hi = hi;
 }
 AVP_D void pl_rs_sample_local(const PlanWs& w, PlShared& s, const avp_params& p)
 {
@@ -1052,7 +1061,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
             const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
             const bool in_radius = distance < p.flag_radius;
-            if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; }
+            if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 0; }
             if (tid < nchild) {
                 PlChild& c = s.child[tid];
                 const int si = tid % p.n_steer;
@@ -1070,9 +1079,34 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 c.rs_err = 0;
                 c.L = 0;
                 if (one_pass) s.frame[tid + 1] = rs_frame(c.x, c.y, c.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            } else if (one_pass && tid == 64) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            } else if (one_pass && tid == PL_THREADS - 2) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1);
+            // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
+            // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
+            const int wave = tid >> 6, lane = tid & 63;
+            const int nwave = PL_THREADS / 64;
+            const int nsubs = nchild * p.n_sub;
+            {
+                const int nw = nwave - 2;
+                const int per = max(1, min(PL_WPOSE, (nsubs + nw - 1) / nw));      // spread the poses evenly over the waves
+                if (wave >= 1 && wave <= nw) {
+                    for (int base = (wave - 1) * per; base < nsubs; base += nw * per) {
+                        const int cnt = min(per, nsubs - base);
+                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th) {
+                            const int t = base + k;
+                            const int ci = t / p.n_sub, j = t - ci * p.n_sub;
+                            const int si = ci % p.n_steer;
+                            const double td = ci < p.n_steer ? p.travel_ddt[j] : -p.travel_ddt[j];
+                            th = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
+                            x = cn.x + td * avp_cos(th);
+                            y = cn.y + td * avp_sin(th);
+                        }, &s.chk_hit[base]);
+                    }
+                }
+            }
             __syncthreads();
+            for (int t = tid; t < nsubs; t += PL_THREADS)
+                if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
             const long long t_e = clock64();
             if (tid == 0) s.phase[PH_CHILD] += t_e - t_d;
 
@@ -1086,14 +1120,48 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (g == 0) { x = cn.x; y = cn.y; th = cn.th; }
                         else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
                     }, one_pass);
-                    pl_rs_accept(s, p, cnt);
-                    for (int q = tid >> 6; q < cnt; q += PL_THREADS / 64) {
-                        const int g = base + q;
-                        RsPath rp;
-                        const int st = pl_rs_fold_wave(s, q, rp);
-                        if ((tid & 63) == 0) {
-                            if (g == 0) { s.rs_status = in_radius ? st : 0; if (!st) s.rs = rp; }
-                            else { s.child[g - 1].rs_err = (int8_t)st; s.child[g - 1].L = st ? 0.0 : rp.L / p.maxc; }
+                    // set_path and arg-min, a whole query per wave (20 lanes run its type groups, then the wave folds):
+                    // no cross-wave hand-over. Wave 0 owns the shot (query 0 of the first pass) and goes straight on to
+                    // the sampler's index bookkeeping; the last wave, after its children, walks the chain of segment origins as
+                    // soon as wave 0 has published the path -- two serial jobs hidden behind the children's queries.
+                    const int q_first = base == 0 ? 1 : 0;              // first query of this pass that is a child
+                    if (wave == 0) {
+                        if (base == 0) {
+                            if (lane < 20) pl_rs_accept_group(s, p, 0, lane);
+                            wave_sync();
+                            RsPath rp;
+                            const int st = pl_rs_fold_wave(s, 0, rp);
+                            if (lane == 0) {
+                                s.rs_status = in_radius ? st : 0;
+                                const bool shot = in_radius && !st;
+                                if (!st) s.rs = rp;
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                *(volatile int32_t*)&s.shot_ready = shot ? 1 : 2;
+                                if (shot) { s.n_rs += 1; pl_rs_sample_book(s, p); }
+                            }
+                        }
+                    } else {
+                        // up to two queries per wave at a time: lanes 0..19 / 32..51 run the type groups of one each
+                        for (int q = q_first + (wave - 1); q < cnt; q += 2 * (nwave - 1)) {
+                            const int q2 = q + (nwave - 1);
+                            const int half = lane >> 5, gl = lane & 31;
+                            const int qa = half ? q2 : q;
+                            if (gl < 20 && qa < cnt) pl_rs_accept_group(s, p, qa, gl);
+                            wave_sync();
+                            for (int k = 0; k < 2; k++) {
+                                const int qq = k ? q2 : q;
+                                if (qq >= cnt) break;
+                                RsPath rp;
+                                const int st = pl_rs_fold_wave(s, qq, rp);
+                                if (lane == 0) { const int g = base + qq; s.child[g - 1].rs_err = (int8_t)st; s.child[g - 1].L = st ? 0.0 : rp.L / p.maxc; }
+                            }
+                        }
+                        if (wave == nwave - 1 && base == 0) {
+                            if (lane == 0) {
+                                while (*(volatile int32_t*)&s.shot_ready == 0) __builtin_amdgcn_s_sleep(1);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                if (*(volatile int32_t*)&s.shot_ready == 1) pl_rs_sample_origins(s, p);
+                            }
                         }
                     }
                     __syncthreads();
@@ -1101,42 +1169,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             const long long t_f0 = clock64();
             if (tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
-            if (in_radius && s.rs_status) { if (tid == 0) s.status = s.rs_status == 4 ? 5 : 3; __syncthreads(); break; }
-
-            // ---- shot sampling + collision passes -----------------------------------------------------
-            // Thread 0 replays the sampler's index bookkeeping while the other waves already check the
-            // 30 sub-step poses of the children (:185-204), which depend on neither the shot nor the RS words.
-            const int wave = tid >> 6, lane = tid & 63;
-            const int nwave = PL_THREADS / 64;
-            const int nsubs = nchild * p.n_sub;
-            auto substep_pose = [&](int t, double& x, double& y, double& th) {
-                const int ci = t / p.n_sub, j = t - ci * p.n_sub;
-                const int si = ci % p.n_steer;
-                const double td = ci < p.n_steer ? p.travel_ddt[j] : -p.travel_ddt[j];
-                th = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
-                x = cn.x + td * avp_cos(th);
-                y = cn.y + td * avp_sin(th);
-            };
+            if (in_radius && s.rs_status) { if (tid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? 5 : 3; __syncthreads(); break; }
             const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);   // stable until the resolution
-            if (in_radius && tid == 0) { s.n_rs += 1; pl_rs_sample_replay(s, p); }
-            {
-                // sub-steps: waves 1.. (all waves when there is no shot), PL_WPOSE poses per wave and round
-                const int w0 = in_radius ? 1 : 0, nw = nwave - w0;
-                const int per = min(PL_WPOSE, (nsubs + nw - 1) / nw);      // spread the poses evenly over the waves
-                if (wave >= w0) {
-                    for (int base = (wave - w0) * per; base < nsubs; base += nw * per) {
-                        const int cnt = min(per, nsubs - base);
-                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th) { substep_pose(base + k, x, y, th); },
-                                      &s.chk_hit[base]);
-                    }
-                }
-            }
-            __syncthreads();
-            if (in_radius && s.rs_status) { if (tid == 0) s.status = 5; __syncthreads(); break; }
-            for (int t = tid; t < nsubs; t += PL_THREADS)
-                if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
-            const long long t_g = clock64();
-            if (tid == 0) s.phase[PH_SHOT_SAMPLE] += t_g - t_f0;
+            const long long t_g = t_f0;
             // The outcome of the shot is not an input of the child resolution, so when the resolution can take its
             // fast path, wave 0 runs it SPECULATIVELY while the other waves sample and check the shot; if the shot
             // then turns out collision free (the search ends at this pop, before expand_node), the counters are
@@ -1144,7 +1179,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             // The samples are produced by the wave that checks them (no hand-over through memory, no barrier), in
             // path order, and a wave stops as soon as a collision is known before its next chunk: the reference
             // stops at the first colliding sample (:335-345), typically among the first few.
-            if (nsubs > 64) __syncthreads();                    // (the reduction above ran outside wave 0 as well)
             if (in_radius) {
                 const int total = s.smp_hi + 1;                 // entries past smp_hi are unset = popped by the trim
                 const int w0 = can_fast ? 1 : 0, nw = nwave - w0;
