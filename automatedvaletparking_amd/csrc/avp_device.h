@@ -7,7 +7,7 @@
 #include "../../include/avp_libm.h"
 
 // static LDS taken by the trig tables in every kernel that evaluates trig
-#define AVP_LDS_TABLE_BYTES (sizeof(AVP_SINCOS_TAB) + sizeof(AVP_ATAN_TAB))
+#define AVP_LDS_TABLE_BYTES (sizeof(AVP_SINCOS_TAB) + sizeof(AVP_ATAN_TAB) + 1024)   /* + the Reeds-Shepp word tables (avp_rs_kernels.h) */
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Copy the sin/cos and atan tables into LDS; all threads of the workgroup, once, before any trig call.

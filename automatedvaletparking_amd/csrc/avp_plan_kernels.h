@@ -966,6 +966,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                                           double* __restrict__ trace, int32_t max_trace)
 {
     avp_lds_tables_fill<true>();
+    rs_lds_tables_fill();
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
     PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);

@@ -216,7 +216,7 @@ AVP_D bool rs_LRSLR(double x, double y, double phi, double sp, double cp, double
 //           12 (t,-hp,u,-hp,v) 13 (-t,hp,-u,hp,-v)
 struct RsWord { int8_t solver, sx, sy, sphi, back, recipe, n, a, b, c, d, e; };
 #define W_(solver, sx, sy, sp, back, rec, n, a, b, c, d, e) { solver, sx, sy, sp, back, rec, n, a, b, c, d, e }
-static __device__ const RsWord RS_WORDS[46] = {
+static __device__ const RsWord RS_WORDS_G[46] = {
     // SCS :200-210
     W_(0, 1, 1, 1, 0, 0, 3, RS_S, RS_L, RS_S, 0, 0), W_(0, 1, -1, -1, 0, 0, 3, RS_S, RS_R, RS_S, 0, 0),
     // CSC :232-265
@@ -251,12 +251,23 @@ static __device__ const RsWord RS_WORDS[46] = {
 
 // Words grouped by type sequence (set_path only compares candidates of identical ctypes), ascending
 // word index inside a group, -1 padded.
-static __device__ const int8_t RS_GROUPS[20][4] = {
+static __device__ const int8_t RS_GROUPS_G[20][4] = {
     { 0, -1, -1, -1 }, { 1, -1, -1, -1 }, { 2, 3, -1, -1 }, { 4, 5, -1, -1 }, { 6, 7, -1, -1 }, { 8, 9, -1, -1 },
     { 10, 11, 14, 15 }, { 12, 13, 16, 17 }, { 18, 19, 22, 23 }, { 20, 21, 24, 25 },
     { 26, 27, -1, -1 }, { 28, 29, -1, -1 }, { 30, 31, -1, -1 }, { 32, 33, -1, -1 },
     { 34, 35, -1, -1 }, { 36, 37, -1, -1 }, { 38, 39, -1, -1 }, { 40, 41, -1, -1 }, { 42, 43, -1, -1 }, { 44, 45, -1, -1 },
 };
+// Like the trig tables, the word / type-group tables are read through LDS copies (filled by rs_lds_tables_fill): set_path
+// walks them inside dependent loops, where a global read costs several hundred cycles each.
+__shared__ RsWord RS_WORDS[46];
+__shared__ int8_t RS_GROUPS[20][4];
+__device__ __forceinline__ void rs_lds_tables_fill()
+{
+    for (int i = threadIdx.x; i < 46; i += blockDim.x) RS_WORDS[i] = RS_WORDS_G[i];
+    for (int i = threadIdx.x; i < 80; i += blockDim.x) (&RS_GROUPS[0][0])[i] = (&RS_GROUPS_G[0][0])[i];
+    __syncthreads();
+}
+
 
 // Start-frame normalisation of generate_path (rs_curve.py:627-634) + the "backwards" frame
 // (:286-287, :456-457).
@@ -434,6 +445,7 @@ __global__ __launch_bounds__(64) void rs_optimal_kernel(const double* __restrict
                                                         double* __restrict__ xyyaw, int8_t* __restrict__ dir)
 {
     avp_lds_tables_fill<true>();
+    rs_lds_tables_fill();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     RsPath p;

@@ -19,6 +19,7 @@ __device__ long long chain(double& x, F f)
 __global__ void probe(double seed, long long* out, double* sink)
 {
     avp_lds_tables_fill<true>();
+    rs_lds_tables_fill();
     double x = seed + 1e-3 * threadIdx.x;
     int k = 0;
     out[k++] = chain(x, [](double v) { return v * 1.0000001 + 1e-9; });                       // mul+add

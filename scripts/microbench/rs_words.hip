@@ -10,6 +10,7 @@
 __global__ void probe(long long* out, int* okc, double* sink)
 {
     avp_lds_tables_fill<true>();
+    rs_lds_tables_fill();
     const int lane = threadIdx.x;
     // queries like the planner's: goal 2..14 m away, any heading
     const double ang = 0.37 * lane, dist = 2.0 + 0.19 * lane;
