@@ -225,6 +225,7 @@ struct PlShared {
     int64_t n_checks, n_rs;
     int64_t snap[5];                  // counters saved before a speculative resolution
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
+    double k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
     long long phase[10];
     uint32_t hq_d;                    // result of the collective query
@@ -973,6 +974,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
     const int tid = threadIdx.x;
     if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; }
+    if (tid < AVP_MAX_STEER) { s.k_dth_dt[tid] = p.dth_dt[tid]; for (int j = 0; j < 4; j++) s.k_dth_ddt[tid][j] = p.dth_ddt[tid][j]; }
+    if (tid < 4) s.k_travel_ddt[tid] = p.travel_ddt[tid];
     // STAGE: the column bitmaps and node coordinates of the map live in LDS behind PlShared for the whole
     // (persistent) lifetime of the workgroup; otherwise they are read through L1/L2
     MapTabs mt;
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 const int si = tid % p.n_steer;
                 const bool fwd = tid < p.n_steer;       // i < next_index / 2
                 const double travel = fwd ? p.travel_dt : -p.travel_dt;
-                const double th_ = avp_pi_2_pi(cn.th + p.dth_dt[si]);
+                const double th_ = avp_pi_2_pi(cn.th + s.k_dth_dt[si]);
                 c.th = th_;
                 c.x = cn.x + travel * avp_cos(th_);
                 c.y = cn.y + travel * avp_sin(th_);
@@ -1097,8 +1100,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             const int t = base + k;
                             const int ci = t / p.n_sub, j = t - ci * p.n_sub;
                             const int si = ci % p.n_steer;
-                            const double td = ci < p.n_steer ? p.travel_ddt[j] : -p.travel_ddt[j];
-                            th = avp_pi_2_pi(cn.th + p.dth_ddt[si][j]);
+                            const double td = ci < p.n_steer ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
+                            th = avp_pi_2_pi(cn.th + s.k_dth_ddt[si][j]);
                             x = cn.x + td * avp_cos(th);
                             y = cn.y + td * avp_sin(th);
                         }, &s.chk_hit[base]);

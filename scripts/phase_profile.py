@@ -21,13 +21,13 @@ for _ in range(2):
     res, _, _ = bp.plan_dev(st, go)
 torch.cuda.synchronize()
 rec = res.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:256]
-names = ["init", "pop", "shot_rs", "shot_sample", "shot_check", "child", "child_rs", "resolve", "(sweep)", "finish"]
+names = ["init", "pop", "(unused)", "(unused)", "resolve||shot", "children||substeps", "rs_words..replay", "slow_resolve", "(sweep)", "finish"]
 ph = rec["phase_cycles"].astype(np.float64)
 cap = rec["status"] == 4
 one = rec["n_pops"] == 1
 print("capped problems:", int(cap.sum()), " mean cycles per pop by phase:")
 for k, n in enumerate(names):
-    print(f"  {n:12s} {ph[cap, k].mean() / 1000:10.1f} cyc/pop   one-pop problems total: {ph[one, k].mean():12.0f} cyc")
+    print(f"  {n:18s} {ph[cap, k].mean() / 1000:10.1f} cyc/pop   one-pop problems total: {ph[one, k].mean():12.0f} cyc")
 print("total cycles capped mean", ph[cap][:, [0,1,2,3,4,5,6,7,9]].sum(axis=1).mean(), " one-pop mean", ph[one][:, [0,1,2,3,4,5,6,7,9]].sum(axis=1).mean())
 print("h_cells one-pop mean", rec["h_cells"][one].mean(), "misses", rec["h_misses"][one].mean())
 mid = (rec["status"] == 0) & (rec["n_pops"] > 1)
