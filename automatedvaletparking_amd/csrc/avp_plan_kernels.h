@@ -35,8 +35,9 @@
 #define PL_UNSEEN 0x7fffffffu
 #define PL_TRACE_W 11
 #define PL_FLAG_T 1
-// phase timers (thread 0, s_memtime): init, heap pop, shot words+fold, shot sampling, shot checks,
-// children poses + sub-step checks, children RS, sequential resolution, of which sweep, finish
+// phase timers (thread 0, s_memtime): init, heap pop, (two unused slots), speculative resolution || shot sampling
+// and checks, children stage || sub-step checks, RS words .. set_path / arg-min || sampler replay, the rest of the
+// resolution (fast path when not speculated, slow path), of which sweep extensions, finish
 enum { PH_INIT = 0, PH_POP, PH_SHOT_RS, PH_SHOT_SAMPLE, PH_SHOT_CHECK, PH_CHILD, PH_CHILD_RS, PH_RESOLVE, PH_SWEEP, PH_FINISH };
 #define PH_T0() const long long ph_t0_ = clock64()
 #define PH_ADD(k) do { if (threadIdx.x == 0) s.phase[k] += clock64() - ph_t0_; } while (0)
