@@ -148,6 +148,17 @@ AVP_HD int avp_last_lt(const double* A, int n, double a0, double pitch, double v
     return i;
 }
 
+// first_ge (upper = false) / last_le (upper = true) as ONE instruction stream, so that lanes searching different
+// bounds of different axes do not diverge (same results as avp_first_ge / avp_last_le for finite v)
+AVP_HD int avp_node_search(const double* A, int n, double a0, double pitch, double v, bool upper)
+{
+    const double g = floor((v - a0) / pitch) + (upper ? 1.0 : 0.0);
+    int c = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);          // estimate of #{A[i] < v} resp. #{A[i] <= v}
+    while (c > 0 && (upper ? A[c - 1] > v : A[c - 1] >= v)) --c;
+    while (c < n && (upper ? A[c] <= v : A[c] < v)) ++c;
+    return upper ? c - 1 : c;
+}
+
 // map/costmap.py:319-329
 AVP_HD int64_t avp_pos_to_index(const DevMap& m, double gx, double gy)
 {

@@ -781,7 +781,7 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
     PlWaveChk& wc = s.wchk[threadIdx.x >> 6];
     if (count <= 0) return;
     if (p.checker_kind == 1) {
-        if (lane < count) { double x, y, th; pose(lane, x, y, th); out_hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
+        if (lane < count) { double x, y, th, cs, sn; pose(lane, x, y, th, cs, sn); out_hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
         wave_sync();
         return;
     }
@@ -793,9 +793,8 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
     {
         const int grp = lane >> 3, sub = lane & 7;
         if (grp < count) {
-            double x, y, th;
-            pose(grp, x, y, th);
-            const double cs = avp_cos(th), sn = avp_sin(th);
+            double x, y, th, cs, sn;
+            pose(grp, x, y, th, cs, sn);                  // cs, sn = cos / sin of th (the pose's own, not recomputed)
             const double lx[4] = { p.fp_xr, p.fp_xf, p.fp_xf, p.fp_xr };
             const double ly[4] = { p.fp_yr, p.fp_yr, p.fp_yl, p.fp_yl };
             double cx[4], cy[4];
@@ -805,23 +804,22 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
                 cy[i] = AVP_FMA(cs, ly[i], sn * lx[i]) + y;
             }
             Footprint& f = wc.fp[grp];
-            if (sub < 4) {
-                // edge sub: corner sub -> corner (sub + 1) & 3
-                const double x1 = sub == 0 ? cx[0] : sub == 1 ? cx[1] : sub == 2 ? cx[2] : cx[3];
+            if (sub < 6) {
+                // sub 0..3: edge sub (corner sub -> corner (sub + 1) & 3): slope, intercept, norm sqrt(1 + k*k);
+                // sub 4: |rr - lr| (width), sub 5: |lr - lf| (length). One sqrt(u*u + v*v) serves all six lanes
+                // (1*1 is exact, so sqrt(1 + k*k) is the same expression).
+                const double x1 = sub == 0 ? cx[0] : sub == 1 ? cx[1] : sub == 2 ? cx[2] : cx[3];     // sub 4, 5: corner lr
                 const double y1 = sub == 0 ? cy[0] : sub == 1 ? cy[1] : sub == 2 ? cy[2] : cy[3];
                 const double x2 = sub == 0 ? cx[1] : sub == 1 ? cx[2] : sub == 2 ? cx[3] : cx[0];
                 const double y2 = sub == 0 ? cy[1] : sub == 1 ? cy[2] : sub == 2 ? cy[3] : cy[0];
-                const double k = (y2 - y1) / (x2 - x1);          // +-inf / NaN when axis aligned, as numpy
-                f.cx[sub] = x1; f.cy[sub] = y1;
-                f.k[sub] = k;
-                f.b[sub] = y1 - k * x1;
-                f.den[sub] = sqrt(1 + k * k);
-            } else if (sub < 6) {
-                // sub 4: |rr - lr| (width), sub 5: |lr - lf| (length)
-                const double t0 = sub == 4 ? cx[0] - cx[3] : cx[3] - cx[2];
-                const double t1 = sub == 4 ? cy[0] - cy[3] : cy[3] - cy[2];
-                const double thr = sqrt(t0 * t0 + t1 * t1) - 0.01;
-                if (sub == 4) f.wthr = thr; else f.lthr = thr;
+                double u = 1.0, v = 0.0, k = 0.0;
+                if (sub < 4) { k = (y2 - y1) / (x2 - x1); v = k; }            // +-inf / NaN when axis aligned, as numpy
+                else if (sub == 4) { u = cx[0] - cx[3]; v = cy[0] - cy[3]; }
+                else { u = cx[3] - cx[2]; v = cy[3] - cy[2]; }
+                const double r = sqrt(u * u + v * v);
+                if (sub < 4) { f.cx[sub] = x1; f.cy[sub] = y1; f.k[sub] = k; f.b[sub] = y1 - k * x1; f.den[sub] = r; }
+                else if (sub == 4) f.wthr = r - 0.01;
+                else f.lthr = r - 0.01;
             }
             double xmin = cx[0], xmax = cx[0], ymin = cy[0], ymax = cy[0];
 #pragma unroll
@@ -831,12 +829,11 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
                 if (cy[i] > ymax) ymax = cy[i];
                 if (cy[i] < ymin) ymin = cy[i];
             }
-            if (sub == 0 || sub == 2) {          // first node >= lower bound: x (sub 0), y (sub 2)
-                const bool ax = sub == 0;
-                wc.rng[grp][sub] = (int16_t)avp_first_ge(ax ? mt.X : mt.Y, ax ? m.nx : m.ny, ax ? m.b0 : m.b2, ax ? m.dx : m.dy, ax ? xmin : ymin);
-            } else if (sub == 1 || sub == 3) {   // last node <= upper bound: x (sub 1), y (sub 3)
-                const bool ax = sub == 1;
-                wc.rng[grp][sub] = (int16_t)avp_last_le(ax ? mt.X : mt.Y, ax ? m.nx : m.ny, ax ? m.b0 : m.b2, ax ? m.dx : m.dy, ax ? xmax : ymax);
+            if (sub < 4) {
+                // ixlo = first node >= xmin, ixhi = last node <= xmax, iylo, iyhi likewise: one code path for the four
+                const bool ax = sub < 2, upper = sub & 1;
+                wc.rng[grp][sub] = (int16_t)avp_node_search(ax ? mt.X : mt.Y, ax ? m.nx : m.ny, ax ? m.b0 : m.b2, ax ? m.dx : m.dy,
+                                                            ax ? (upper ? xmax : xmin) : (upper ? ymax : ymin), upper);
             }
             if (sub == 7) wc.hit[grp] = 0;
         }
@@ -862,7 +859,7 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
     wave_sync();
     if (wc.over) {
         // more candidates than the queue holds (dense clutter): every lane checks its own pose serially
-        if (lane < count) { double x, y, th; pose(lane, x, y, th); wc.hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
+        if (lane < count) { double x, y, th, cs, sn; pose(lane, x, y, th, cs, sn); wc.hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
     } else {
         const int qn = wc.qn;
         for (int e = lane; e < qn; e += 64) {
@@ -1097,14 +1094,15 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (wave >= 1 && wave <= nw) {
                     for (int base = (wave - 1) * per; base < nsubs; base += nw * per) {
                         const int cnt = min(per, nsubs - base);
-                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th) {
+                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             const int t = base + k;
                             const int ci = t / p.n_sub, j = t - ci * p.n_sub;
                             const int si = ci % p.n_steer;
                             const double td = ci < p.n_steer ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
                             th = avp_pi_2_pi(cn.th + s.k_dth_ddt[si][j]);
-                            x = cn.x + td * avp_cos(th);
-                            y = cn.y + td * avp_sin(th);
+                            cs = avp_cos(th); sn = avp_sin(th);
+                            x = cn.x + td * cs;
+                            y = cn.y + td * sn;
                         }, &s.chk_hit[base]);
                     }
                 }
@@ -1201,8 +1199,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         double tx = 0.0, ty = 0.0, tth = 0.0;
                         if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, base + lane, tx, ty, tth);
                         // lane k holds pose k: broadcast it to whichever lanes ask for it
-                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th) {
+                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
+                            cs = avp_cos(th); sn = avp_sin(th);
                         }, &s.chk_hit[nsubs + base]);
                         if (lane < cnt && s.chk_hit[nsubs + base + lane]) atomicMin(&s.rs_first_coll, base + lane);
                     };
