@@ -382,10 +382,11 @@ AVP_D void rs_interpolate(double l, int m, double maxc, double ox, double oy, do
         py = oy + l / maxc * avp_sin(oyaw);
         pyaw = oyaw;
     } else {
+        const double cl = avp_cos(l), co = avp_cos(-oyaw), so = avp_sin(-oyaw);      // each used twice (:605-612)
         const double ldx = avp_sin(l) / maxc;
-        const double ldy = (m == RS_L) ? (1.0 - avp_cos(l)) / maxc : (1.0 - avp_cos(l)) / (-maxc);
-        const double gdx = avp_cos(-oyaw) * ldx + avp_sin(-oyaw) * ldy;
-        const double gdy = -avp_sin(-oyaw) * ldx + avp_cos(-oyaw) * ldy;
+        const double ldy = (m == RS_L) ? (1.0 - cl) / maxc : (1.0 - cl) / (-maxc);
+        const double gdx = co * ldx + so * ldy;
+        const double gdy = -so * ldx + co * ldy;
         px = ox + gdx;
         py = oy + gdy;
         pyaw = (m == RS_L) ? oyaw + l : oyaw - l;
