@@ -288,7 +288,14 @@ __global__ void trig_kernel(const double* __restrict__ x, int64_t n, double* __r
 {
     avp_lds_tables_fill<false>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { s[i] = avp_sin(x[i]); c[i] = avp_cos(x[i]); }
+    if (i < n) {
+        // both evaluations; a fused result that differs in any bit poisons the output, so the parity test sees it
+        const double sv = avp_sin(x[i]), cv = avp_cos(x[i]);
+        double sf, cf;
+        avp_sincos(x[i], sf, cf);
+        const bool same = avp_d2u(sv) == avp_d2u(sf) && avp_d2u(cv) == avp_d2u(cf);
+        s[i] = same ? sv : NAN; c[i] = same ? cv : NAN;
+    }
 }
 __global__ void ieee_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ q,
                             double* __restrict__ r, double* __restrict__ h)

@@ -54,7 +54,8 @@ struct Footprint {
 // reference's BLAS call rounds it: acc = a0*b0; acc = fma(a1, b1, acc)  (numerics).
 AVP_HD void avp_footprint_setup(const avp_params& p, double x, double y, double th, Footprint& f)
 {
-    const double cs = avp_cos(th), sn = avp_sin(th);
+    double cs, sn;
+    avp_sincos(th, sn, cs);
     const double lx[4] = { p.fp_xr, p.fp_xf, p.fp_xf, p.fp_xr };
     const double ly[4] = { p.fp_yr, p.fp_yr, p.fp_yl, p.fp_yl };
 #pragma unroll

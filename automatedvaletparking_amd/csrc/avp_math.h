@@ -159,6 +159,36 @@ AVP_HD double avp_cos(double x)
     return NAN;
 }
 
+// sin and cos of the same argument, the values of avp_sin(x) and avp_cos(x) bit for bit: one range dispatch, one
+// pi/2 reduction, and in a wave whose lanes fall into different ranges each range body runs once for both results.
+AVP_HD void avp_sincos(double x, double& sn, double& cs)
+{
+    using namespace avp_trig;
+    const int32_t k = 0x7fffffff & (int32_t)(avp_d2u(x) >> 32);
+    if (k < 0x3e500000) { sn = x; cs = (k < 0x3e400000) ? 1.0 : do_cos(x, 0); return; }
+    if (k < 0x3feb6000) { sn = do_sin(x, 0); cs = do_cos(x, 0); return; }
+    if (k < 0x400368fd) {
+        const double t = hp0 - fabs(x);
+        sn = copysign(do_cos(t, hp1), x);
+        const double a = t + hp1;
+        const double da = (t - a) + hp1;
+        cs = do_sin(a, da);
+        return;
+    }
+    if (k < 0x419921FB) {
+        double a, da;
+        const int n = reduce_sincos(x, &a, &da);
+        const double S = do_sin(a, da), C = do_cos(a, da);          // do_sincos(a, da, m) = (m & 1 ? C : S), negated when m & 2
+        const double rs = (n & 1) ? C : S;
+        sn = (n & 2) ? -rs : rs;
+        const int m = n + 1;
+        const double rc = (m & 1) ? C : S;
+        cs = (m & 2) ? -rc : rc;
+        return;
+    }
+    sn = NAN; cs = NAN;
+}
+
 // ---- Python float semantics ------------------------------------------------------------------
 // CPython float %: result takes the sign of the divisor (Objects/floatobject.c float_rem)
 AVP_HD double avp_pymod(double vx, double wx)

@@ -121,7 +121,8 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 __device__ __noinline__ bool pl_check_pose(const DevMap& m, const avp_params& p, double x, double y, double th)
 {
     if (p.checker_kind == 1) {
-        const double cs = avp_cos(th), sn = avp_sin(th);
+        double cs, sn;
+        avp_sincos(th, sn, cs);
         const double Rd = p.circ_rd;
         const double fx = x + p.circ_cf * cs, fy = y + p.circ_cf * sn;
         const double rx = x + p.circ_cr * cs, ry = y + p.circ_cr * sn;
@@ -1071,8 +1072,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 const double travel = fwd ? p.travel_dt : -p.travel_dt;
                 const double th_ = avp_pi_2_pi(cn.th + s.k_dth_dt[si]);
                 c.th = th_;
-                c.x = cn.x + travel * avp_cos(th_);
-                c.y = cn.y + travel * avp_sin(th_);
+                double sth, cth;
+                avp_sincos(th_, sth, cth);
+                c.x = cn.x + travel * cth;
+                c.y = cn.y + travel * sth;
                 c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
                 c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
                 c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
@@ -1100,7 +1103,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             const int si = ci % p.n_steer;
                             const double td = ci < p.n_steer ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
                             th = avp_pi_2_pi(cn.th + s.k_dth_ddt[si][j]);
-                            cs = avp_cos(th); sn = avp_sin(th);
+                            avp_sincos(th, sn, cs);
                             x = cn.x + td * cs;
                             y = cn.y + td * sn;
                         }, &s.chk_hit[base]);
@@ -1194,14 +1197,15 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     if (can_fast) pl_resolve_fast_wave(m, p, w, s, dims, cn, nchild);
                 }
                 if (wave >= w0) {
-                    const double cm = avp_cos(-cn.th), sm = avp_sin(-cn.th);
+                    double cm, sm;
+                    avp_sincos(-cn.th, sm, cm);
                     auto do_chunk = [&](int base, int cnt) {
                         double tx = 0.0, ty = 0.0, tth = 0.0;
                         if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, base + lane, tx, ty, tth);
                         // lane k holds pose k: broadcast it to whichever lanes ask for it
                         pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
-                            cs = avp_cos(th); sn = avp_sin(th);
+                            avp_sincos(th, sn, cs);
                         }, &s.chk_hit[nsubs + base]);
                         if (lane < cnt && s.chk_hit[nsubs + base + lane]) atomicMin(&s.rs_first_coll, base + lane);
                     };
@@ -1340,7 +1344,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             // the reference hands back the last (colliding) shot when the open list runs empty
             // (path_planner.py:100-108): the early exit above may have left samples unproduced
             const PlNode cl = w.nodes[s.cur];
-            const double cm = avp_cos(-cl.th), sm = avp_sin(-cl.th);
+            double cm, sm;
+            avp_sincos(-cl.th, sm, cm);
             for (int i = tid; i <= s.smp_hi; i += PL_THREADS) { double a, b, c; pl_rs_sample_world(w, s, p, cl, cm, sm, i, a, b, c); }
             __syncthreads();
         }

@@ -126,8 +126,10 @@ AVP_D bool rs_SLS(double x, double y, double phi, double& t, double& u, double& 
 AVP_D void rs_tauOmega(double u, double v, double xi, double eta, double phi, double& tau, double& omega)
 {
     const double delta = avp_M(u - v);
-    const double cos_u = avp_cos(u), cos_d = avp_cos(delta);      // each used twice below
-    const double A = avp_sin(u) - avp_sin(delta);
+    double sin_u, cos_u, sin_d, cos_d;                            // each cosine is used twice below
+    avp_sincos(u, sin_u, cos_u);
+    avp_sincos(delta, sin_d, cos_d);
+    const double A = sin_u - sin_d;
     const double B = cos_u - cos_d - 1.0;
     const double t1 = avp_atan2(eta * A - xi * B, xi * A + eta * B);
     const double t2 = 2.0 * (cos_d - avp_cos(v) - cos_u) + 3.0;
@@ -277,11 +279,12 @@ AVP_D RsFrame rs_frame(double q0x, double q0y, double q0t, double q1x, double q1
     RsFrame f;
     const double dx = q1x - q0x, dy = q1y - q0y;
     f.phi0 = q1t - q0t;
-    const double c = avp_cos(q0t), s = avp_sin(q0t);
+    double c, s;
+    avp_sincos(q0t, s, c);
     f.x0 = (c * dx + s * dy) * maxc;
     f.y0 = (-s * dx + c * dy) * maxc;
-    f.sphi = avp_sin(f.phi0);          // sin is odd and cos even bit for bit, so the mirrored / time-flipped
-    f.cphi = avp_cos(f.phi0);          // words (phi -> -phi) reuse these two values
+    avp_sincos(f.phi0, f.sphi, f.cphi);   // sin is odd and cos even bit for bit, so the mirrored / time-flipped
+                                          // words (phi -> -phi) reuse these two values
     f.xb = f.x0 * f.cphi + f.y0 * f.sphi;
     f.yb = f.x0 * f.sphi - f.y0 * f.cphi;
     return f;
@@ -378,12 +381,16 @@ AVP_D int rs_optimal(double q0x, double q0y, double q0t, double q1x, double q1y,
 AVP_D void rs_interpolate(double l, int m, double maxc, double ox, double oy, double oyaw, double& px, double& py, double& pyaw)
 {
     if (m == RS_S) {
-        px = ox + l / maxc * avp_cos(oyaw);
-        py = oy + l / maxc * avp_sin(oyaw);
+        double so, co;
+        avp_sincos(oyaw, so, co);
+        px = ox + l / maxc * co;
+        py = oy + l / maxc * so;
         pyaw = oyaw;
     } else {
-        const double cl = avp_cos(l), co = avp_cos(-oyaw), so = avp_sin(-oyaw);      // each used twice (:605-612)
-        const double ldx = avp_sin(l) / maxc;
+        double sl, cl, so, co;                                                       // each used twice (:605-612)
+        avp_sincos(l, sl, cl);
+        avp_sincos(-oyaw, so, co);
+        const double ldx = sl / maxc;
         const double ldy = (m == RS_L) ? (1.0 - cl) / maxc : (1.0 - cl) / (-maxc);
         const double gdx = co * ldx + so * ldy;
         const double gdy = -so * ldx + co * ldy;
@@ -428,7 +435,8 @@ __device__ __noinline__ int rs_sample(const RsPath& p, double maxc, double q0x, 
     }
     int np = point_num;
     while (np > 0 && xyyaw[(np - 1) * stride] == 0.0) np--;
-    const double cm = avp_cos(-q0t), sm = avp_sin(-q0t);
+    double cm, sm;
+    avp_sincos(-q0t, sm, cm);
     for (int i = 0; i < np; i++) {
         const double ix = xyyaw[i * stride], iy = xyyaw[i * stride + 1];
         xyyaw[i * stride] = cm * ix + sm * iy + q0x;

@@ -35,6 +35,21 @@ def test_sincos_bit_equal_glibc():
     assert np.array_equal(_sincos(sub)[1], np.array([math.cos(v) for v in sub]))
 
 
+def test_fused_sincos_equals_separate_bit_for_bit():
+    """avp_sincos (what the kernels call) == (avp_sin, avp_cos) on every range: tiny, table, pi/2 - x, reduced, huge."""
+    L = _lib()
+    rng = np.random.default_rng(321)
+    xs = np.concatenate([rng.uniform(-np.pi, np.pi, 1_000_000), rng.uniform(-30, 30, 300_000), rng.uniform(-1e8, 1.2e8, 200_000),
+                         rng.uniform(-1e-7, 1e-7, 50_000), 10.0 ** rng.uniform(-320, 9, 100_000) * rng.choice([-1, 1], 100_000),
+                         np.array([0.0, -0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, 0.855469, 0.85546875, 2.426265, 2.4262657, 0.126,
+                                   1e-300, 105414350.0, 105414357.0, 2e8, np.inf, -np.inf, np.nan])])
+    s0, c0 = _sincos(xs)
+    s1 = np.empty_like(xs)
+    c1 = np.empty_like(xs)
+    L.avp_host_sincos_fused(xs.ctypes.data_as(C.c_void_p), C.c_long(len(xs)), s1.ctypes.data_as(C.c_void_p), c1.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64)) and np.array_equal(c0.view(np.uint64), c1.view(np.uint64))
+
+
 def test_hypot_mod_wraps_match_cpython():
     L = _lib()
     rng = np.random.default_rng(5)
