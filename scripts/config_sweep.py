@@ -1,0 +1,137 @@
+"""BASELINE.json configs 3-5 at full size on one GPU: throughput + parity against the CPU oracle (portable libm).
+
+    python scripts/config_sweep.py [--pairs 128] [--cap 300] [--threads 64] > profiles/rNN_config_sweep.jsonl
+
+C3: all 20 BenchmarkCases x `pairs` random start/goal pairs (seed 20260927 + k), pop cap `cap`;
+C4: synthetic 200 x 200 grid, 32 convex polygons, 4096 poses -> check_batch (both checkers) + 256 plans;
+C5: parking lot (2 x 60 cars, one empty bay), 1024 starts in the aisle, flag_radius 1e9 (RS shot at every pop).
+Each problem's status, pop count, counters, pop trace (grid ids + poses, bit for bit) and final path are compared
+with the oracle's; the oracle runs one problem per host thread. One JSON line per config."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from automatedvaletparking_amd import _native, config, costmap, path_planner, sampling  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def same(r, w, cap):
+    if r.status != w["status"] or r.n_pops != w["n_pops"]:
+        return False
+    t, wt = r.trace, w["trace"]
+    if not np.array_equal(t[:, :10], wt[:len(t), :10]):
+        return False
+    c = r.counters
+    if any(c[k] != w[k] for k in ("n_closed", "n_open", "global_index", "n_rs", "n_checks")):
+        return False
+    if r.status == 0 and not np.array_equal(np.asarray(r.final_path), np.asarray(w["final_path"])):
+        return False
+    return True
+
+
+def free_pairs(m, dm, n_pairs, rng):
+    free = []
+    while len(free) < 2 * n_pairs:
+        cand = sampling.sample_free_poses(m.boundary, m.case.obs, 8 * n_pairs, rng, margin=6.0, reject=False)
+        hit = dm.check_batch(cand)
+        free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
+    poses = np.array(free[:2 * n_pairs])
+    return poses[0::2], poses[1::2]
+
+
+def plan_and_compare(m, veh, cfg, starts, goals, cap, threads, max_nodes=8192):
+    dm = _native.DeviceMap(m, veh, cfg, max_pops=cap)
+    bp = path_planner.BatchPlanner(dm, max_nodes=max_nodes)
+    bp.plan(starts[:8], goals[:8], max_trace=cap)                       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = bp.plan(starts, goals, max_trace=cap)
+    torch.cuda.synchronize()
+    t_gpu = time.perf_counter() - t0
+    o = oracle.Oracle(m, veh, cfg, max_pops=cap)
+    t1 = time.perf_counter()
+    with oracle.portable_libm():
+        with ThreadPoolExecutor(threads) as ex:
+            ws = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=cap), zip(starts, goals)))
+    t_cpu = time.perf_counter() - t1
+    ok = sum(same(r, w, cap) for r, w in zip(res, ws))
+    return res, ok, t_gpu, t_cpu
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=128)
+    ap.add_argument("--cap", type=int, default=300)
+    ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 1))
+    a = ap.parse_args()
+    cfg = config.default_config()
+    veh = costmap.Vehicle()
+    # ---- C3 -------------------------------------------------------------------------------------
+    tot = dict(problems=0, identical=0, solved=0, capped=0, pops=0, t_gpu=0.0, t_cpu=0.0)
+    per_map = []
+    for k in range(1, 21):
+        m = costmap.Map(file=os.path.join(ROOT, "data", "BenchmarkCases", f"Case{k}.csv"), discrete_size=cfg["map_discrete_size"], device="cuda")
+        dm = _native.DeviceMap(m, veh, cfg, max_pops=a.cap)
+        st, go = free_pairs(m, dm, a.pairs, np.random.default_rng(20260927 + k))
+        res, ok, tg, tc = plan_and_compare(m, veh, cfg, st, go, a.cap, a.threads)
+        per_map.append(dict(case=k, identical=ok, problems=len(res), gpu_s=round(tg, 4)))
+        tot["problems"] += len(res); tot["identical"] += ok; tot["t_gpu"] += tg; tot["t_cpu"] += tc
+        tot["solved"] += sum(r.status == 0 for r in res); tot["capped"] += sum(r.status == 4 for r in res)
+        tot["pops"] += sum(r.n_pops for r in res)
+    print(json.dumps(dict(config="C3: 20 BenchmarkCases x %d random pairs, pop cap %d, 1 GPU (incl. trace + path read-back)" % (a.pairs, a.cap),
+                          problems=tot["problems"], identical_to_oracle=tot["identical"], solved=tot["solved"], capped=tot["capped"],
+                          plans_per_s=tot["problems"] / tot["t_gpu"], expansions_per_s=tot["pops"] / tot["t_gpu"],
+                          oracle_plans_per_s=tot["problems"] / tot["t_cpu"], oracle_threads=a.threads, per_map=per_map)))
+    sys.stdout.flush()
+    # ---- C4 -------------------------------------------------------------------------------------
+    with tempfile.TemporaryDirectory() as td:
+        polys = sampling.synthetic_polygon_map(seed=4)
+        p = os.path.join(td, "c4.csv")
+        sampling.write_tpcap_csv(p, (12.0, 12.0, 0.0), (12.0, 12.0, 0.5), polys)
+        m = costmap.Map(file=p, discrete_size=0.12, device="cuda")
+        dm = _native.DeviceMap(m, veh, cfg, max_pops=a.cap)
+        o = oracle.Oracle(m, veh, cfg, max_pops=a.cap)
+        rng = np.random.default_rng(4)
+        poses = np.stack([rng.uniform(m.boundary[0] + 3, m.boundary[1] - 3, 4096), rng.uniform(m.boundary[2] + 3, m.boundary[3] - 3, 4096),
+                          rng.uniform(-np.pi, np.pi, 4096)], 1)
+        out = {}
+        for kind, name in ((0, "distance"), (1, "circle")):
+            g = np.asarray(dm.check_batch(poses, kind=kind)).astype(bool)
+            w = np.asarray(o.check_batch(poses, kind=kind)).astype(bool)
+            out[name + "_identical"] = int((g == w).sum())
+            out[name + "_colliding"] = int(g.sum())
+        st, go = free_pairs(m, dm, 256, rng)
+        res, ok, tg, tc = plan_and_compare(m, veh, cfg, st, go, a.cap, a.threads)
+        print(json.dumps(dict(config="C4: synthetic %dx%d grid, %d polygons (P=%d points), 4096-pose check batch + 256 plans" %
+                              (m.cost_map.shape[0], m.cost_map.shape[1], len(polys), len(m.pack()["obs_ix"])), poses=4096, **out,
+                              plan_problems=len(res), plan_identical_to_oracle=ok, plans_per_s=len(res) / tg,
+                              solved=sum(r.status == 0 for r in res))))
+        sys.stdout.flush()
+        # ---- C5 ---------------------------------------------------------------------------------
+        obs, goal, aisle = sampling.parking_lot_map()
+        p = os.path.join(td, "c5.csv")
+        sampling.write_tpcap_csv(p, (aisle[0] + 8.0, 0.5 * (aisle[2] + aisle[3]), 0.0), goal, obs)
+        c5 = dict(cfg); c5["flag_radius"] = 1e9
+        m = costmap.Map(file=p, discrete_size=cfg["map_discrete_size"], device="cuda")
+        rng = np.random.default_rng(5)
+        starts = np.stack([rng.uniform(m.boundary[0] + 4, m.boundary[1] - 4, 1024), rng.uniform(aisle[2] + 1.2, aisle[3] - 1.2, 1024),
+                           rng.choice([0.0, np.pi], 1024) + rng.normal(0, 0.05, 1024)], 1)
+        goals = np.tile(np.array(goal), (1024, 1))
+        res, ok, tg, tc = plan_and_compare(m, veh, c5, starts, goals, a.cap, a.threads, max_nodes=8192)
+        print(json.dumps(dict(config="C5: parking lot %dx%d grid, %d obstacles (P=%d), 1024 starts in the aisle, RS shot at every pop, pop cap %d" %
+                              (m.cost_map.shape[0], m.cost_map.shape[1], len(obs), len(m.pack()["obs_ix"]), a.cap), problems=len(res),
+                              identical_to_oracle=ok, solved=sum(r.status == 0 for r in res), capped=sum(r.status == 4 for r in res),
+                              plans_per_s=len(res) / tg, expansions_per_s=sum(r.n_pops for r in res) / tg, oracle_plans_per_s=len(res) / tc)))
+
+
+if __name__ == "__main__":
+    main()
