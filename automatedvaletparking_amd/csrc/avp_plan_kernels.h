@@ -228,6 +228,7 @@ struct PlShared {
     int64_t snap[5];                  // counters saved before a speculative resolution
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
     double k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
+    int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
     long long phase[10];
     uint32_t hq_d;                    // result of the collective query
@@ -975,6 +976,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; }
     if (tid < AVP_MAX_STEER) { s.k_dth_dt[tid] = p.dth_dt[tid]; for (int j = 0; j < 4; j++) s.k_dth_ddt[tid][j] = p.dth_ddt[tid][j]; }
     if (tid < 4) s.k_travel_ddt[tid] = p.travel_ddt[tid];
+    if (tid < PL_MAXCHILD * 4 && p.n_sub > 0 && p.n_steer > 0) { const int ci = tid / p.n_sub; s.sub_child[tid] = (int8_t)ci; s.sub_j[tid] = (int8_t)(tid - ci * p.n_sub); s.sub_steer[tid] = (int8_t)(ci % p.n_steer); }
     // STAGE: the column bitmaps and node coordinates of the map live in LDS behind PlShared for the whole
     // (persistent) lifetime of the workgroup; otherwise they are read through L1/L2
     MapTabs mt;
@@ -1099,8 +1101,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         const int cnt = min(per, nsubs - base);
                         pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             const int t = base + k;
-                            const int ci = t / p.n_sub, j = t - ci * p.n_sub;
-                            const int si = ci % p.n_steer;
+                            const int ci = s.sub_child[t], j = s.sub_j[t], si = s.sub_steer[t];
                             const double td = ci < p.n_steer ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
                             th = avp_pi_2_pi(cn.th + s.k_dth_ddt[si][j]);
                             avp_sincos(th, sn, cs);
