@@ -95,6 +95,12 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
         bits[(size_t)ix * d.wpc + (iy >> 6)] |= 1ull << (iy & 63);
     }
     for (int32_t i = 0; i < nx; i++) colStart[(size_t)i + 1] += colStart[i];
+    {
+        // the list must be complete too: the kernels read obstacle cells through the bitmaps built from it
+        int64_t n255 = 0;
+        for (size_t c = 0; c < (size_t)nx * ny; c++) n255 += occ[c] == 255;
+        if (n255 != P) { delete m; return set_err(AVP_ERR_ARG, "avp_map_create: obstacle cell list does not cover every 255 cell of the costmap"); }
+    }
 
     // one blob: [X][Y][ox][oy][bits][colStart][occ]
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };

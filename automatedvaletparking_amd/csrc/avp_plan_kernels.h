@@ -226,6 +226,7 @@ struct PlShared {
     RsPath rs;                        // normalised winner of the shot
     int64_t n_checks, n_rs;
     int64_t snap[5];                  // counters saved before a speculative resolution
+    MapTabs mt;                       // the map tables as the kernel sees them (LDS copies when staged)
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
     double k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
@@ -364,7 +365,7 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, PlShared& s, int col, int 
     int oy = s.orow0 + (s.row0 - row);
     if (oy >= m.Sy) oy = m.Sy - 1;
     if (oy < 0) oy += m.ny;
-    if (m.occ[(size_t)ox * m.ny + oy] == 255) return;
+    if ((s.mt.bits[(size_t)ox * m.wpc + (oy >> 6)] >> (oy & 63)) & 1ull) return;      // the column bitmaps (LDS when staged) hold the 255 cells
     const int64_t nid = (int64_t)col + (int64_t)row * m.S;
     if (s.alias && (col == 0 || col == m.S)) {
         const int slot = col == 0 ? row : row + 1;
@@ -398,7 +399,9 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
         const int64_t id = (int64_t)(ent & 0xffffffffull);
         if (w.dist[id] != d) continue;                    // stale entry (distance was lowered later)
         if (w.flags[id] & PL_FLAG_T) continue;            // terminator: closed but never expanded
-        int col = (int)(id % m.S), row = (int)(id / m.S);
+        // queue ids are in [0, idCap) < 2^31 (the queue entry keeps 32 bits): 32-bit division, not the 64-bit sequence
+        const uint32_t id32 = (uint32_t)id, row_u = id32 / (uint32_t)m.S;
+        int col = (int)(id32 - row_u * (uint32_t)m.S), row = (int)row_u;
         if (s.alias && col == 0) {
             if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
         }
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(PL_THREADS) void hfield_kernel(DevMap m, double gx,
     PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace, dims);
-    if (threadIdx.x == 0) { s.status = 0; s.sched_cnt = -1; s.sched_n = 0; for (int k = 0; k < 10; k++) s.phase[k] = 0; }
+    if (threadIdx.x == 0) { s.status = 0; s.sched_cnt = -1; s.sched_n = 0; for (int k = 0; k < 10; k++) s.phase[k] = 0; s.mt.X = m.X; s.mt.Y = m.Y; s.mt.bits = m.colBits; }
     __syncthreads();
     pl_sweep_init(m, w, s, dims, gx, gy);
     for (int i = 0; i < nq && s.status == 0; i++) {
@@ -990,6 +993,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         mt.X = lx; mt.Y = ly; mt.bits = lb;
         __syncthreads();
     } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
+    if (tid == 0) s.mt = mt;
     const int nchild = 2 * p.n_steer;
     const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
 
