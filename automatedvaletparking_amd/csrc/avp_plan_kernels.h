@@ -887,16 +887,20 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
 AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const PlanWs& w, PlShared& s, const PlanDims& dims,
                                 const PlNode& cn, int nchild)
 {
+    // Per-child state stays in the registers of the child's lane; the order dependent parts read it with ballots
+    // and shuffles -- the serial sections below would otherwise spend most of their time on LDS round trips.
     const int lane = threadIdx.x & 63;
+    int cls = CL_SKIP, found = -1, first_coll = 0x7fffffff;
+    double cg = 0.0, ch_ = 0.0, cf = 0.0, cx = 0.0, cy = 0.0, cth = 0.0;
     if (lane < nchild) {
         PlChild& c = s.child[lane];
         c.pre_d = pl_id_in_range(m, c.id) ? w.dist[c.id] : PL_UNSEEN;
+        found = c.found; first_coll = c.first_coll; cx = c.x; cy = c.y; cth = c.th;
         const int is_forward = lane < p.n_steer ? 1 : 0;
-        const bool found_closed = c.found >= 0 && c.found_state == 2;
-        const bool found_open = c.found >= 0 && c.found_state == 1;
-        int cls;
+        const bool found_closed = found >= 0 && c.found_state == 2;
+        const bool found_open = found >= 0 && c.found_state == 1;
         if (found_closed || c.oob) cls = CL_SKIP;
-        else if (!found_open && c.first_coll != 0x7fffffff) cls = CL_NEW_CLOSED;
+        else if (!found_open && first_coll != 0x7fffffff) cls = CL_NEW_CLOSED;
         else {
             uint32_t hd = PL_UNSEEN;
             const bool hit = pl_hquery_hit(m, s, c.id, c.pre_d, hd);
@@ -905,56 +909,63 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
                 const double hv1 = (double)hd / 100, hv2 = c.L;
                 const double hval = hv2 > hv1 ? hv2 : hv1;
                 if (!found_open) {
-                    c.g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
-                    c.h = hval; c.f = c.g + hval;
+                    cg = pl_node_cost(p, is_forward, cth, cn.th, cn.forward);
+                    ch_ = hval; cf = cg + hval;
                     cls = CL_NEW_OPEN;
                 } else {
-                    const PlNode& ch = w.nodes[c.found];
-                    c.g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
-                    c.h = hval; c.f = hval + c.g;
-                    c.old_f = ch.f; c.old_heap_pos = ch.heap_pos;
-                    cls = c.f < ch.f ? CL_IMPROVE : CL_KEEP;
+                    const PlNode& ch = w.nodes[found];
+                    cg = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
+                    ch_ = hval; cf = hval + cg;
+                    cls = cf < ch.f ? CL_IMPROVE : CL_KEEP;
                 }
             }
         }
-        c.cls = cls;
     }
     wave_sync();
     if (!s.fast) return;
+    // arena slots in child order = prefix count of the children that create a node; counters by ballot / reduction
+    const unsigned long long m_closed = __ballot(cls == CL_NEW_CLOSED), m_open = __ballot(cls == CL_NEW_OPEN);
+    const unsigned long long m_rs = m_open | __ballot(cls == CL_IMPROVE || cls == CL_KEEP);
+    const unsigned long long m_new = m_closed | m_open;
+    const int32_t nnodes0 = s.nnodes;
+    const int32_t pos = nnodes0 + __popcll(m_new & ((1ull << lane) - 1ull));
+    int chk = cls == CL_NEW_CLOSED ? first_coll + 1 : 0;          // checks spent on the children that collided
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) chk += __shfl_xor(chk, d, 64);
     if (lane == 0) {
-        for (int i = 0; i < nchild; i++) {
-            PlChild& c = s.child[i];
-            if (c.cls == CL_NEW_CLOSED) { c.pos = s.nnodes++; s.n_checks += c.first_coll + 1; s.nclosed++; }
-            else if (c.cls == CL_NEW_OPEN) { c.pos = s.nnodes++; s.n_checks += p.n_sub; s.n_rs += 1; }
-            else if (c.cls == CL_IMPROVE || c.cls == CL_KEEP) s.n_rs += 1;
-        }
+        s.nnodes = nnodes0 + __popcll(m_new);
+        s.nclosed += __popcll(m_closed);
+        s.n_checks += chk + (long long)__popcll(m_open) * p.n_sub;
+        s.n_rs += __popcll(m_rs);
     }
-    wave_sync();
-    if (lane < nchild) {
-        const PlChild& c = s.child[lane];
-        if (c.cls == CL_NEW_CLOSED || c.cls == CL_NEW_OPEN) {
-            const bool open = c.cls == CL_NEW_OPEN;
-            PlNode& nd = w.nodes[c.pos];
-            nd.x = c.x; nd.y = c.y; nd.th = c.th;
-            nd.g = open ? c.g : 0.0; nd.h = open ? c.h : 0.0; nd.f = open ? c.f : 0.0;
-            nd.index = (int32_t)(s.global_index + lane + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
-            nd.forward = (int8_t)(lane < p.n_steer ? 1 : 0); nd.steer_i = (int8_t)(lane % p.n_steer);
-            nd.state = open ? 1 : 2; nd.heap_pos = -1;
-            pl_hash_put_atomic(w, dims.hashCap, c.pos, c.x, c.y, c.th);
-        }
+    const int32_t gidx = (int32_t)s.global_index, cur = s.cur;
+    if (cls == CL_NEW_CLOSED || cls == CL_NEW_OPEN) {
+        const bool open = cls == CL_NEW_OPEN;
+        PlNode& nd = w.nodes[pos];
+        nd.x = cx; nd.y = cy; nd.th = cth;
+        nd.g = open ? cg : 0.0; nd.h = open ? ch_ : 0.0; nd.f = open ? cf : 0.0;
+        nd.index = gidx + lane + 1; nd.parent_index = cn.index; nd.parent_pos = cur;
+        nd.forward = (int8_t)(lane < p.n_steer ? 1 : 0); nd.steer_i = (int8_t)(lane % p.n_steer);
+        nd.state = open ? 1 : 2; nd.heap_pos = -1;
+        pl_hash_put_atomic(w, dims.hashCap, pos, cx, cy, cth);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     wave_sync();
-    if (lane == 0) {
-        for (int i = 0; i < nchild; i++) {
-            const PlChild& c = s.child[i];
-            if (c.cls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)c.pos, c.f);
-            else if (c.cls == CL_IMPROVE) {
-                PlNode& ch = w.nodes[c.found];
-                ch.f = c.f; ch.g = c.g; ch.h = c.h;
-                ch.parent_index = cn.index; ch.parent_pos = s.cur;
+    // heap pushes / in-place improvements in child order (lane 0; the operands come from the children's lanes)
+    unsigned long long todo = m_open | __ballot(cls == CL_IMPROVE);
+    while (todo) {
+        const int i = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const int icls = __shfl(cls, i, 64), ipos = __shfl(pos, i, 64), ifound = __shfl(found, i, 64);
+        const double if_ = __shfl(cf, i, 64), ig = __shfl(cg, i, 64), ih = __shfl(ch_, i, 64);
+        if (lane == 0) {
+            if (icls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)ipos, if_);
+            else {
+                PlNode& ch = w.nodes[ifound];
+                ch.f = if_; ch.g = ig; ch.h = ih;
+                ch.parent_index = cn.index; ch.parent_pos = cur;
                 ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
-                w.heap[ch.heap_pos].f = c.f;      // current slot: earlier pushes of this pop may have moved it
+                w.heap[ch.heap_pos].f = if_;      // current slot: earlier pushes of this pop may have moved it
             }
         }
     }
