@@ -879,6 +879,11 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
     wave_sync();
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits until every global store of the wave
+// has been acknowledged (a few thousand cycles after the node / heap / hash writes of a resolution). Use where the
+// data handed over lives in LDS and the global writes are not read before a later full barrier.
+__device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- fast path of the child resolution (expand_node :153-232), run by WAVE 0 alone (wave-level syncs only) ----
 // Preconditions (caller): closed list non-empty and the arena has room for every child. Lanes classify and cost
 // their child in parallel; if every heuristic query hits the closed frontier, lane 0 then applies, in child
@@ -1215,24 +1220,28 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (wave >= w0) {
                     double cm, sm;
                     avp_sincos(-cn.th, sm, cm);
-                    auto do_chunk = [&](int base, int cnt) {
+                    // chunk = samples base, base + stride, ... (cnt of them); hit flags land in s.chk_hit[nsubs + sample]
+                    auto do_chunk = [&](int base, int stride, int cnt) {
                         double tx = 0.0, ty = 0.0, tth = 0.0;
-                        if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, base + lane, tx, ty, tth);
+                        const int mine = base + lane * stride;
+                        if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
                         // lane k holds pose k: broadcast it to whichever lanes ask for it
+                        uint32_t* hits = &s.wchk[wave].hit[0];
                         pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
                             avp_sincos(th, sn, cs);
-                        }, &s.chk_hit[nsubs + base]);
-                        if (lane < cnt && s.chk_hit[nsubs + base + lane]) atomicMin(&s.rs_first_coll, base + lane);
+                        }, hits);
+                        if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
+                        wave_sync();
                     };
-                    // Round 0: PL_WPOSE0 samples per wave. On the bench workload 88 % of the colliding shots hit within
-                    // their first 21 samples (all within 32), which lie next to the node and are cheap; the later
-                    // chunks (towards the goal, next to obstacles: many candidate points) then never run. The
-                    // checking waves meet at a software barrier so that the decision sees every round-0 result.
+                    // Round 0: PL_WPOSE0 samples per wave, interleaved (wave c takes samples c, c + nw, ...: samples get
+                    // dearer along the path, towards the obstacles around the goal). On the bench workload 88 % of the
+                    // colliding shots hit within their first 21 samples (all within 32); the later chunks then never
+                    // run. The checking waves meet at a software barrier so that the decision sees every round-0 result.
                     const int head = min(total, nw * PL_WPOSE0);
                     {
-                        const int base = (wave - w0) * PL_WPOSE0;
-                        if (base < head) do_chunk(base, min(PL_WPOSE0, head - base));
+                        const int first = wave - w0;
+                        if (first < head) do_chunk(first, nw, (head - first + nw - 1) / nw);
                     }
                     if (head < total) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1246,11 +1255,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         const int per = max(1, min(PL_WPOSE, (rest + nw - 1) / nw));
                         for (int base = head + (wave - w0) * per; base < total; base += nw * per) {
                             if (*(volatile int32_t*)&s.rs_first_coll < base) break;
-                            do_chunk(base, min(per, total - base));
+                            do_chunk(base, 1, min(per, total - base));
                         }
                     }
                 }
-                __syncthreads();
+                pl_lds_barrier();                                   // (the resolution's global stores need not have landed)
                 if (tid == 0) {
                     // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
                     if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
@@ -1262,7 +1271,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     } else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
                 }
             }
-            __syncthreads();
+            pl_lds_barrier();
             const long long t_f = clock64();
             if (tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
             if (s.status != 0 || s.done) break;
