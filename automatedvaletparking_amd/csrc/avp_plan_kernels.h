@@ -629,24 +629,31 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose, bo
 // order. w_acc / w_err were cleared by pl_rs_words.
 AVP_D void pl_rs_accept_group(PlShared& s, const avp_params& p, int q, int g)
 {
+    // The unused tail of a word's 5 lengths is 0.0 (rs_word), so the sums below always run over all 5 entries:
+    // same values (x + 0.0), but the LDS loads no longer depend on the per-word segment count and issue together.
     unsigned accmask = 0;                     // accepted words of this group so far (bit j = RS_GROUPS[g][j])
+    double kept[4][5];                        // lengths of the group's words seen so far
     for (int j = 0; j < 4; j++) {
         const int wd = RS_GROUPS[g][j];
         if (wd < 0) break;
         const int slot = q * 46 + wd;
         if (!s.w_ok[slot]) continue;
-        const int n = RS_WORDS[wd].n;
+        double l[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { l[i] = s.w_l[slot][i]; kept[j][i] = l[i]; }
         bool dup = false;
-        for (int e = 0; e < j && !dup; e++) {
-            if (!(accmask & (1u << e))) continue;
-            const int eslot = q * 46 + RS_GROUPS[g][e];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            if (e >= j || dup || !(accmask & (1u << e))) continue;
             double sum = 0;
-            for (int i = 0; i < n; i++) sum = sum + (s.w_l[eslot][i] - s.w_l[slot][i]);
+#pragma unroll
+            for (int i = 0; i < 5; i++) sum = sum + (kept[e][i] - l[i]);
             if (sum <= 0.01) dup = true;
         }
         if (dup) continue;
         double L = 0;
-        for (int i = 0; i < n; i++) L = L + fabs(s.w_l[slot][i]);
+#pragma unroll
+        for (int i = 0; i < 5; i++) L = L + fabs(l[i]);
         if (L >= 1000.0) continue;
         if (!(L >= 0.01)) { s.w_err[q] = 1; continue; }
         accmask |= 1u << j;
