@@ -226,6 +226,8 @@ struct PlShared {
     RsPath rs;                        // normalised winner of the shot
     int64_t n_checks, n_rs;
     int64_t snap[5];                  // counters saved before a speculative resolution
+    unsigned long long fold_key[PL_THREADS / 64];   // per-wave scratch of pl_rs_fold_wave
+    int32_t fold_idx[PL_THREADS / 64];
     MapTabs mt;                       // the map tables as the kernel sees them (LDS copies when staged)
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
     double k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
@@ -666,17 +668,22 @@ AVP_D void pl_rs_accept_group(PlShared& s, const avp_params& p, int q, int g)
 // the result is valid on every lane.
 AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
 {
-    const int lane = threadIdx.x & 63;
-    int acc = 0, wd = lane;
-    double Lm = 0.0;
-    if (lane < 46) { acc = s.w_acc[q * 46 + lane]; Lm = s.w_Lm[q * 46 + lane]; }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int oacc = __shfl_xor(acc, d, 64), owd = __shfl_xor(wd, d, 64);
-        const double oL = __shfl_xor(Lm, d, 64);
-        const bool take = oacc && (!acc || oL < Lm || (oL == Lm && owd > wd));
-        if (take) { acc = oacc; wd = owd; Lm = oL; }
-    }
+    // min over the accepted words of (length, then the LATER word on a tie: "<=" in calc_optimal_path keeps the last).
+    // Lengths are positive doubles, so their bit patterns order like the values: one LDS atomic min on the bits, one
+    // atomic max on the word index among the lanes that hold the minimum -- two round trips instead of a 6-step
+    // butterfly over three values.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int acc = 0;
+    unsigned long long lb = ~0ull;
+    if (lane < 46) { acc = s.w_acc[q * 46 + lane]; lb = (unsigned long long)__double_as_longlong(s.w_Lm[q * 46 + lane]); }
+    if (lane == 0) { s.fold_key[wv] = ~0ull; s.fold_idx[wv] = -1; }
+    wave_sync();
+    if (acc) atomicMin(&s.fold_key[wv], lb);
+    wave_sync();
+    if (acc && lb == s.fold_key[wv]) atomicMax(&s.fold_idx[wv], lane);
+    wave_sync();
+    const int wd = s.fold_idx[wv];
+    acc = wd >= 0;
     out.n = 0; out.L = 0;
     if (s.w_err[q]) return 2;
     if (!acc) return 1;
