@@ -696,10 +696,11 @@ AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
 }
 
 // ---- parallel Reeds-Shepp sampling (rs_curve.py:537-594 + :125-131), in stages -----------------------
-// A (one thread): replay the index bookkeeping of generate_local_course (which output index each
-//   interpolate() call writes; later writes overwrite earlier ones) and chain the segment origins.
-// B (all threads): evaluate the interpolations in the local frame.
-// C (one thread): drop the trailing px == 0.0 entries.  D (all): world transform (fused with the checks).
+// A (two lanes of two waves): the index bookkeeping of generate_local_course (which output index each
+//   interpolate() call writes; later writes overwrite earlier ones) and the chain of segment origins.
+// B (the checking waves): each lane evaluates the interpolation of one sample, transforms it to the world frame
+//   and hands it to the wave's collision pass (pl_rs_sample_world); the trailing px == 0.0 entries the reference
+//   pops are tracked through an atomic max of the last non-zero index.
 // generate_local_course (rs_curve.py:537-592) split in two independent serial jobs:
 //   pl_rs_sample_book    -- the index bookkeeping: which sample lies at which arc length of which segment;
 //   pl_rs_sample_origins -- the chain of segment origins (end pose of the previous segment).
@@ -746,28 +747,8 @@ AVP_D void pl_rs_sample_origins(PlShared& s, const avp_params& p)
         }
     }
 }
-AVP_D void pl_rs_sample_local(const PlanWs& w, PlShared& s, const avp_params& p)
-{
-    // s.rs_npts must be 0 on entry; it ends as 1 + the last index whose local px is not 0.0, i.e. the list
-    // length after the reference's "while px[-1] == 0.0: pop()" (rs_curve.py:588-592)
-    const int point_num = s.smp_point_num, hi = s.smp_hi;
-    for (int i = threadIdx.x; i < point_num; i += PL_THREADS) {
-        double px = 0.0, py = 0.0, pyaw = 0.0;
-        int8_t dr = 0;
-        if (i == 0) dr = s.rs.l[0] > 0.0 ? 1 : -1;
-        else if (i <= hi) {
-            const int sg = s.smp_seg[i];
-            const double l = s.smp_l[i];
-            rs_interpolate(l, s.rs.t[sg], p.maxc, s.seg_o[sg][0], s.seg_o[sg][1], s.seg_o[sg][2], px, py, pyaw);
-            dr = l > 0.0 ? 1 : -1;
-        }
-        w.rsbuf[3 * i] = px; w.rsbuf[3 * i + 1] = py; w.rsbuf[3 * i + 2] = pyaw; w.rsdir[i] = dr;
-        if (px != 0.0) atomicMax(&s.rs_npts, i + 1);
-    }
-}
-
 // Sample i of the shot, straight to the world frame (generate_local_course's interpolation :537-624 followed by
-// calc_all_paths' rotation :125-131): the same arithmetic as pl_rs_sample_local + the transform, per sample, so
+// calc_all_paths' rotation :125-131), per sample, so
 // that a wave can produce exactly the samples it is about to check. Also maintains the trim bound s.rs_npts.
 AVP_D void pl_rs_sample_world(const PlanWs& w, PlShared& s, const avp_params& p, const PlNode& cn, double cm, double sm,
                               int i, double& tx, double& ty, double& tth)
