@@ -113,52 +113,7 @@ AVP_HD bool avp_footprint_point_hit(const Footprint& f, double px, double py)
     return edge;
 }
 
-// First node index i with A[i] >= v (A ascending, n entries): exact against the table, any v.
-AVP_HD int avp_first_ge(const double* A, int n, double a0, double pitch, double v)
-{
-    double g = floor((v - a0) / pitch);
-    int i = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);
-    while (i > 0 && A[i - 1] >= v) --i;
-    while (i < n && A[i] < v) ++i;
-    return i;
-}
-// Last node index i with A[i] <= v, or -1.
-AVP_HD int avp_last_le(const double* A, int n, double a0, double pitch, double v)
-{
-    double g = floor((v - a0) / pitch);
-    int i = !(g >= 0.0) ? -1 : (g >= (double)n ? n - 1 : (int)g);
-    while (i + 1 < n && A[i + 1] <= v) ++i;
-    while (i >= 0 && A[i] > v) --i;
-    return i;
-}
-// strict versions for the two-circle checker's exclusive filter (collision_check.py:119-127)
-AVP_HD int avp_first_gt(const double* A, int n, double a0, double pitch, double v)
-{
-    double g = floor((v - a0) / pitch);
-    int i = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);
-    while (i > 0 && A[i - 1] > v) --i;
-    while (i < n && !(A[i] > v)) ++i;
-    return i;
-}
-AVP_HD int avp_last_lt(const double* A, int n, double a0, double pitch, double v)
-{
-    double g = floor((v - a0) / pitch);
-    int i = !(g >= 0.0) ? -1 : (g >= (double)n ? n - 1 : (int)g);
-    while (i + 1 < n && A[i + 1] < v) ++i;
-    while (i >= 0 && !(A[i] < v)) --i;
-    return i;
-}
-
-// first_ge (upper = false) / last_le (upper = true) as ONE instruction stream, so that lanes searching different
-// bounds of different axes do not diverge (same results as avp_first_ge / avp_last_le for finite v)
-AVP_HD int avp_node_search(const double* A, int n, double a0, double pitch, double v, bool upper)
-{
-    const double g = floor((v - a0) / pitch) + (upper ? 1.0 : 0.0);
-    int c = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);          // estimate of #{A[i] < v} resp. #{A[i] <= v}
-    while (c > 0 && (upper ? A[c - 1] > v : A[c - 1] >= v)) --c;
-    while (c < n && (upper ? A[c] <= v : A[c] < v)) ++c;
-    return upper ? c - 1 : c;
-}
+// (the index searches avp_first_ge / avp_last_le / avp_first_gt / avp_last_lt / avp_node_search live in avp_math.h)
 
 // map/costmap.py:319-329
 AVP_HD int64_t avp_pos_to_index(const DevMap& m, double gx, double gy)

@@ -1,6 +1,16 @@
 // Host build of avp_math.h for CPU-side unit tests (bit-compare against this host's libm).
 #include "avp_math.h"
 extern "C" {
+// index searches of the collision set-up: the four reference routines and the unified one the kernels use
+__attribute__((visibility("default"))) void avp_host_node_search(const double* A, int n, double a0, double pitch, const double* v, long m,
+                                                                 int* first_ge, int* last_le, int* first_gt, int* last_lt, int* uni_lo, int* uni_hi)
+{
+    for (long i = 0; i < m; i++) {
+        first_ge[i] = avp_first_ge(A, n, a0, pitch, v[i]); last_le[i] = avp_last_le(A, n, a0, pitch, v[i]);
+        first_gt[i] = avp_first_gt(A, n, a0, pitch, v[i]); last_lt[i] = avp_last_lt(A, n, a0, pitch, v[i]);
+        uni_lo[i] = avp_node_search(A, n, a0, pitch, v[i], false); uni_hi[i] = avp_node_search(A, n, a0, pitch, v[i], true);
+    }
+}
 __attribute__((visibility("default"))) void avp_host_sincos(const double* x, long n, double* s, double* c)
 { for (long i = 0; i < n; i++) { s[i] = avp_sin(x[i]); c[i] = avp_cos(x[i]); } }
 // the fused evaluation used by the kernels: must give the two values above bit for bit

@@ -78,3 +78,25 @@ def test_hypot_mod_wraps_match_cpython():
         return phi
     assert np.array_equal(p2p, np.array([p2(t) for t in a.tolist()]))
     assert np.array_equal(M, np.array([mm(t) for t in a.tolist()]))
+
+
+def test_unified_node_search_equals_reference_routines():
+    """avp_node_search (one instruction stream for all four bounds of a footprint AABB) == avp_first_ge / avp_last_le,
+    and the strict variants keep their own definitions, on linspace tables like map_position, incl. exact hits,
+    values off both ends and a pitch estimate that is off by a few cells."""
+    L = _lib()
+    rng = np.random.default_rng(11)
+    for n, lo, hi in ((290, -28.0, 1.0), (250, -26.0, -1.0), (2, 0.0, 1.0), (620, 4.4e9, 4.4e9 + 62.0)):
+        A = np.linspace(lo, hi, n)
+        pitch = A[1] - A[0]
+        v = np.concatenate([rng.uniform(lo - 3 * pitch, hi + 3 * pitch, 20000), A, A + 1e-12, A - 1e-12,
+                            np.nextafter(A, np.inf), np.nextafter(A, -np.inf), [lo - 100, hi + 100]])
+        m = len(v)
+        out = [np.empty(m, dtype=np.int32) for _ in range(6)]
+        for pf in (pitch, pitch * 1.03, pitch * 0.97):            # the pitch is only a hint
+            L.avp_host_node_search(A.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_double(lo), C.c_double(pf), v.ctypes.data_as(C.c_void_p),
+                                   C.c_long(m), *[o.ctypes.data_as(C.c_void_p) for o in out])
+            fge, lle, fgt, llt, ulo, uhi = out
+            assert np.array_equal(fge, np.searchsorted(A, v, side="left")) and np.array_equal(lle, np.searchsorted(A, v, side="right") - 1)
+            assert np.array_equal(fgt, np.searchsorted(A, v, side="right")) and np.array_equal(llt, np.searchsorted(A, v, side="left") - 1)
+            assert np.array_equal(ulo, fge) and np.array_equal(uhi, lle)
