@@ -1132,6 +1132,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const long long t_e = clock64();
             if (tid == 0) s.phase[PH_CHILD] += t_e - t_d;
 
+            // read here, a full barrier before the speculative resolution on wave 0 starts to move s.nnodes
+            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
+
             // ---- Reeds-Shepp words: query 0 = the shot from the popped node (:326-332), 1.. = children (:286-294)
             {
                 const int nq = nchild + 1;
@@ -1192,7 +1195,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const long long t_f0 = clock64();
             if (tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
             if (in_radius && s.rs_status) { if (tid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? 5 : 3; __syncthreads(); break; }
-            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);   // stable until the resolution
             const long long t_g = t_f0;
             // The outcome of the shot is not an input of the child resolution, so when the resolution can take its
             // fast path, wave 0 runs it SPECULATIVELY while the other waves sample and check the shot; if the shot
