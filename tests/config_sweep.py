@@ -1,6 +1,6 @@
 """BASELINE.json configs 3-5 at full size on one GPU: throughput + parity against the CPU oracle (portable libm).
 
-    python scripts/config_sweep.py [--pairs 128] [--cap 300] [--threads 64] > profiles/rNN_config_sweep.jsonl
+    python tests/config_sweep.py [--pairs 128] [--cap 300] [--threads 64] > profiles/rNN_config_sweep.jsonl
 
 C3: all 20 BenchmarkCases x `pairs` random start/goal pairs (seed 20260927 + k), pop cap `cap`;
 C4: synthetic 200 x 200 grid, 32 convex polygons, 4096 poses -> check_batch (both checkers) + 256 plans;
@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (lives under tests/: it uses the oracle as the checker)
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from automatedvaletparking_amd import _native, config, costmap, path_planner, sampling  # noqa: E402
