@@ -1,6 +1,8 @@
 // Host build of avp_math.h for CPU-side unit tests (bit-compare against this host's libm).
 #include "avp_math.h"
 extern "C" {
+__attribute__((visibility("default"))) void avp_host_linspace0(double stop, int num, double* out)
+{ for (int q = 0; q < num; q++) out[q] = avp_linspace0(stop, num, q); }
 // index searches of the collision set-up: the four reference routines and the unified one the kernels use
 __attribute__((visibility("default"))) void avp_host_node_search(const double* A, int n, double a0, double pitch, const double* v, long m,
                                                                  int* first_ge, int* last_le, int* first_gt, int* last_lt, int* uni_lo, int* uni_hi)

@@ -308,3 +308,18 @@ AVP_HD int avp_node_search(const double* A, int n, double a0, double pitch, doub
     return upper ? c - 1 : c;
 }
 
+// ---- numpy.linspace restated (obstacle-edge rasteriser, map/costmap.py:239) -------------------------
+// numpy.linspace(0.0, stop, num)[q] (numpy/_core/function_base.py): step = stop / (num - 1);
+// y = arange(num) * step (or (arange(num) / div) * stop when step == 0), y += 0.0, y[-1] = stop
+AVP_HD double avp_linspace0(double stop, int num, int q)
+{
+    if (num > 1 && q == num - 1) return stop;
+    const int div = num - 1;
+    double y = (double)q;
+    if (div > 0) {
+        const double step = stop / (double)div;
+        y = (step == 0.0) ? (y / (double)div) * stop : y * step;
+    } else y = y * stop;
+    return y + 0.0;
+}
+

@@ -21,19 +21,7 @@ struct RasterGrid {
     double dx, dy;        // X[1] - X[0], Y[1] - Y[0]
 };
 
-// numpy.linspace(0.0, stop, num)[q] (numpy/_core/function_base.py): step = stop / (num - 1);
-// y = arange(num) * step (or (arange(num) / div) * stop when step == 0), y += 0.0, y[-1] = stop
-AVP_HD double avp_linspace0(double stop, int num, int q)
-{
-    if (num > 1 && q == num - 1) return stop;
-    const int div = num - 1;
-    double y = (double)q;
-    if (div > 0) {
-        const double step = stop / (double)div;
-        y = (step == 0.0) ? (y / (double)div) * stop : y * step;
-    } else y = y * stop;
-    return y + 0.0;
-}
+// (avp_linspace0 -- numpy.linspace(0.0, stop, num)[q] -- lives in avp_math.h, where the host tests reach it)
 
 // cell of one sample, or -1 (no node on an axis) / -2 (more than one)
 AVP_HD int64_t avp_raster_cell(const RasterGrid& g, const double* e, int q)

@@ -100,3 +100,17 @@ def test_unified_node_search_equals_reference_routines():
             assert np.array_equal(fge, np.searchsorted(A, v, side="left")) and np.array_equal(lle, np.searchsorted(A, v, side="right") - 1)
             assert np.array_equal(fgt, np.searchsorted(A, v, side="right")) and np.array_equal(llt, np.searchsorted(A, v, side="left") - 1)
             assert np.array_equal(ulo, fge) and np.array_equal(uhi, lle)
+
+
+def test_linspace_restatement_bit_equal_numpy():
+    """avp_linspace0(stop, num, q) == numpy.linspace(0, stop, num)[q] bit for bit (end-point overwrite, num 0/1/2,
+    zero and denormal steps): the rasteriser's sample positions (map/costmap.py:239)."""
+    L = _lib()
+    rng = np.random.default_rng(2)
+    cases = [(0.0, 5), (1e-320, 7), (5e-324, 3), (0.05, 0), (0.15, 1), (0.25, 2), (-3.7, 9)]
+    cases += [(float(s), int(n)) for s, n in zip(rng.uniform(0, 60, 3000), rng.integers(0, 700, 3000))]
+    for stop, num in cases:
+        out = np.empty(max(num, 1))
+        L.avp_host_linspace0(C.c_double(stop), C.c_int(num), out.ctypes.data_as(C.c_void_p))
+        want = np.linspace(0, stop, num)
+        assert np.array_equal(out[:num].view(np.uint64), want.view(np.uint64)), (stop, num)
