@@ -13,6 +13,7 @@ Usage:  python oracle/gen_golden.py micro            # G1-G5 micro vectors (minu
         python oracle/gen_golden.py trace 1 2 3 ...   # G6 pop traces of BenchmarkCases (minutes-hours)
         python oracle/gen_golden.py random 1 8        # G7: 8 random start/goal problems on Case1
         python oracle/gen_golden.py synth             # G8 synthetic maps (C4, C5 small variants)
+        python oracle/gen_golden.py variants 4        # G10: other config.yaml values on Case4
 """
 import io
 import os
@@ -435,6 +436,44 @@ def gen_random(case_id, n, seed_off=0, timeout=1200):
         print("random", case_id, i, d["status"], "pops", len(d["pops"]), "t", time.time() - t0, flush=True)
 
 
+VARIANTS = {
+    "steer7_r6": {"steering_angle_num": 7, "flag_radius": 6.0},
+    "steer3": {"steering_angle_num": 3},
+    "dt08": {"dt": 0.8, "trajectory_dt": 0.2, "cost_gear": 3, "cost_heading_change": 1.5},
+    "circle": {"collision_check": "circle"},
+    "margins_rsall": {"flag_radius": 1e9, "safe_side_dis": 0.05, "safe_fr_dis": 0.2},
+}
+
+
+def gen_variants(case_id=4, n_random=3, timeout=600, names=None):
+    """G10: the reference under other config.yaml values (motion-primitive sets, time steps, costs, checker,
+    margins, flag radius): the case's own start/goal plus n_random random pairs per variant. The overrides
+    travel in the fixture as JSON (`cfg_json`)."""
+    import json
+    csv = os.path.join(CASES, f"Case{case_id}.csv")
+    for name, over in VARIANTS.items():
+        if names and name not in names:
+            continue
+        cfg = config()
+        cfg.update(over)
+        m0 = load_map(csv, cfg)
+        veh = ref_costmap.Vehicle()
+        dc = ref_cc.distance_checker(map=m0, vehicle=veh, config=cfg)
+        rng = np.random.default_rng(20260927 + 77 * case_id)
+        poses = sampling.sample_free_poses(m0.boundary, m0.case.obs, 2 * n_random, rng, margin=6.0, check=dc.check)
+        probs = [(None, None)] + [(poses[2 * i], poses[2 * i + 1]) for i in range(n_random)]
+        for i, (st, go) in enumerate(probs):
+            t0 = time.time()
+            d = run_plan(csv, cfg, start=st, goal=go, timeout=timeout)
+            d["case"] = case_id
+            d["cfg_json"] = json.dumps(over)
+            if st is not None:
+                d["start"] = st
+                d["goal"] = go
+            save(f"g10_variant_{name}_case{case_id}_{i}.npz", d)
+            print("variant", name, case_id, i, d["status"], "pops", len(d["pops"]), "t", time.time() - t0, flush=True)
+
+
 def gen_synth():
     """G8: small synthetic maps through the reference (C4-style polygons, C5-style parking row)."""
     cfg = config()
@@ -518,6 +557,8 @@ if __name__ == "__main__":
         gen_hfield(tuple(int(a) for a in sys.argv[2:]) or (1, 4))
     elif what == "trace":
         gen_trace([int(a) for a in sys.argv[2:]])
+    elif what == "variants":
+        gen_variants(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
     elif what == "random":
         gen_random(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif what == "synth":

@@ -15,7 +15,7 @@ from conftest import CASES, GOLD, gold, case_map_from_gold
 
 pytestmark = pytest.mark.gpu
 GOLDENS = sorted(glob.glob(os.path.join(GOLD, "g6_trace_case*.npz")) + glob.glob(os.path.join(GOLD, "g7_random_case*.npz"))
-                 + glob.glob(os.path.join(GOLD, "g8_synth_c*_plan*.npz")))
+                 + glob.glob(os.path.join(GOLD, "g8_synth_c*_plan*.npz")) + glob.glob(os.path.join(GOLD, "g10_variant_*.npz")))
 
 
 def _gold_problem(g):
@@ -61,6 +61,9 @@ def test_golden_problems(path, vehicle, cfg):
     cfgp = dict(cfg)
     if "synth_c5" in path:
         cfgp["flag_radius"] = 1e9
+    if "cfg_json" in g.files:                     # G10: the reference under other config.yaml values
+        import json
+        cfgp.update(json.loads(str(g["cfg_json"])))
     cap = 30000
     dm = _native.DeviceMap(m, vehicle, cfgp, max_pops=cap)
     bp = path_planner.BatchPlanner(dm, n_slots=1, max_nodes=1 << 19)

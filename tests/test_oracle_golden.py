@@ -160,6 +160,30 @@ def test_pop_trace_synthetic_maps(path, vehicle, cfg):
     _check_plan(g, m, o, g["start"], g["goal"])
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g10_variant_*.npz"))))
+def test_pop_trace_config_variants(path, vehicle, cfg):
+    """G10: the reference under other config.yaml values (7 / 3 steering angles, dt 0.8 with 4 sub-steps, other
+    costs, the two-circle checker, other safety margins, flag_radius 1e9); the overrides travel in the fixture."""
+    import json
+    g = np.load(path)
+    from automatedvaletparking_amd import costmap
+    from oracle import oracle
+    k = int(g["case"])
+    case = costmap.Case.read(os.path.join(CASES, f"Case{k}.csv"))
+    m = costmap.Map.from_cells(case, g["map_boundary"], int(g["map_nx"]), int(g["map_ny"]), g["map_cells"])
+    c2 = dict(cfg)
+    c2.update(json.loads(str(g["cfg_json"])))
+    st, go = (g["start"], g["goal"]) if "start" in g.files else ([case.x0, case.y0, case.theta0], [case.xf, case.yf, case.thetaf])
+    if str(g["status"]) == "timeout":
+        n = len(g["pops"])
+        if n == 0:
+            pytest.skip("reference did not get to its first pop")
+        r = oracle.Oracle(m, vehicle, c2, max_pops=n).plan(st, go, max_trace=n)
+        assert r["n_pops"] == n and np.array_equal(r["trace"][:, :10], g["pops"][:, :10])
+    else:
+        _check_plan(g, m, oracle.Oracle(m, vehicle, c2), st, go)
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g6_trace_case*.npz")) + glob.glob(os.path.join(GOLD, "g7_random_case*.npz"))))
 def test_pop_trace_prefix_of_unfinished_reference_runs(path, vehicle, cfg):
     """Reference runs that hit the generator's time limit (Cases 7, 8, 19: > 13 000 pops in 90 min; hard random
