@@ -38,35 +38,49 @@ def test_rs_portable_vs_reference(vehicle, cfg):
         assert any(match), (i, r["types"][i], g4["types"][i])
 
 
-# golden problems on which the portable arithmetic resolves a tie differently from glibc (measured; see
-# DESIGN.md "Numerics"). With the nearly correctly rounded atan2/asin/acos of include/avp_libm.h there is
-# none among the 33 finished golden plans (the first, fdlibm-accuracy version diverged on Case18 at pop 466).
-KNOWN_TIE_DIVERGENCE = set()
+# golden problems on which the portable arithmetic orders two open nodes differently from glibc (measured; see
+# DESIGN.md "Numerics"). With the nearly correctly rounded atan2/asin/acos of include/avp_libm.h there is none
+# among the finished golden plans (the first, fdlibm-accuracy version diverged on Case18 at pop 466) and one
+# among the 93 trace fixtures incl. the unfinished reference runs: in the two-circle-checker variant below a
+# Reeds-Shepp length that differs in its last bit (h = 9.4061481238178093 vs ...8111; the same 1-ulp noise shows
+# up at pops 483 and 1048 without consequence) swaps two nodes of almost equal f at pop 3506 of 4048.
+KNOWN_TIE_DIVERGENCE = {"g10_variant_circle_case4_2.npz"}
+
+TRACE_FIXTURES = sorted(glob.glob(os.path.join(GOLD, "g6_trace_case*.npz")) + glob.glob(os.path.join(GOLD, "g7_random_case*.npz"))
+                        + glob.glob(os.path.join(GOLD, "g10_variant_*.npz")))
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g6_trace_case*.npz")) + glob.glob(os.path.join(GOLD, "g7_random_case*.npz"))))
+@pytest.mark.parametrize("path", TRACE_FIXTURES)
 def test_trace_portable_vs_reference(path, vehicle, cfg):
     """north_star bar for the device arithmetic, checked on the CPU: the popped grid-id sequence is
-    identical to the reference's and the final path agrees to 1e-6, except where an exact
-    Reeds-Shepp tie or a twin-node tie (two open nodes whose poses differ by an ulp and whose costs
-    are equal in glibc arithmetic) is resolved the other way; those cases are listed, not hidden."""
+    identical to the reference's -- for finished reference runs to the end (and the final path agrees to
+    1e-6), for runs that hit the generator's time limit over their whole recorded prefix -- except where an
+    exact Reeds-Shepp tie or a twin-node tie (two open nodes whose costs differ by an ulp of libm noise) is
+    resolved the other way; those cases are listed, not hidden."""
+    import json
     from automatedvaletparking_amd import costmap
     from oracle import oracle
     g = np.load(path)
-    if str(g["status"]) != "ok":
-        pytest.skip("no finished reference plan")
+    gp = g["pops"]
+    if str(g["status"]) not in ("ok", "timeout") or len(gp) == 0:
+        pytest.skip("no reference pop trace")
     k = int(g["case"])
     case = costmap.Case.read(os.path.join(CASES, f"Case{k}.csv"))
     m = costmap.Map.from_cells(case, g["map_boundary"], int(g["map_nx"]), int(g["map_ny"]), g["map_cells"])
     st, go = (g["start"], g["goal"]) if "start" in g.files else ([case.x0, case.y0, case.theta0], [case.xf, case.yf, case.thetaf])
-    o = oracle.Oracle(m, vehicle, cfg)
+    c2 = dict(cfg)
+    if "cfg_json" in g.files:
+        c2.update(json.loads(str(g["cfg_json"])))
+    finished = str(g["status"]) == "ok"
+    o = oracle.Oracle(m, vehicle, c2, max_pops=0 if finished else len(gp))
     with oracle.portable_libm():
-        r = o.plan(st, go, max_trace=len(g["pops"]) + 2000)
-    gp = g["pops"]
+        r = o.plan(st, go, max_trace=len(gp) + 2000)
     name = os.path.basename(path)
-    same_ids = r["n_pops"] == len(gp) and np.array_equal(r["trace"][:, 2], gp[:, 2])
+    n = min(r["n_pops"], len(gp))
+    same_ids = (r["n_pops"] == len(gp) or (not finished and r["n_pops"] >= len(gp))) and np.array_equal(r["trace"][:n, 2], gp[:n, 2])
     if name in KNOWN_TIE_DIVERGENCE:
-        assert r["status"] == 0
+        assert not same_ids, f"{name} no longer diverges: take it off the list"
         return
     assert same_ids, name
-    assert r["final_path"].shape == g["final_path"].shape and np.abs(r["final_path"] - g["final_path"]).max() < 1e-6, name
+    if finished:
+        assert r["final_path"].shape == g["final_path"].shape and np.abs(r["final_path"] - g["final_path"]).max() < 1e-6, name
