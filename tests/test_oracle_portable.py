@@ -41,7 +41,7 @@ def test_rs_portable_vs_reference(vehicle, cfg):
 # golden problems on which the portable arithmetic orders two open nodes differently from glibc (measured; see
 # DESIGN.md "Numerics"). With the nearly correctly rounded atan2/asin/acos of include/avp_libm.h there is none
 # among the finished golden plans (the first, fdlibm-accuracy version diverged on Case18 at pop 466) and one
-# among the 93 trace fixtures incl. the unfinished reference runs: in the two-circle-checker variant below a
+# among the 117 trace fixtures incl. the unfinished reference runs: in the two-circle-checker variant below a
 # Reeds-Shepp length that differs in its last bit (h = 9.4061481238178093 vs ...8111; the same 1-ulp noise shows
 # up at pops 483 and 1048 without consequence) swaps two nodes of almost equal f at pop 3506 of 4048.
 KNOWN_TIE_DIVERGENCE = {"g10_variant_circle_case4_2.npz"}
