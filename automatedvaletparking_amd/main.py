@@ -70,13 +70,23 @@ def main(argv=None) -> int:
         hit = dm.check_batch(cand)
         free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], park_map.case.obs)]
     poses = np.array(free[:2 * a.batch])
-    res = path_planner.BatchPlanner(dm).plan(poses[0::2], poses[1::2])
+    planner._batch = path_planner.BatchPlanner(dm)
+    # a_star_plan + split_path per problem = path_planning() (path_planner.py:45-56); every extension pose of the batch
+    # is collision-checked in one launch
+    res = planner.plan_batch(poses[0::2], poses[1::2], split=True)
     dt = time.perf_counter() - t0
     ok = sum(r.ok for r in res)
+    n_seg = 0
+    for i, r in enumerate(res):
+        if r.segments is not None:       # one file per solved problem, the layout of the single-problem run (main.py:66-70 consumes it)
+            write_segments(os.path.join(a.out_dir, f"Planned_{a.case_name}_{i}.tsv"), r.segments)
+            n_seg += 1
     np.savez_compressed(os.path.join(a.out_dir, f"Batch_{a.case_name}.npz"), starts=poses[0::2], goals=poses[1::2],
                         status=np.array([r.status for r in res]), n_pops=np.array([r.n_pops for r in res]),
+                        change_gear=np.array([-1 if r.change_gear is None else r.change_gear for r in res]),
                         **{f"path_{i}": r.final_path for i, r in enumerate(res) if r.ok})
-    print(f"{a.case_name}: {a.batch} problems, {ok} solved, {sum(r.n_pops for r in res)} expansions, {dt:.3f} s")
+    print(f"{a.case_name}: {a.batch} problems, {ok} solved, {n_seg} segment files (the others have no gear change: the "
+          f"reference raises IndexError there), {sum(r.n_pops for r in res)} expansions, {dt:.3f} s")
     return 0
 
 

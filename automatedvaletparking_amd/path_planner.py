@@ -57,6 +57,10 @@ class PlanResult:
     rs_dirs: np.ndarray = None        # (n_rs_pts,) +1 forward / -1 reverse
     counters: Dict[str, int] = field(default_factory=dict)
     trace: Optional[np.ndarray] = None
+    # filled by plan_batch(..., split=True): what path_planning() adds on top of a_star_plan() (path_planner.py:45-56)
+    segments: Optional[List[List[List[float]]]] = None   # split_path_list: gear segments incl. the extension points
+    change_gear: Optional[int] = None
+    split_error: Optional[str] = None                    # "IndexError": the path has no gear change (path_planner.py:181)
 
     @property
     def ok(self) -> bool:
@@ -171,10 +175,22 @@ class PathPlanner:
             self._batch = BatchPlanner(_native.device_map(self.map, self.vehicle, self.config), **kw)
         return self._batch
 
-    def plan_batch(self, starts, goals, max_trace: int = 0) -> List[PlanResult]:
+    def plan_batch(self, starts, goals, max_trace: int = 0, split: bool = False) -> List[PlanResult]:
         """N independent (start, goal) problems on this map; element i equals what
-        `a_star_plan()` gives for `map.case.{x0..thetaf}` = (starts[i], goals[i])."""
-        return self.batch_planner().plan(starts, goals, max_trace=max_trace)
+        `a_star_plan()` gives for `map.case.{x0..thetaf}` = (starts[i], goals[i]).
+        split=True also runs `split_path` on every solved problem -- all extension poses of the batch in ONE
+        collision-check launch -- and fills `segments` / `change_gear` (= what `path_planning()` returns,
+        path_planner.py:45-56) or `split_error` where the reference raises IndexError (:181)."""
+        res = self.batch_planner().plan(starts, goals, max_trace=max_trace)
+        if split:
+            todo = [r for r in res if r.rs_types and r.status in (0, 1)]
+            outs = split_path_batch([r.final_path for r in todo], self.config, self.vehicle, self.collision_checker)
+            for r, o in zip(todo, outs):
+                if isinstance(o, Exception):
+                    r.split_error = type(o).__name__
+                else:
+                    r.segments, r.change_gear = o
+        return res
 
     # -- reference API -----------------------------------------------------------------------------------
     def a_star_plan(self) -> Tuple[List[List], List[List], PATH]:
@@ -269,3 +285,76 @@ def split_path(final_path, config, vehicle, checker):
         prepend_carried(tail)
     segments.append(tail)
     return segments, int(change_gear)
+
+
+def _gear_cuts(P: np.ndarray) -> np.ndarray:
+    """Indices i with cosine(P[i+1]-P[i], P[i+2]-P[i+1]) < 0 (path_planner.py:126-134), evaluated per triple with the
+    scalar routine above so that the BLAS rounding of the reference's scipy call is kept."""
+    return np.array([i for i in range(len(P) - 2)
+                     if (1 - _cosine_distance((P[i + 1, 0] - P[i, 0], P[i + 1, 1] - P[i, 1]),
+                                              (P[i + 2, 0] - P[i + 1, 0], P[i + 2, 1] - P[i + 1, 1]))) < 0], dtype=np.int64)
+
+
+def _extension_poses(a, b, n_extend, vmax, ddt):
+    """The `extended_num` candidate poses behind a cut (path_planner.py:142-166): same expressions as split_path."""
+    heading = a[2]
+    moving_pos_x = b[0] > a[0]
+    moving_neg_x = b[0] < a[0]
+    facing_pos_x = -np.pi / 2 < heading < np.pi / 2
+    facing_neg_x = (np.pi / 2 < heading < np.pi) or (-np.pi < heading < -np.pi / 2)
+    forward = (moving_pos_x and facing_pos_x) or (moving_neg_x and facing_neg_x)
+    speed = vmax if forward else -vmax
+    th = b[2]
+    return [[b[0] + speed * ddt * (j + 1) * np.cos(th), b[1] + speed * ddt * (j + 1) * np.sin(th), th] for j in range(n_extend)]
+
+
+def split_path_batch(paths, config, vehicle, checker):
+    """`split_path` for many paths with ONE collision-check launch for all their extension poses.
+    The candidate extension poses of a cut depend only on the path (not on each other's check results), so they are
+    generated for every cut of every path first, checked together (`check_batch`), and the segments are then
+    assembled with the reference's bookkeeping (`path_planner.py:112-192`). Returns one entry per path:
+    `(segments, change_gear)` or the `IndexError` the reference raises when the path has no gear change."""
+    n_extend = config['extended_num']
+    ddt = config['trajectory_dt']
+    plist = [[[float(q[0]), float(q[1]), float(q[2])] for q in p] for p in paths]
+    cuts, cand, owner = [], [], []
+    for k, p in enumerate(plist):
+        P = np.asarray(p, dtype=np.float64).reshape(-1, 3)
+        c = _gear_cuts(P)
+        cuts.append(c)
+        for i in c:
+            cand += _extension_poses(p[i], p[i + 1], n_extend, vehicle.max_v, ddt)
+    hit = checker.check_batch(np.asarray(cand, dtype=np.float64).reshape(-1, 3)) if cand else np.zeros(0, np.uint8)
+    out = []
+    pos = 0
+    for k, p in enumerate(plist):
+        if len(cuts[k]) == 0:
+            out.append(IndexError("list index out of range"))        # segments[-1] on an empty list, path_planner.py:181
+            continue
+        segments: List[List[List]] = []
+        seg_start = 0
+        carried = 0
+        for ci, i in enumerate(cuts[k]):
+            seg = p[seg_start:i + 2]
+            if ci > 0 and carried > 0:
+                prev = segments[-1]
+                for j in range(carried):
+                    q = prev[-(carried - j)]
+                    seg.insert(0, [q[0], q[1], q[2]])
+                carried = 0
+            for j in range(n_extend):
+                if not hit[pos]:
+                    seg.append(list(cand[pos]))
+                    carried += 1
+                pos += 1
+            segments.append(seg)
+            seg_start = i + 1
+        tail = p[seg_start:]
+        if carried > 0:
+            prev = segments[-1]
+            for j in range(carried):
+                q = prev[-(carried - j)]
+                tail.insert(0, [q[0], q[1], q[2]])
+        segments.append(tail)
+        out.append((segments, int(len(cuts[k]))))
+    return out

@@ -283,13 +283,13 @@ def gen_micro_g2(maps, rng):
     save("g2_index.npz", g2)
 
 
-def gen_micro_g3(maps, rng, cfg, veh):
+def gen_micro_g3(maps, rng, cfg, veh, cases=(1, 4, 5, 13, 19, 20), name="g3_collision.npz", n_rand=3000):
     # G3: collision booleans
     g3 = {}
-    for k in (1, 4, 5, 13, 19, 20):
+    for k in cases:
         m = maps[k]
         b = m.boundary
-        n = 3000 if k != 19 else 1500
+        n = n_rand if k != 19 else n_rand // 2
         poses = np.stack([rng.uniform(b[0] + 2, b[1] - 2, n), rng.uniform(b[2] + 2, b[3] - 2, n),
                           rng.uniform(-np.pi, np.pi, n)], 1)
         # exactly axis-aligned headings (k = +-inf -> NaN distances)
@@ -318,7 +318,16 @@ def gen_micro_g3(maps, rng, cfg, veh):
     pp = np.stack([rng.uniform(-30, 30, 500), rng.uniform(-30, 30, 500), rng.uniform(-np.pi, np.pi, 500)], 1)
     g3["corner_poses"] = pp
     g3["corners"] = np.array([veh.create_anticlockpoint(x, y, t, cfg).reshape(5, 2) for x, y, t in pp])
-    save("g3_collision.npz", g3)
+    save(name, g3)
+
+
+def gen_g3_rest():
+    """G3 for the 14 BenchmarkCases the first fixture does not hold (SURVEY 8c asks for all 20)."""
+    cfg = config()
+    veh = ref_costmap.Vehicle()
+    rest = [k for k in range(1, 21) if k not in (1, 4, 5, 13, 19, 20)]
+    maps = {k: load_map(os.path.join(CASES, f"Case{k}.csv"), cfg) for k in rest}
+    gen_micro_g3(maps, np.random.default_rng(20260927 + 3), cfg, veh, cases=rest, name="g3_collision_rest.npz", n_rand=1200)
 
 
 def gen_micro_g4(rng, veh):
@@ -366,19 +375,31 @@ def gen_micro_g4(rng, veh):
     save("g4_angles.npz", dict(th=th, pi2pi=np.array([ref_rs.pi_2_pi(t) for t in th]), M=np.array([ref_rs.M(t) for t in th])))
 
 
-def gen_hfield(cases=(1, 4)):
-    """G5: heuristic fields. Query the far corner region so that the sweep closes (almost) the whole map."""
+def gen_hfield(cases=(1, 4), random_goals=None):
+    """G5: heuristic fields. Query the far corner region so that the sweep closes (almost) the whole map.
+    random_goals=(first, count): instead of the case's own goal, `count` random free goals (index first..) on
+    each case, written as g5_hfield_c<k>_r<i>.npz (8 random goals on Case1)."""
     cfg = config()
     rng = np.random.default_rng(5)
     for k in cases:
         csv = os.path.join(CASES, f"Case{k}.csv")
         m = load_map(csv, cfg)
         goals = [(m.case.xf, m.case.yf)]
-        if k == 1:
+        tag = "g"
+        if random_goals is not None:
+            first, count = random_goals
+            rr = np.random.default_rng(50 + k)
+            allg = sampling.sample_free_poses(m.boundary, m.case.obs, 64, rr, margin=6.0)
+            goals = [(allg[i][0], allg[i][1]) for i in range(first, first + count)]
+            tag = "r"
+            rng = np.random.default_rng(500 + 10 * k + first)
+        elif k == 1:
             for _ in range(2):
                 p = sampling.sample_free_poses(m.boundary, m.case.obs, 1, rng, margin=6.0)[0]
                 goals.append((p[0], p[1]))
         for gi, (gx, gy) in enumerate(goals):
+            if random_goals is not None:
+                gi = random_goals[0] + gi
             m.case.xf, m.case.yf = float(gx), float(gy)
             dj = ref_h.Dijkstra(m)
             b = m.boundary
@@ -398,7 +419,7 @@ def gen_hfield(cases=(1, 4)):
                     break
                 finally:
                     signal.alarm(0)
-            save(f"g5_hfield_c{k}_g{gi}.npz", dict(goal=np.array([gx, gy]), queries=np.array(res, dtype=np.float64),
+            save(f"g5_hfield_c{k}_{tag}{gi}.npz", dict(goal=np.array([gx, gy]), queries=np.array(res, dtype=np.float64),
                                                      closed_id=np.array([g.grid_id for g in dj.closedlist], dtype=np.int64),
                                                      closed_dist=np.array([g.distance for g in dj.closedlist], dtype=np.int64),
                                                      closed_x=np.array([g.grid_x for g in dj.closedlist]),
@@ -427,6 +448,8 @@ def gen_random(case_id, n, seed_off=0, timeout=1200):
     poses = sampling.sample_free_poses(m0.boundary, m0.case.obs, 2 * n, rng, margin=6.0, check=dc.check)
     for i in range(n):
         st, go = poses[2 * i], poses[2 * i + 1]
+        if os.path.exists(os.path.join(GOLD, f"g7_random_case{case_id}_s{seed_off}_{i}.npz")):
+            continue                      # the sampler is sequential: a longer run extends an earlier one
         t0 = time.time()
         d = run_plan(csv, cfg, start=st, goal=go, timeout=timeout)
         d["case"] = case_id
@@ -560,7 +583,12 @@ if __name__ == "__main__":
     elif what == "variants":
         gen_variants(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
     elif what == "random":
-        gen_random(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+        gen_random(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0,
+                   timeout=int(sys.argv[5]) if len(sys.argv) > 5 else 1200)
+    elif what == "hfield_random":          # hfield_random <case> <first> <count>
+        gen_hfield((int(sys.argv[2]),), random_goals=(int(sys.argv[3]), int(sys.argv[4])))
+    elif what == "g3rest":
+        gen_g3_rest()
     elif what == "synth":
         gen_synth()
     elif what == "corridor":

@@ -1,0 +1,114 @@
+"""BASELINE.json configs 3-5 at full size: problem builders and the GPU-vs-oracle comparison shared by
+tests/test_gpu_configs.py (collected by `pytest -m gpu`) and tests/config_sweep.py (the same runs as a script that
+prints throughput lines). Test infrastructure: it uses the CPU oracle as the checker."""
+import os
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CAP = 300                      # pop cap of the full-size runs (the reference has none; see DESIGN.md "Workload")
+THREADS = min(256, os.cpu_count() or 1)
+
+
+def same(r, w):
+    """GPU PlanResult r == oracle dict w: status, pops, the whole pop trace (node index, parent, grid id, pose, g, h, f,
+    gear -- bit for bit), counters, final path."""
+    if r.status != w["status"] or r.n_pops != w["n_pops"]:
+        return False
+    t, wt = r.trace, w["trace"]
+    if not np.array_equal(t[:, :10], wt[:len(t), :10]):
+        return False
+    c = r.counters
+    if any(c[k] != w[k] for k in ("n_closed", "n_open", "global_index", "n_rs", "n_checks")):
+        return False
+    if r.status == 0 and not np.array_equal(np.asarray(r.final_path), np.asarray(w["final_path"])):
+        return False
+    return True
+
+
+def free_pairs(m, dm, n_pairs, rng):
+    """SURVEY 8(d) sampler: footprint-free (GPU check) poses outside every obstacle polygon, paired up."""
+    from automatedvaletparking_amd import sampling
+    free = []
+    while len(free) < 2 * n_pairs:
+        cand = sampling.sample_free_poses(m.boundary, m.case.obs, 8 * n_pairs, rng, margin=6.0, reject=False)
+        hit = dm.check_batch(cand)
+        free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
+    poses = np.array(free[:2 * n_pairs])
+    return poses[0::2], poses[1::2]
+
+
+def plan_and_compare(m, veh, cfg, starts, goals, cap=CAP, threads=THREADS, max_nodes=8192):
+    """Plans the batch on the GPU (with traces) and on the oracle (portable libm, one problem per host thread).
+    Returns (results, indices that differ, gpu seconds, cpu seconds)."""
+    import torch
+    from automatedvaletparking_amd import _native, path_planner
+    from oracle import oracle
+    dm = _native.DeviceMap(m, veh, cfg, max_pops=cap)
+    bp = path_planner.BatchPlanner(dm, max_nodes=max_nodes)
+    bp.plan(starts[:8], goals[:8], max_trace=cap)                       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = bp.plan(starts, goals, max_trace=cap)
+    torch.cuda.synchronize()
+    t_gpu = time.perf_counter() - t0
+    o = oracle.Oracle(m, veh, cfg, max_pops=cap)
+    t1 = time.perf_counter()
+    with oracle.portable_libm():
+        with ThreadPoolExecutor(threads) as ex:
+            ws = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=cap), zip(starts, goals)))
+    t_cpu = time.perf_counter() - t1
+    bad = [i for i, (r, w) in enumerate(zip(res, ws)) if not same(r, w)]
+    return res, bad, t_gpu, t_cpu
+
+
+def c3_problems(k, cfg, veh, pairs=128, cap=CAP):
+    """C3, map k of 20: BenchmarkCase k rasterised on the device, `pairs` random pairs, seed 20260927 + k."""
+    from automatedvaletparking_amd import _native, costmap
+    m = costmap.Map(file=os.path.join(ROOT, "data", "BenchmarkCases", f"Case{k}.csv"), discrete_size=cfg["map_discrete_size"], device="cuda")
+    dm = _native.DeviceMap(m, veh, cfg, max_pops=cap)
+    st, go = free_pairs(m, dm, pairs, np.random.default_rng(20260927 + k))
+    return m, st, go
+
+
+def c4_map():
+    """C4: 24 m x 24 m, discrete_size 0.12 -> 200 x 200 nodes, 32 regular n-gons (seed 4)."""
+    from automatedvaletparking_amd import costmap, sampling
+    with tempfile.TemporaryDirectory() as td:
+        polys = sampling.synthetic_polygon_map(seed=4)
+        p = os.path.join(td, "c4.csv")
+        sampling.write_tpcap_csv(p, (12.0, 12.0, 0.0), (12.0, 12.0, 0.5), polys)
+        m = costmap.Map(file=p, discrete_size=0.12, device="cuda")
+    return m, polys
+
+
+def c4_poses(m, n=4096):
+    rng = np.random.default_rng(4)
+    poses = np.stack([rng.uniform(m.boundary[0] + 3, m.boundary[1] - 3, n), rng.uniform(m.boundary[2] + 3, m.boundary[3] - 3, n),
+                      rng.uniform(-np.pi, np.pi, n)], 1)
+    return poses, rng
+
+
+def c5_problems(cfg, n=1024):
+    """C5: parking lot (2 x 60 cars, one empty bay = goal), n starts in the aisle (seed 5), flag_radius 1e9 so that
+    the Reeds-Shepp shot runs at every pop."""
+    from automatedvaletparking_amd import costmap, sampling
+    obs, goal, aisle = sampling.parking_lot_map()
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "c5.csv")
+        sampling.write_tpcap_csv(p, (aisle[0] + 8.0, 0.5 * (aisle[2] + aisle[3]), 0.0), goal, obs)
+        m = costmap.Map(file=p, discrete_size=cfg["map_discrete_size"], device="cuda")
+    c5 = dict(cfg)
+    c5["flag_radius"] = 1e9
+    rng = np.random.default_rng(5)
+    starts = np.stack([rng.uniform(m.boundary[0] + 4, m.boundary[1] - 4, n), rng.uniform(aisle[2] + 1.2, aisle[3] - 1.2, n),
+                       rng.choice([0.0, np.pi], n) + rng.normal(0, 0.05, n)], 1)
+    goals = np.tile(np.array(goal), (n, 1))
+    return m, c5, starts, goals, obs
