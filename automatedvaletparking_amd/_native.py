@@ -184,7 +184,9 @@ class DeviceMap:
         self.use_current_stream()
 
     def use_current_stream(self):
-        """Queue kernels on torch's current stream of this device (so torch.cuda.Event timing sees them)."""
+        """Queue kernels on torch's current stream of this device. Called by every launch wrapper, so that the launch
+        is ordered against the tensors the caller has just produced on that stream (also under torch.cuda.stream(s))
+        and torch.cuda.Event timing sees it."""
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         chk(lib().avp_map_set_stream(self.h, C.c_void_p(s)), "avp_map_set_stream")
 
@@ -205,6 +207,7 @@ class DeviceMap:
     def check_batch_dev(self, x, y, th, out=None, kind: int = 0, variant: int = 0):
         """x, y, th: float64 CUDA tensors (SoA). Returns a uint8 CUDA tensor (asynchronous)."""
         torch = self.torch
+        self.use_current_stream()
         n = x.numel()
         if out is None:
             out = torch.empty(n, dtype=torch.uint8, device=x.device)
@@ -227,6 +230,7 @@ class DeviceMap:
         n = len(poses)
         if n == 0:
             return np.zeros((0, 4))
+        self.use_current_stream()
         soa = self.dev_tensor(poses.T.copy())
         out = self.empty((n, 4), self.torch.float64)
         chk(lib().avp_corridor_batch(self.h, C.c_double(float(expand_dis)), C.c_void_p(soa[0].data_ptr()), C.c_void_p(soa[1].data_ptr()),
@@ -235,30 +239,12 @@ class DeviceMap:
 
     # ---- Reeds-Shepp ---------------------------------------------------------------------------
     def rs_optimal_batch(self, q0, q1, maxc=None, maxpts: int = 128) -> dict:
-        torch = self.torch
-        q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(-1, 3)
-        q1 = np.ascontiguousarray(q1, dtype=np.float64).reshape(-1, 3)
-        n = len(q0)
-        maxc = float(self.params.maxc if maxc is None else maxc)
-        t0, t1 = self.dev_tensor(q0), self.dev_tensor(q1)
-        st = self.empty(n, torch.int32)
-        L = self.empty(n, torch.float64)
-        ty = self.empty((n, 5), torch.int8)
-        le = self.empty((n, 5), torch.float64)
-        npts = self.empty(n, torch.int32)
-        pts = self.zeros((n, max(maxpts, 1), 3), torch.float64)
-        dr = self.zeros((n, max(maxpts, 1)), torch.int8)
-        chk(lib().avp_rs_optimal_batch(self.h, C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()), C.c_double(maxc),
-                                       C.c_int64(n), C.c_int32(maxpts), C.c_void_p(st.data_ptr()), C.c_void_p(L.data_ptr()),
-                                       C.c_void_p(ty.data_ptr()), C.c_void_p(le.data_ptr()), C.c_void_p(npts.data_ptr()),
-                                       C.c_void_p(pts.data_ptr()) if maxpts > 0 else None,
-                                       C.c_void_p(dr.data_ptr()) if maxpts > 0 else None), "avp_rs_optimal_batch")
-        return dict(status=st.cpu().numpy(), L=L.cpu().numpy(), types=ty.cpu().numpy(), lens=le.cpu().numpy(),
-                    npts=npts.cpu().numpy(), pts=pts.cpu().numpy(), dirs=dr.cpu().numpy())
+        return rs_optimal_batch(q0, q1, float(self.params.maxc if maxc is None else maxc), maxpts, dm=self)
 
     # ---- heuristic field (diagnostic entry) ----------------------------------------------------------
     def hfield_queries(self, goal_xy, queries, force=None) -> dict:
         torch = self.torch
+        self.use_current_stream()
         q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 2)
         nq = len(q)
         f = np.zeros(nq, np.int32) if force is None else np.ascontiguousarray(force, dtype=np.int32)
@@ -283,6 +269,37 @@ class DeviceMap:
                 self.h = None
         except Exception:
             pass
+
+
+def rs_optimal_batch(q0, q1, maxc: float, maxpts: int = 128, dm: Optional[DeviceMap] = None) -> dict:
+    """avp_rs_optimal_batch. With a DeviceMap: its device and stream; without (the reference's module-level
+    `rs_curve.calc_optimal_path` needs no map): torch's current device, the NULL stream."""
+    torch = dm.torch if dm is not None else torch_cuda()
+    dev = f"cuda:{dm.device}" if dm is not None else f"cuda:{torch.cuda.current_device()}"
+    if dm is not None:
+        dm.use_current_stream()
+    q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(-1, 3)
+    q1 = np.ascontiguousarray(q1, dtype=np.float64).reshape(-1, 3)
+    n = len(q0)
+    t0, t1 = torch.as_tensor(q0, device=dev), torch.as_tensor(q1, device=dev)
+    st = torch.empty(n, dtype=torch.int32, device=dev)
+    L = torch.empty(n, dtype=torch.float64, device=dev)
+    ty = torch.empty((n, 5), dtype=torch.int8, device=dev)
+    le = torch.empty((n, 5), dtype=torch.float64, device=dev)
+    npts = torch.empty(n, dtype=torch.int32, device=dev)
+    pts = torch.zeros((n, max(maxpts, 1), 3), dtype=torch.float64, device=dev)
+    dr = torch.zeros((n, max(maxpts, 1)), dtype=torch.int8, device=dev)
+    if dm is None:
+        torch.cuda.current_stream().synchronize()      # the inputs were produced on torch's stream, the launch goes to the NULL stream
+    chk(lib().avp_rs_optimal_batch(dm.h if dm is not None else None, C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()),
+                                   C.c_double(float(maxc)), C.c_int64(n), C.c_int32(maxpts), C.c_void_p(st.data_ptr()),
+                                   C.c_void_p(L.data_ptr()), C.c_void_p(ty.data_ptr()), C.c_void_p(le.data_ptr()),
+                                   C.c_void_p(npts.data_ptr()), C.c_void_p(pts.data_ptr()) if maxpts > 0 else None,
+                                   C.c_void_p(dr.data_ptr()) if maxpts > 0 else None), "avp_rs_optimal_batch")
+    if dm is None:
+        torch.cuda.synchronize()
+    return dict(status=st.cpu().numpy(), L=L.cpu().numpy(), types=ty.cpu().numpy(), lens=le.cpu().numpy(),
+                npts=npts.cpu().numpy(), pts=pts.cpu().numpy(), dirs=dr.cpu().numpy())
 
 
 def device_map(park_map, vehicle, config, device: Optional[int] = None) -> DeviceMap:

@@ -24,6 +24,24 @@ static int32_t set_err(int32_t code, const char* fmt, const char* a = "", const 
         if (e_ != hipSuccess) return set_err(AVP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point that touches the device runs under this guard: the calling thread's current HIP device is
+// restored on every exit path (a process that drives several GPUs keeps its own current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool armed = false;
+    hipError_t enter(int device)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev == device) return hipSuccess;
+        e = hipSetDevice(device);
+        armed = e == hipSuccess;
+        return e;
+    }
+    ~DeviceGuard() { if (armed) (void)hipSetDevice(prev); }
+};
+#define AVP_ON_DEVICE(dev) DeviceGuard guard_; HIPCHK(guard_.enter(dev))
+
 struct avp_map {
     avp_params params;
     DevMap dev;
@@ -60,7 +78,7 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(AVP_ERR_NOGPU, "no HIP device visible");
     if (device < 0 || device >= ndev) return set_err(AVP_ERR_ARG, "avp_map_create: device ordinal out of range");
-    HIPCHK(hipSetDevice(device));
+    AVP_ON_DEVICE(device);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
 
@@ -124,7 +142,7 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
     memcpy(host.data() + oC, colStart.data(), colStart.size() * 4);
     memcpy(host.data() + oOcc, occ, (size_t)nx * ny);
     if (hipMemcpy(base, host.data(), off, hipMemcpyHostToDevice) != hipSuccess) {
-        hipFree(m->blob); delete m;
+        (void)hipFree(m->blob); delete m;
         return set_err(AVP_ERR_HIP, "hipMemcpy of the map blob failed");
     }
     d.X = (const double*)(base + oX); d.Y = (const double*)(base + oY);
@@ -139,8 +157,9 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
 AVP_EXPORT int32_t avp_map_destroy(avp_map* map)
 {
     if (!map) return AVP_OK;
-    hipSetDevice(map->device);
-    if (map->blob) hipFree(map->blob);
+    DeviceGuard g;
+    (void)g.enter(map->device);
+    if (map->blob) (void)hipFree(map->blob);
     delete map;
     return AVP_OK;
 }
@@ -155,7 +174,7 @@ AVP_EXPORT int32_t avp_map_set_stream(avp_map* map, void* hip_stream)
 AVP_EXPORT int32_t avp_sync(avp_map* map)
 {
     if (!map) return set_err(AVP_ERR_ARG, "null map");
-    HIPCHK(hipSetDevice(map->device));
+    AVP_ON_DEVICE(map->device);
     HIPCHK(hipStreamSynchronize(map->stream));
     return AVP_OK;
 }
@@ -165,7 +184,7 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
 {
     if (!map || n < 0 || (n > 0 && (!x || !y || !th || !out))) return set_err(AVP_ERR_ARG, "avp_check_batch: bad argument");
     if (n == 0) return AVP_OK;
-    HIPCHK(hipSetDevice(map->device));
+    AVP_ON_DEVICE(map->device);
     const DevMap& d = map->dev;
     if (kind == 1) {
         const int64_t blocks = (n + 255) / 256;
@@ -205,7 +224,7 @@ AVP_EXPORT int32_t avp_corridor_batch(avp_map* map, double expand_dis, const dou
 {
     if (!map || n < 0 || !(expand_dis >= 0.0) || (n > 0 && (!x || !y || !th || !out))) return set_err(AVP_ERR_ARG, "avp_corridor_batch: bad argument");
     if (n == 0) return AVP_OK;
-    HIPCHK(hipSetDevice(map->device));
+    AVP_ON_DEVICE(map->device);
     hipLaunchKernelGGL(corridor_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, map->stream, map->dev, map->params, expand_dis,
                        x, y, th, n, out);
     HIPCHK(hipGetLastError());
@@ -215,7 +234,7 @@ AVP_EXPORT int32_t avp_corridor_batch(avp_map* map, double expand_dis, const dou
 AVP_EXPORT int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos)
 {
     if (!map || n <= 0 || !x || !out_sin || !out_cos) return set_err(AVP_ERR_ARG, "avp_trig_batch: bad argument");
-    HIPCHK(hipSetDevice(map->device));
+    AVP_ON_DEVICE(map->device);
     hipLaunchKernelGGL(trig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, map->stream, x, n, out_sin, out_cos);
     HIPCHK(hipGetLastError());
     return AVP_OK;
@@ -224,7 +243,7 @@ AVP_EXPORT int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, doub
 AVP_EXPORT int32_t avp_ieee_batch(avp_map* map, const double* a, const double* b, int64_t n, double* q, double* r, double* h)
 {
     if (!map || n <= 0 || !a || !b || !q || !r || !h) return set_err(AVP_ERR_ARG, "avp_ieee_batch: bad argument");
-    HIPCHK(hipSetDevice(map->device));
+    AVP_ON_DEVICE(map->device);
     hipLaunchKernelGGL(ieee_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, map->stream, a, b, n, q, r, h);
     HIPCHK(hipGetLastError());
     return AVP_OK;
@@ -238,7 +257,8 @@ AVP_EXPORT int32_t avp_rasterize_edges(int32_t device, void* stream, const doubl
         return set_err(AVP_ERR_ARG, "avp_rasterize_edges: bad argument");
     if (n_edges == 0 || max_count <= 0) return AVP_OK;
     if (n_edges > 65535) return set_err(AVP_ERR_ARG, "avp_rasterize_edges: more than 65535 edges in one call");
-    if (device >= 0) HIPCHK(hipSetDevice(device));
+    DeviceGuard guard_;
+    if (device >= 0) HIPCHK(guard_.enter(device));
     RasterGrid g;
     g.X = xs; g.Y = ys; g.nx = nx; g.ny = ny; g.dx = dx; g.dy = dy; g.b0 = x0; g.b2 = y0;
     hipLaunchKernelGGL(rasterize_kernel, dim3((unsigned)((max_count + 63) / 64), (unsigned)n_edges), dim3(64), 0, (hipStream_t)stream,

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void check_distance_naive_kernel(DevMap m, avp
 // ---- production kernel ------------------------------------------------------------------------
 #define CHK_WAVES 4
 #define CHK_QCAP 4096          // queue entries per wave (u32)
-#define CHK_QDRAIN 512         // drain threshold: CHK_QCAP - 64 lanes * 56 rows
+#define CHK_QDRAIN 512         // early-drain threshold (keeps the narrow phase on full waves without waiting for a full queue)
+static_assert(CHK_QCAP >= 64 * 64, "one column step appends at most 64 lanes x 64 rows: it must fit an empty queue");
 #define CHK_FPW (sizeof(Footprint) / 8)
 
 __device__ __forceinline__ int wave_prefix_excl(int v, int lane, int& total)
@@ -154,8 +155,10 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
             }
             const int cnt = __popcll(bits0) + __popcll(bits1);
             int total;
-            int off = qtail + wave_prefix_excl(cnt, lane, total);
+            const int pre = wave_prefix_excl(cnt, lane, total);
             if (total == 0) continue;
+            if (qtail + total > CHK_QCAP) drain();            // (wave-uniform) never write past the queue, whatever the AABB height
+            int off = qtail + pre;
             const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)ix << 13);
             while (bits0) { const int bpos = __ffsll((unsigned long long)bits0) - 1; bits0 &= bits0 - 1; sQ[off++] = tag | (uint32_t)((w0 << 6) + bpos); }
             while (bits1) { const int bpos = __ffsll((unsigned long long)bits1) - 1; bits1 &= bits1 - 1; sQ[off++] = tag | (uint32_t)((w1 << 6) + bpos); }

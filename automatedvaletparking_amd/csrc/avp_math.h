@@ -9,6 +9,18 @@
 // x86-64 FMA build written out explicitly; the table is regenerated from first principles by
 // gen_sincos_table.py. tests/test_math_host.py checks bit equality against this host's libm.
 //
+// THIRD-PARTY NOTICE. avp_sin / avp_cos / avp_sincos and their helpers (the "glibc 2.35 s_sin.c restated" section:
+// branch thresholds, polynomial coefficients, the 3-part pi/2 reduction constants and the table layout) follow
+// the algorithm of the GNU C Library's sysdeps/ieee754/dbl-64/s_sin.c, dosincos.c and branred-free paths:
+//   IBM Accurate Mathematical Library, written by International Business Machines Corp.
+//   Copyright (C) 2001-2022 Free Software Foundation, Inc.
+//   The GNU C Library is free software; you can redistribute it and/or modify it under the terms of the GNU
+//   Lesser General Public License as published by the Free Software Foundation; either version 2.1 of the
+//   License, or (at your option) any later version.
+// The code here is an independent restatement of that published algorithm (no glibc source text is included); the
+// 440-entry table is regenerated from first principles by gen_sincos_table.py. avp_hypot restates CPython's
+// Modules/mathmodule.c vector_norm (Python Software Foundation License v2).
+//
 // Everything here compiles for the device (hipcc, gfx950) and for the host (gcc, used only by
 // the CPU-side unit tests of this header). Build with -ffp-contract=off: every fused operation
 // is spelled AVP_FMA.

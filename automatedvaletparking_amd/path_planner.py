@@ -100,6 +100,7 @@ class BatchPlanner:
         """starts_t/goals_t: (n,3) float64 CUDA tensors. Asynchronous; returns device tensors
         (results as uint8 (n, sizeof result), paths (n, max_path, 3) or None, trace or None)."""
         torch = self.dm.torch
+        self.dm.use_current_stream()
         n = starts_t.shape[0]
         slots = max(1, min(self.n_slots, n))
         ws = self._workspace(slots)
@@ -196,6 +197,14 @@ class PathPlanner:
     def a_star_plan(self) -> Tuple[List[List], List[List], PATH]:
         c = self.map.case
         r = self.plan_batch([[c.x0, c.y0, c.theta0]], [[c.xf, c.yf, c.thetaf]])[0]
+        # The reference has no capacity limits: when the node arena or the path buffer of the default
+        # workspace is exhausted (status CAPACITY) the search is repeated with both doubled, up to ~4 M nodes.
+        bp = self.batch_planner()
+        max_nodes, max_path = bp.max_nodes, bp.max_path
+        while r.status == 5 and max_nodes < (1 << 22):
+            max_nodes, max_path = 2 * max_nodes, 2 * max_path
+            big = BatchPlanner(bp.dm, max_nodes=max_nodes, n_slots=1, max_path=max_path)
+            r = big.plan([[c.x0, c.y0, c.theta0]], [[c.xf, c.yf, c.thetaf]])[0]
         if r.status in (0, 1):
             if not r.rs_types:
                 raise AttributeError("'NoneType' object has no attribute 'x'")       # path_planner.py:104

@@ -42,8 +42,22 @@ def path_from_arrays(types, lens, L, pts, dirs) -> PATH:
                 directions=[int(d) for d in dirs])
 
 
+def calc_optimal_path(sx, sy, syaw, gx, gy, gyaw, maxc, step_size=STEP_SIZE) -> PATH:
+    """The reference's scalar entry (`rs_curve.py:99-134`), same signature: the optimal Reeds-Shepp PATH from
+    (sx, sy, syaw) to (gx, gy, gyaw) with curvature `maxc`, sampled every `step_size` metres. One query through
+    the batched kernel (no map handle needed: avp_rs_optimal_batch accepts map = NULL)."""
+    if step_size != STEP_SIZE:
+        raise ValueError("the kernel samples at the reference's STEP_SIZE = 0.5 (rs_curve.py:27)")
+    from . import _native
+    r = _native.rs_optimal_batch([[sx, sy, syaw]], [[gx, gy, gyaw]], float(maxc), maxpts=1024)
+    return _paths_from_result(r)[0]
+
+
 def calc_optimal_path_batch(device_map, q0, q1, maxc=None, maxpts: int = 256) -> List[PATH]:
-    r = device_map.rs_optimal_batch(q0, q1, maxc=maxc, maxpts=maxpts)
+    return _paths_from_result(device_map.rs_optimal_batch(q0, q1, maxc=maxc, maxpts=maxpts))
+
+
+def _paths_from_result(r) -> List[PATH]:
     out = []
     for i in range(len(r["L"])):
         st = int(r["status"][i])

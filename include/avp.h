@@ -121,6 +121,8 @@ int32_t avp_corridor_batch(avp_map* map, double expand_dis, const double* x, con
  * capacity), L[i] total length [m], types[i*5+k] in {0 S, 1 L, 2 R, -1 unused}, lens[i*5+k] signed
  * segment lengths [m], npts[i], xyyaw[(i*maxpts+j)*3 + {0,1,2}] world-frame samples every 0.5 m
  * (yaw wrapped by pi_2_pi), dir[i*maxpts+j] in {+1,-1}. maxpts = 0 (xyyaw/dir NULL) skips sampling.
+ * map may be NULL (the reference's function is module-level and needs no map): the launch then goes to the
+ * calling thread's current device on the NULL stream.
  */
 int32_t avp_rs_optimal_batch(avp_map* map, const double* q0, const double* q1, double maxc, int64_t n,
                              int32_t maxpts, int32_t* status, double* L, int8_t* types, double* lens,
