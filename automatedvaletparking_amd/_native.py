@@ -14,14 +14,14 @@ from typing import Optional
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libavp_hip.so")
+LIB_PATH = os.environ.get("AVP_HIP_LIB") or os.path.join(_PKG, "libavp_hip.so")    # AVP_HIP_LIB: kernel-variant experiments (scripts/variant_bench.py)
 HOSTMATH_PATH = os.path.join(_PKG, "libavp_hostmath.so")
 AVP_MAX_STEER = 16
 
 EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
     "avp_check_batch", "avp_corridor_batch", "avp_trig_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
-    "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch",
+    "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch", "avp_plan_batch_profile",
     "avp_hfield_id_capacity", "avp_hfield_queries", "avp_rasterize_edges",
 ]
 

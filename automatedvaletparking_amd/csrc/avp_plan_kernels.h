@@ -34,13 +34,16 @@
 #define PL_RS_CAP 1024                // samples of one RS shot
 #define PL_UNSEEN 0x7fffffffu
 #define PL_TRACE_W 11
+#define PL_SCHED_ROUNDS 4             // rounds of the RS word schedule: ceil(12 solver chunks of <= 64 lanes / (PL_THREADS / 64) waves) with slack
 #define PL_FLAG_T 1
 // phase timers (thread 0, s_memtime): init, heap pop, (two unused slots), speculative resolution || shot sampling
 // and checks, children stage || sub-step checks, RS words .. set_path / arg-min || sampler replay, the rest of the
 // resolution (fast path when not speculated, slow path), of which sweep extensions, finish
 enum { PH_INIT = 0, PH_POP, PH_SHOT_RS, PH_SHOT_SAMPLE, PH_SHOT_CHECK, PH_CHILD, PH_CHILD_RS, PH_RESOLVE, PH_SWEEP, PH_FINISH };
-#define PH_T0() const long long ph_t0_ = clock64()
-#define PH_ADD(k) do { if (threadIdx.x == 0) s.phase[k] += clock64() - ph_t0_; } while (0)
+// The timers are compiled into the PROFILE instantiation only (avp_plan_batch_profile): s_memtime instrumentation costs
+// ~10 % of the wave cycles, so the production kernel carries none and reports phase_cycles = 0.
+#define PH_NOW() (PROFILE ? clock64() : 0ll)
+#define PH_ACC(k, t0) do { if (PROFILE && threadIdx.x == 0) s.phase[k] += clock64() - (t0); } while (0)
 
 struct PlNode {
     double x, y, th, g, h, f;
@@ -56,7 +59,7 @@ struct avp_plan_result_dev {          // mirrors avp_plan_result in include/avp.
     double rs_lengths[5];
     double rs_L;
     double rs_start[3];               // RS sample 0 (the popped node's pose)
-    int32_t rs_dir0, pad;
+    int32_t rs_dir0, slot;
     int64_t phase_cycles[10];         // diagnostics: shader cycles per phase (see PH_* below)
 };
 
@@ -118,7 +121,7 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 }
 
 // ---- lane-per-pose collision test through the column bitmaps (reads L1/L2-resident tables) -----
-__device__ __noinline__ bool pl_check_pose(const DevMap& m, const avp_params& p, double x, double y, double th)
+__device__ __forceinline__ bool pl_check_pose(const DevMap& m, const avp_params& p, double x, double y, double th)
 {
     if (p.checker_kind == 1) {
         double cs, sn;
@@ -230,7 +233,7 @@ struct PlShared {
     int32_t fold_idx[PL_THREADS / 64];
     MapTabs mt;                       // the map tables as the kernel sees them (LDS copies when staged)
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
-    double k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
+    double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
     long long phase[10];
@@ -243,7 +246,8 @@ struct PlShared {
     // RS word results: [query][word] ok + 5 lengths; kept candidates per query
     RsFrame frame[PL_RSQ];
     int32_t sched_cnt, sched_n;       // lane schedule of the (word, query) items for sched_cnt queries
-    uint16_t sched[4 * PL_THREADS];   // [round][wave][lane] -> word << 4 | query, 0xffff = idle lane
+    uint16_t sched[PL_SCHED_ROUNDS * PL_THREADS];   // [round][wave][lane] -> word << 4 | query, 0xffff = idle lane
+    int32_t sched_load[PL_THREADS / 64], sched_rounds[PL_THREADS / 64];   // work arrays of pl_rs_build_schedule
     uint8_t w_ok[PL_RSQ * 46];        // word valid
     uint8_t w_acc[PL_RSQ * 46];       // word accepted by set_path
     uint8_t w_err[PL_RSQ];            // assertion L >= 0.01 failed for an accepted word
@@ -385,9 +389,10 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, PlShared& s, int col, int 
 }
 
 // Expand bucket s.E (all threads). Each thread handles (entry, neighbour) pairs.
+template <bool PROFILE>
 AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
 {
-    const long long t_sw = clock64();
+    const long long t_sw = PH_NOW();
     const int q = s.E & (PL_NQ - 1);
     const uint32_t cnt = min(s.qcount[q], (uint32_t)PL_QCAP);
     __syncthreads();
@@ -411,7 +416,7 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
         pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { s.qcount[q] = 0; s.E += 1; s.phase[PH_SWEEP] += clock64() - t_sw; }
+    if (threadIdx.x == 0) { s.qcount[q] = 0; s.E += 1; if (PROFILE) s.phase[PH_SWEEP] += clock64() - t_sw; }
     __syncthreads();
 }
 
@@ -429,6 +434,7 @@ AVP_D bool pl_hquery_hit(const DevMap& m, const PlShared& s, int64_t id, uint32_
     return false;
 }
 
+template <bool PROFILE = false>
 AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, PlShared& s, int64_t id)
 {
     __syncthreads();
@@ -444,7 +450,7 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, PlShared& s, int64_t
             __syncthreads();
             continue;
         }
-        pl_expand_bucket(m, w, s);
+        pl_expand_bucket<PROFILE>(m, w, s);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -561,34 +567,34 @@ AVP_D double pl_node_cost(const avp_params& p, int node_forward, double node_the
 // every word solver any of its lanes runs, so the items are grouped into chunks of <= 64 lanes of ONE solver
 // and the chunks are spread over the waves (longest-processing-time first, measured solver costs), each
 // chunk in its own round of its wave: sched[round][wave][lane].
+static __device__ const int8_t PL_SCHED_WORDS[9][8] = { { 18, 19, 20, 21, -1, -1, -1, -1 }, { 22, 23, 24, 25, -1, -1, -1, -1 }, { 0, 1, -1, -1, -1, -1, -1, -1 },
+                                                        { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 }, { 6, 7, 8, 9, -1, -1, -1, -1 },
+                                                        { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 }, { 42, 43, 44, 45, -1, -1, -1, -1 } };
+static __device__ const int32_t PL_SCHED_COST[9] = { 106, 85, 78, 60, 60, 59, 45, 43, 30 };
 AVP_D void pl_rs_build_schedule(PlShared& s, int nq)
 {
     // solvers by descending cost (x100 cycles per call of one wave, scripts/microbench/rs_words.hip on MI355X):
     // LRLRn, LRLRp (tauOmega: 5 sin/cos + acos + atan2), SLS (two nearly-CR tan), LRL, LRSL, LSR, LRSR, LSL, LRSLR
-    const int8_t words[9][8] = { { 18, 19, 20, 21, -1, -1, -1, -1 }, { 22, 23, 24, 25, -1, -1, -1, -1 }, { 0, 1, -1, -1, -1, -1, -1, -1 },
-                                 { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 }, { 6, 7, 8, 9, -1, -1, -1, -1 },
-                                 { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 }, { 42, 43, 44, 45, -1, -1, -1, -1 } };
-    const int cost[9] = { 106, 85, 78, 60, 60, 59, 45, 43, 30 };
+    // (runs once per workgroup and per child count, on one thread; its work arrays live in LDS: no stack objects)
     const int nwave = PL_THREADS / 64;
-    int load[PL_THREADS / 64], rounds[PL_THREADS / 64];
-    for (int w = 0; w < nwave; w++) { load[w] = 0; rounds[w] = 0; }
-    for (int i = 0; i < 4 * PL_THREADS; i++) s.sched[i] = 0xffff;
+    for (int w = 0; w < nwave; w++) { s.sched_load[w] = 0; s.sched_rounds[w] = 0; }
+    for (int i = 0; i < PL_SCHED_ROUNDS * PL_THREADS; i++) s.sched[i] = 0xffff;
     int maxround = 0;
     for (int sv = 0; sv < 9; sv++) {
         int nw = 0;
-        while (nw < 8 && words[sv][nw] >= 0) nw++;
+        while (nw < 8 && PL_SCHED_WORDS[sv][nw] >= 0) nw++;
         const int items = nw * nq;
         for (int base = 0; base < items; base += 64) {
             const int cnt = items - base < 64 ? items - base : 64;
             int best = 0;
-            for (int w = 1; w < nwave; w++) if (load[w] < load[best]) best = w;
-            const int r = rounds[best]++;
-            load[best] += cost[sv];
-            if (r >= 4) continue;                         // cannot happen for nq <= 16
+            for (int w = 1; w < nwave; w++) if (s.sched_load[w] < s.sched_load[best]) best = w;
+            const int r = s.sched_rounds[best]++;
+            s.sched_load[best] += PL_SCHED_COST[sv];
+            if (r >= PL_SCHED_ROUNDS) continue;           // cannot happen for nq <= PL_RSQ (static_assert below)
             if (r + 1 > maxround) maxround = r + 1;
             for (int k = 0; k < cnt; k++) {
                 const int it = base + k;
-                s.sched[r * PL_THREADS + best * 64 + k] = (uint16_t)((words[sv][it / nq] << 4) | (it % nq));
+                s.sched[r * PL_THREADS + best * 64 + k] = (uint16_t)((PL_SCHED_WORDS[sv][it / nq] << 4) | (it % nq));
             }
         }
     }
@@ -633,30 +639,32 @@ AVP_D void pl_rs_accept_group(PlShared& s, const avp_params& p, int q, int g)
 {
     // The unused tail of a word's 5 lengths is 0.0 (rs_word), so the sums below always run over all 5 entries:
     // same values (x + 0.0), but the LDS loads no longer depend on the per-word segment count and issue together.
+    // Fully unrolled over the group's (<= 4) words: kept[][] stays in registers (no stack object).
     unsigned accmask = 0;                     // accepted words of this group so far (bit j = RS_GROUPS[g][j])
     double kept[4][5];                        // lengths of the group's words seen so far
+    bool live = true;
+#pragma unroll
     for (int j = 0; j < 4; j++) {
         const int wd = RS_GROUPS[g][j];
-        if (wd < 0) break;
-        const int slot = q * 46 + wd;
-        if (!s.w_ok[slot]) continue;
+        if (wd < 0) live = false;
+        const int slot = q * 46 + (wd < 0 ? 0 : wd);
+        const bool ok = live && s.w_ok[slot];
         double l[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) { l[i] = s.w_l[slot][i]; kept[j][i] = l[i]; }
         bool dup = false;
 #pragma unroll
         for (int e = 0; e < 3; e++) {
-            if (e >= j || dup || !(accmask & (1u << e))) continue;
+            if (e >= j) continue;
             double sum = 0;
 #pragma unroll
             for (int i = 0; i < 5; i++) sum = sum + (kept[e][i] - l[i]);
-            if (sum <= 0.01) dup = true;
+            if ((accmask & (1u << e)) && !dup && sum <= 0.01) dup = true;
         }
-        if (dup) continue;
         double L = 0;
 #pragma unroll
         for (int i = 0; i < 5; i++) L = L + fabs(l[i]);
-        if (L >= 1000.0) continue;
+        if (!ok || dup || L >= 1000.0) continue;
         if (!(L >= 0.01)) { s.w_err[q] = 1; continue; }
         accmask |= 1u << j;
         s.w_acc[slot] = 1; s.w_Ln[slot] = L; s.w_Lm[slot] = L / p.maxc;
@@ -688,9 +696,11 @@ AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
     if (s.w_err[q]) return 2;
     if (!acc) return 1;
     const RsWord W = RS_WORDS[wd];
-    const int8_t ty[5] = { W.a, W.b, W.c, W.d, W.e };
     out.n = W.n;
-    for (int i = 0; i < AVP_RS_MAXSEG; i++) { out.t[i] = i < W.n ? ty[i] : (int8_t)-1; out.l[i] = s.w_l[q * 46 + wd][i]; }
+    out.t[0] = 0 < W.n ? W.a : (int8_t)-1; out.t[1] = 1 < W.n ? W.b : (int8_t)-1; out.t[2] = 2 < W.n ? W.c : (int8_t)-1;
+    out.t[3] = 3 < W.n ? W.d : (int8_t)-1; out.t[4] = 4 < W.n ? W.e : (int8_t)-1;
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) out.l[i] = s.w_l[q * 46 + wd][i];
     out.L = s.w_Ln[q * 46 + wd];
     return 0;
 }
@@ -972,7 +982,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     wave_sync();
 }
 
-template <bool STAGE>
+template <bool STAGE, bool PROFILE>
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                           const double* __restrict__ goals, int64_t n, int32_t maxNodes,
                                                           char* __restrict__ workspace, unsigned int* __restrict__ counter,
@@ -988,8 +998,16 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
     const int tid = threadIdx.x;
     if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; }
-    if (tid < AVP_MAX_STEER) { s.k_dth_dt[tid] = p.dth_dt[tid]; for (int j = 0; j < 4; j++) s.k_dth_ddt[tid][j] = p.dth_ddt[tid][j]; }
-    if (tid < 4) s.k_travel_ddt[tid] = p.travel_ddt[tid];
+    // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
+    // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
+#pragma unroll
+    for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
+        s.k_steer[k] = p.steer[k]; s.k_dth_dt[k] = p.dth_dt[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) s.k_dth_ddt[k][j] = p.dth_ddt[k][j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (tid == k) s.k_travel_ddt[k] = p.travel_ddt[k];
     if (tid < PL_MAXCHILD * 4 && p.n_sub > 0 && p.n_steer > 0) { const int ci = tid / p.n_sub; s.sub_child[tid] = (int8_t)ci; s.sub_j[tid] = (int8_t)(tid - ci * p.n_sub); s.sub_steer[tid] = (int8_t)(ci % p.n_steer); }
     // STAGE: the column bitmaps and node coordinates of the map live in LDS behind PlShared for the whole
     // (persistent) lifetime of the workgroup; otherwise they are read through L1/L2
@@ -1018,7 +1036,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
 
         // ---- init ------------------------------------------------------------------------------
-        const long long t_init0 = clock64();
+        const long long t_init0 = PH_NOW();
         for (int64_t i = tid; i < dims.hashCap; i += PL_THREADS) w.hash[i] = 0;
         if (tid == 0) {
             s.status = 0; s.done = 0;
@@ -1033,7 +1051,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         if (s.status == 0) {
             // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
             const int64_t sid = avp_pos_to_index(m, sx, sy);
-            pl_hquery_miss(m, w, s, sid);
+            pl_hquery_miss<PROFILE>(m, w, s, sid);
             if (tid == 0) {
                 if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
                 else {
@@ -1048,12 +1066,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
         }
 
-        if (tid == 0) s.phase[PH_INIT] += clock64() - t_init0;
+        PH_ACC(PH_INIT, t_init0);
         int64_t n_pops = 0;
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
         while (s.status == 0 && !s.done) {
             __syncthreads();
-            { PH_T0();
+            { const long long t_pop = PH_NOW();
             if (tid == 0) {
                 if (s.nheap == 0) { s.status = 1; }
                 else if (n_pops >= max_pops) { s.status = 4; }
@@ -1063,7 +1081,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     w.nodes[c].state = 3;
                 }
             }
-            PH_ADD(PH_POP); }
+            PH_ACC(PH_POP, t_pop); }
             __syncthreads();
             if (s.status != 0) break;
             const PlNode cn = w.nodes[s.cur];
@@ -1071,12 +1089,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
                 t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(m, cn.x, cn.y);
                 t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
-                t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : p.steer[cn.steer_i];
+                t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : s.k_steer[cn.steer_i];
             }
             n_pops++;
 
             // ---- children poses (expand_node :134-151) + try_reach_goal radius test (:308-312) ----------
-            const long long t_d = clock64();
+            const long long t_d = PH_NOW();
             const bool one_pass = nchild + 1 <= PL_RSQ;          // shot + all children fit one RS pass
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
             const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
@@ -1129,8 +1147,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
             for (int t = tid; t < nsubs; t += PL_THREADS)
                 if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
-            const long long t_e = clock64();
-            if (tid == 0) s.phase[PH_CHILD] += t_e - t_d;
+            const long long t_e = PH_NOW();
+            if (PROFILE && tid == 0) s.phase[PH_CHILD] += t_e - t_d;
 
             // read here, a full barrier before the speculative resolution on wave 0 starts to move s.nnodes
             const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
@@ -1192,8 +1210,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     __syncthreads();
                 }
             }
-            const long long t_f0 = clock64();
-            if (tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
+            const long long t_f0 = PH_NOW();
+            if (PROFILE && tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
             if (in_radius && s.rs_status) { if (tid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? 5 : 3; __syncthreads(); break; }
             const long long t_g = t_f0;
             // The outcome of the shot is not an input of the child resolution, so when the resolution can take its
@@ -1269,8 +1287,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 }
             }
             pl_lds_barrier();
-            const long long t_f = clock64();
-            if (tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
+            const long long t_f = PH_NOW();
+            if (PROFILE && tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
             if (s.status != 0 || s.done) break;
 
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
@@ -1345,7 +1363,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 }
                 __syncthreads();
                 if (!s.need_sweep) break;
-                pl_hquery_miss(m, w, s, s.pending_id);
+                pl_hquery_miss<PROFILE>(m, w, s, s.pending_id);
                 if (tid == 0) s.have_d = 1;
                 if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
                 __syncthreads();
@@ -1356,12 +1374,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     s.nclosed++; s.closed_nonempty = 1;
                     s.global_index += nchild;
                 }
-                s.phase[PH_RESOLVE] += clock64() - t_f;
+                if (PROFILE) s.phase[PH_RESOLVE] += clock64() - t_f;
             }
             __syncthreads();
         }
         __syncthreads();
-        const long long t_fin = clock64();
+        const long long t_fin = PH_NOW();
         if (s.status == 1 && s.cur >= 0 && s.in_radius && s.rs.n > 0 && s.rs_status == 0 && s.collision) {
             // the reference hands back the last (colliding) shot when the open list runs empty
             // (path_planner.py:100-108): the early exit above may have left samples unproduced
@@ -1373,20 +1391,33 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         }
 
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
+        // Thread 0 writes the record straight to global memory (no local copy of the struct: its dynamically
+        // indexed arrays would be a stack object). The counts and the RS fields are filled whether or not the
+        // caller asked for way-points (paths == NULL).
         if (tid == 0) {
-            avp_plan_result_dev r;
-            memset(&r, 0, sizeof(r));
-            r.status = s.status; r.n_pops = (int32_t)n_pops; r.in_radius_last = s.in_radius; r.rs_collision = s.collision;
+            avp_plan_result_dev& r = results[pid];
+            int32_t status = s.status;
+            r.n_pops = (int32_t)n_pops; r.in_radius_last = s.in_radius; r.rs_collision = s.collision;
             r.n_checks = s.n_checks; r.n_rs = s.n_rs; r.n_closed = s.nclosed; r.n_open = s.nheap;
             r.h_cells = s.h_cells; r.h_misses = s.h_misses; r.global_index = s.global_index; r.n_nodes = s.nnodes;
+            r.slot = (int32_t)blockIdx.x;                  // the slot (persistent workgroup) that ran the problem
             double* out = paths ? paths + (size_t)pid * max_path * 4 : nullptr;
-            if (out && s.cur >= 0 && (s.status == 0 || s.status == 1)) {
+            int32_t n_astar = 0, n_final = 0, rs_n = 0, n_rs_pts = 0, rs_dir0 = 0;
+            double rs_L = 0.0, rs0 = 0.0, rs1 = 0.0, rs2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) r.rs_types[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) r.rs_lengths[k] = 0.0;
+            if (s.cur >= 0 && (status == 0 || status == 1)) {
                 // chain child -> root
                 int32_t len = 0;
                 for (int32_t node = s.cur; node >= 0; node = w.nodes[node].parent_pos) { len++; if (w.nodes[node].index == 0) break; }
                 int32_t cnt = 0;
                 bool over = false;
-                auto push = [&](double X, double Y, double T, double D) { if (cnt < max_path) { out[4 * cnt] = X; out[4 * cnt + 1] = Y; out[4 * cnt + 2] = T; out[4 * cnt + 3] = D; cnt++; } else over = true; };
+                auto push = [&](double X, double Y, double T, double D) {
+                    if (!out) { cnt++; return; }
+                    if (cnt < max_path) { out[4 * cnt] = X; out[4 * cnt + 1] = Y; out[4 * cnt + 2] = T; out[4 * cnt + 3] = D; cnt++; } else over = true;
+                };
                 // walk from the root: position k of the chain is reached by (len-1-k) parent hops
                 int32_t prev = -1;
                 for (int32_t k = 0; k < len; k++) {
@@ -1394,30 +1425,33 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     for (int32_t hop = 0; hop < len - 1 - k; hop++) node = w.nodes[node].parent_pos;
                     const PlNode& nd = w.nodes[node];
                     if (k == 0) push(nd.x, nd.y, nd.th, 0.0);
+                    else if (!out) cnt += p.n_sub;
                     else {
                         const PlNode& par = w.nodes[prev];
                         for (int j = 0; j < p.n_sub; j++) {
-                            const double td = nd.forward ? p.travel_ddt[j] : -p.travel_ddt[j];
-                            const double th_j = avp_pi_2_pi(par.th + p.dth_ddt[nd.steer_i][j]);
+                            const double td = nd.forward ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
+                            const double th_j = avp_pi_2_pi(par.th + s.k_dth_ddt[nd.steer_i][j]);
                             push(par.x + td * avp_cos(th_j), par.y + td * avp_sin(th_j), th_j, 0.0);
                         }
                     }
                     prev = node;
                 }
-                r.n_astar = cnt;
+                n_astar = cnt;
                 if (s.rs.n > 0 && s.rs_status == 0 && s.in_radius) {
-                    r.rs_n = s.rs.n; r.rs_L = s.rs.L / p.maxc;
+                    rs_n = s.rs.n; rs_L = s.rs.L / p.maxc;
                     for (int k = 0; k < s.rs.n; k++) { r.rs_types[k] = s.rs.t[k]; r.rs_lengths[k] = s.rs.l[k] / p.maxc; }
-                    r.n_rs_pts = s.rs_npts;
-                    r.rs_start[0] = w.rsbuf[0]; r.rs_start[1] = w.rsbuf[1]; r.rs_start[2] = w.rsbuf[2]; r.rs_dir0 = w.rsdir[0];
+                    n_rs_pts = s.rs_npts;
+                    rs0 = w.rsbuf[0]; rs1 = w.rsbuf[1]; rs2 = w.rsbuf[2]; rs_dir0 = w.rsdir[0];
                     for (int k = 1; k < s.rs_npts; k++) push(w.rsbuf[3 * k], w.rsbuf[3 * k + 1], w.rsbuf[3 * k + 2], (double)w.rsdir[k]);
-                    r.n_final = cnt;
+                    n_final = cnt;
                 }
-                if (over) r.status = 5;
+                if (over) status = 5;
             }
-            s.phase[PH_FINISH] += clock64() - t_fin;
-            for (int k = 0; k < 10; k++) r.phase_cycles[k] = s.phase[k];
-            results[pid] = r;
+            r.status = status; r.n_astar = n_astar; r.n_final = n_final; r.rs_n = rs_n; r.n_rs_pts = n_rs_pts;
+            r.rs_L = rs_L; r.rs_start[0] = rs0; r.rs_start[1] = rs1; r.rs_start[2] = rs2; r.rs_dir0 = rs_dir0;
+            if (PROFILE) s.phase[PH_FINISH] += clock64() - t_fin;
+#pragma unroll
+            for (int k = 0; k < 10; k++) r.phase_cycles[k] = PROFILE ? s.phase[k] : 0;
         }
         __syncthreads();
     }

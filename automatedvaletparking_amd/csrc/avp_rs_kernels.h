@@ -21,6 +21,39 @@
 enum { RS_S = 0, RS_L = 1, RS_R = 2 };
 #define RS_KEEP_MAX 24
 
+// ---- scalar maths as CALLED leaf functions (PL_LIBM_CALLS) ----------------------------------------------------
+// Fully inlined, the double-double sin/cos, atan2, asin/acos, tan, fmod and hypot bodies make up 60 % of the planner
+// kernel's 290 KB of code -- several times the instruction cache a pair of CUs shares -- and every wave of a
+// workgroup runs a different part of it. As leaf functions (no stack use: arguments and results in registers)
+// each body exists once. Same arithmetic, same results; only the code layout changes. The collision kernels
+// (avp_check_kernels.h, included before this header) keep the inlined forms.
+#ifndef PL_LIBM_CALLS
+#define PL_LIBM_CALLS 0
+#endif
+#if PL_LIBM_CALLS && defined(__HIP_DEVICE_COMPILE__)
+struct AvpSinCos { double s, c; };
+__device__ __noinline__ AvpSinCos avp_sincos_fn(double x) { AvpSinCos r; avp_sincos(x, r.s, r.c); return r; }
+__device__ __noinline__ double avp_sin_fn(double x) { return avp_sin(x); }
+__device__ __noinline__ double avp_cos_fn(double x) { return avp_cos(x); }
+__device__ __noinline__ double avp_atan2_fn(double y, double x) { return avp_atan2(y, x); }
+__device__ __noinline__ double avp_asin_fn(double x) { return avp_asin(x); }
+__device__ __noinline__ double avp_acos_fn(double x) { return avp_acos(x); }
+__device__ __noinline__ double avp_tan_fn(double x) { return avp_tan(x); }
+__device__ __noinline__ double avp_M_fn(double x) { return avp_M(x); }
+__device__ __noinline__ double avp_pi_2_pi_fn(double x) { return avp_pi_2_pi(x); }
+__device__ __noinline__ double avp_hypot_fn(double a, double b) { return avp_hypot(a, b); }
+#define avp_sincos(x, s_, c_) do { const AvpSinCos r_ = avp_sincos_fn(x); (s_) = r_.s; (c_) = r_.c; } while (0)
+#define avp_sin(x) avp_sin_fn(x)
+#define avp_cos(x) avp_cos_fn(x)
+#define avp_atan2(y, x) avp_atan2_fn(y, x)
+#define avp_asin(x) avp_asin_fn(x)
+#define avp_acos(x) avp_acos_fn(x)
+#define avp_tan(x) avp_tan_fn(x)
+#define avp_M(x) avp_M_fn(x)
+#define avp_pi_2_pi(x) avp_pi_2_pi_fn(x)
+#define avp_hypot(a, b) avp_hypot_fn(a, b)
+#endif
+
 struct RsPath {
     int n;                 // segments (3..5); 0 = none
     int8_t t[AVP_RS_MAXSEG];
@@ -291,7 +324,7 @@ AVP_D RsFrame rs_frame(double q0x, double q0y, double q0t, double q1x, double q1
 }
 
 // Word w of the 46 (source order): returns validity and the signed normalised segment lengths.
-__device__ __noinline__ bool rs_word(int w, const RsFrame& f, double l[5])
+__device__ __forceinline__ bool rs_word(int w, const RsFrame& f, double l[5])
 {
     const RsWord W = RS_WORDS[w];
     const double bx = W.back ? f.xb : f.x0, by = W.back ? f.yb : f.y0;

@@ -31,7 +31,7 @@ class AvpPlanResult(C.Structure):
                 ("n_checks", C.c_int64), ("n_rs", C.c_int64), ("n_closed", C.c_int64), ("n_open", C.c_int64),
                 ("h_cells", C.c_int64), ("h_misses", C.c_int64), ("global_index", C.c_int64), ("n_nodes", C.c_int64),
                 ("rs_types", C.c_int8 * 8), ("rs_lengths", C.c_double * 5), ("rs_L", C.c_double),
-                ("rs_start", C.c_double * 3), ("rs_dir0", C.c_int32), ("pad", C.c_int32), ("phase_cycles", C.c_int64 * 10)]
+                ("rs_start", C.c_double * 3), ("rs_dir0", C.c_int32), ("slot", C.c_int32), ("phase_cycles", C.c_int64 * 10)]
 
 
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_pops", "<i4"), ("n_astar", "<i4"), ("n_rs_pts", "<i4"), ("n_final", "<i4"),
@@ -39,7 +39,7 @@ RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_pops", "<i4"), ("n_astar", "<i4"
                          ("n_checks", "<i8"), ("n_rs", "<i8"), ("n_closed", "<i8"), ("n_open", "<i8"), ("h_cells", "<i8"),
                          ("h_misses", "<i8"), ("global_index", "<i8"), ("n_nodes", "<i8"),
                          ("rs_types", "i1", (8,)), ("rs_lengths", "<f8", (5,)), ("rs_L", "<f8"),
-                         ("rs_start", "<f8", (3,)), ("rs_dir0", "<i4"), ("pad", "<i4"), ("phase_cycles", "<i8", (10,))])
+                         ("rs_start", "<f8", (3,)), ("rs_dir0", "<i4"), ("slot", "<i4"), ("phase_cycles", "<i8", (10,))])
 assert RESULT_DTYPE.itemsize == C.sizeof(AvpPlanResult)
 
 
@@ -96,9 +96,10 @@ class BatchPlanner:
             self._ws_slots = slots
         return self._ws
 
-    def plan_dev(self, starts_t, goals_t, want_paths=True, max_trace: int = 0):
+    def plan_dev(self, starts_t, goals_t, want_paths=True, max_trace: int = 0, profile: bool = False):
         """starts_t/goals_t: (n,3) float64 CUDA tensors. Asynchronous; returns device tensors
-        (results as uint8 (n, sizeof result), paths (n, max_path, 3) or None, trace or None)."""
+        (results as uint8 (n, sizeof result), paths (n, max_path, 3) or None, trace or None).
+        profile=True runs the instrumented kernel (phase_cycles filled)."""
         torch = self.dm.torch
         self.dm.use_current_stream()
         n = starts_t.shape[0]
@@ -107,7 +108,8 @@ class BatchPlanner:
         res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
         paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
         trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
-        _native.chk(_native.lib().avp_plan_batch(
+        entry = _native.lib().avp_plan_batch_profile if profile else _native.lib().avp_plan_batch
+        _native.chk(entry(
             self.dm.h, C.c_void_p(starts_t.data_ptr()), C.c_void_p(goals_t.data_ptr()), C.c_int64(n), C.c_int32(slots),
             C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
             C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),

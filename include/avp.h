@@ -152,10 +152,11 @@ typedef struct avp_plan_result {
     double rs_lengths[5];    /* signed segment lengths [m]                                         */
     double rs_L;             /* total RS length [m]                                                */
     double rs_start[3];      /* sample 0 of the last RS shot = pose of the last popped node        */
-    int32_t rs_dir0, pad;    /* its direction flag                                                 */
-    int64_t phase_cycles[10];/* diagnostics: shader cycles spent per phase of the problem (init, heap pop,
-                                shot words, shot sampling, shot checks, children, children RS, resolution,
-                                of which sweep, finish)                                              */
+    int32_t rs_dir0;         /* its direction flag                                                 */
+    int32_t slot;            /* the persistent workgroup (0 .. n_slots-1) that ran the problem      */
+    int64_t phase_cycles[10];/* diagnostics, avp_plan_batch_profile only (else 0): shader cycles per phase of the
+                                problem (init, heap pop, -, -, speculative resolution || shot checks, children ||
+                                sub-steps, RS words .. replay, rest of the resolution, of which sweep, finish) */
 } avp_plan_result;
 
 /*
@@ -174,6 +175,13 @@ int32_t avp_sizeof_plan_result(void);
 int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
                        int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
                        double* paths, int32_t max_path, double* trace, int32_t max_trace);
+
+/* The same call through the instrumented instantiation of the kernel: results[i].phase_cycles holds the shader
+ * cycles thread 0 spent in each phase of problem i (avp_plan_batch leaves them 0: the s_memtime reads cost ~10 % of
+ * the kernel's wave cycles, so the production kernel carries none). Diagnostics only; results are identical. */
+int32_t avp_plan_batch_profile(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
+                               int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
+                               double* paths, int32_t max_path, double* trace, int32_t max_trace);
 
 /*
  * Replaces: Dijkstra.compute_path / the closed-list lookup of calc_node_heuristic
