@@ -25,7 +25,9 @@
 #include "avp_check_kernels.h"   // wave_sync
 #include "avp_rs_kernels.h"
 
+#ifndef PL_THREADS
 #define PL_THREADS 512
+#endif
 #define PL_QCAP 32768                 // entries per rotating bucket queue
 #define PL_NQ 4                       // rotating bucket queues
 #define PL_MAXCHILD 32
@@ -34,12 +36,13 @@
 #define PL_RS_CAP 1024                // samples of one RS shot
 #define PL_UNSEEN 0x7fffffffu
 #define PL_TRACE_W 11
-#define PL_SCHED_ROUNDS 4             // rounds of the RS word schedule: ceil(12 solver chunks of <= 64 lanes / (PL_THREADS / 64) waves) with slack
+#define PL_SCHED_ROUNDS (PL_THREADS >= 512 ? 4 : 8)   // rounds of the RS word schedule: 12 solver chunks of <= 64 lanes over PL_THREADS / 64 waves, with slack
 #define PL_FLAG_T 1
 // phase timers (thread 0, s_memtime): init, heap pop, (two unused slots), speculative resolution || shot sampling
 // and checks, children stage || sub-step checks, RS words .. set_path / arg-min || sampler replay, the rest of the
 // resolution (fast path when not speculated, slow path), of which sweep extensions, finish
-enum { PH_INIT = 0, PH_POP, PH_SHOT_RS, PH_SHOT_SAMPLE, PH_SHOT_CHECK, PH_CHILD, PH_CHILD_RS, PH_RESOLVE, PH_SWEEP, PH_FINISH };
+enum { PH_INIT = 0, PH_POP, PH_RES_CLASSIFY, PH_RES_WRITE, PH_SHOT_CHECK, PH_CHILD, PH_CHILD_RS, PH_RESOLVE, PH_SWEEP, PH_FINISH,
+       PH_RES_PUSH, PH_RS_WORDS, PH_CHILD_W0, PH_SHOT_ROUND0, PH_SHOT_REST, PH_SPARE, PH_COUNT };
 // The timers are compiled into the PROFILE instantiation only (avp_plan_batch_profile): s_memtime instrumentation costs
 // ~10 % of the wave cycles, so the production kernel carries none and reports phase_cycles = 0.
 #define PH_NOW() (PROFILE ? clock64() : 0ll)
@@ -60,7 +63,7 @@ struct avp_plan_result_dev {          // mirrors avp_plan_result in include/avp.
     double rs_L;
     double rs_start[3];               // RS sample 0 (the popped node's pose)
     int32_t rs_dir0, slot;
-    int64_t phase_cycles[10];         // diagnostics: shader cycles per phase (see PH_* below)
+    int64_t phase_cycles[16];         // diagnostics: shader cycles per phase (see PH_* below)
 };
 
 struct PlHeapEnt { double f; uint32_t node; uint32_t pad; };
@@ -236,7 +239,7 @@ struct PlShared {
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
-    long long phase[10];
+    long long phase[PH_COUNT];
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
     // sequential child resolution state machine (thread 0 runs alone between sweep extensions)
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(PL_THREADS) void hfield_kernel(DevMap m, double gx,
     PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace, dims);
-    if (threadIdx.x == 0) { s.status = 0; s.sched_cnt = -1; s.sched_n = 0; for (int k = 0; k < 10; k++) s.phase[k] = 0; s.mt.X = m.X; s.mt.Y = m.Y; s.mt.bits = m.colBits; }
+    if (threadIdx.x == 0) { s.status = 0; s.sched_cnt = -1; s.sched_n = 0; for (int k = 0; k < PH_COUNT; k++) s.phase[k] = 0; s.mt.X = m.X; s.mt.Y = m.Y; s.mt.bits = m.colBits; }
     __syncthreads();
     pl_sweep_init(m, w, s, dims, gx, gy);
     for (int i = 0; i < nq && s.status == 0; i++) {
@@ -571,15 +574,18 @@ static __device__ const int8_t PL_SCHED_WORDS[9][8] = { { 18, 19, 20, 21, -1, -1
                                                         { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 }, { 6, 7, 8, 9, -1, -1, -1, -1 },
                                                         { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 }, { 42, 43, 44, 45, -1, -1, -1, -1 } };
 static __device__ const int32_t PL_SCHED_COST[9] = { 106, 85, 78, 60, 60, 59, 45, 43, 30 };
-AVP_D void pl_rs_build_schedule(PlShared& s, int nq)
+__device__ __noinline__ void pl_rs_build_schedule(PlShared& s, int nq)      // (a leaf call: runs once, must not be unrolled into the kernel body)
 {
     // solvers by descending cost (x100 cycles per call of one wave, scripts/microbench/rs_words.hip on MI355X):
     // LRLRn, LRLRp (tauOmega: 5 sin/cos + acos + atan2), SLS (two nearly-CR tan), LRL, LRSL, LSR, LRSR, LSL, LRSLR
     // (runs once per workgroup and per child count, on one thread; its work arrays live in LDS: no stack objects)
     const int nwave = PL_THREADS / 64;
+#pragma nounroll
     for (int w = 0; w < nwave; w++) { s.sched_load[w] = 0; s.sched_rounds[w] = 0; }
+#pragma nounroll
     for (int i = 0; i < PL_SCHED_ROUNDS * PL_THREADS; i++) s.sched[i] = 0xffff;
     int maxround = 0;
+#pragma nounroll
     for (int sv = 0; sv < 9; sv++) {
         int nw = 0;
         while (nw < 8 && PL_SCHED_WORDS[sv][nw] >= 0) nw++;
@@ -894,9 +900,11 @@ __device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // their child in parallel; if every heuristic query hits the closed frontier, lane 0 then applies, in child
 // order, only what is order dependent: arena slots, in-place improvements of open nodes and heap pushes.
 // s.fast (preset to 1) reports whether the pop was resolved here; when it is 0 nothing has been modified.
+template <bool PROFILE>
 AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const PlanWs& w, PlShared& s, const PlanDims& dims,
                                 const PlNode& cn, int nchild)
 {
+    const long long t_r0 = PH_NOW();
     // Per-child state stays in the registers of the child's lane; the order dependent parts read it with ballots
     // and shuffles -- the serial sections below would otherwise spend most of their time on LDS round trips.
     const int lane = threadIdx.x & 63;
@@ -933,6 +941,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     }
     wave_sync();
     if (!s.fast) return;
+    const long long t_r1 = PH_NOW();
     // arena slots in child order = prefix count of the children that create a node; counters by ballot / reduction
     const unsigned long long m_closed = __ballot(cls == CL_NEW_CLOSED), m_open = __ballot(cls == CL_NEW_OPEN);
     const unsigned long long m_rs = m_open | __ballot(cls == CL_IMPROVE || cls == CL_KEEP);
@@ -961,6 +970,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     wave_sync();
+    const long long t_r2 = PH_NOW();
     // heap pushes / in-place improvements in child order (lane 0; the operands come from the children's lanes)
     unsigned long long todo = m_open | __ballot(cls == CL_IMPROVE);
     while (todo) {
@@ -980,6 +990,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         }
     }
     wave_sync();
+    if (PROFILE && threadIdx.x == 0) { const long long t_r3 = clock64(); s.phase[PH_RES_CLASSIFY] += t_r1 - t_r0; s.phase[PH_RES_WRITE] += t_r2 - t_r1; s.phase[PH_RES_PUSH] += t_r3 - t_r2; }
 }
 
 template <bool STAGE, bool PROFILE>
@@ -1042,7 +1053,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             s.status = 0; s.done = 0;
             s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0;
             s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
-            for (int k = 0; k < 10; k++) s.phase[k] = 0;
+            for (int k = 0; k < PH_COUNT; k++) s.phase[k] = 0;
             s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
             s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
         }
@@ -1121,6 +1132,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (one_pass) s.frame[tid + 1] = rs_frame(c.x, c.y, c.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             } else if (one_pass && tid == PL_THREADS - 2) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1);
+            if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
             const int wave = tid >> 6, lane = tid & 63;
@@ -1163,6 +1175,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (g == 0) { x = cn.x; y = cn.y; th = cn.th; }
                         else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
                     }, one_pass);
+                    if (PROFILE && tid == 0) s.phase[PH_RS_WORDS] += clock64() - t_e;
                     // set_path and arg-min, a whole query per wave (20 lanes run its type groups, then the wave folds):
                     // no cross-wave hand-over. Wave 0 owns the shot (query 0 of the first pass) and goes straight on to
                     // the sampler's index bookkeeping; the last wave, after its children, walks the chain of segment origins as
@@ -1230,7 +1243,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         s.snap[0] = s.nnodes; s.snap[1] = s.n_checks; s.snap[2] = s.n_rs; s.snap[3] = s.nclosed; s.snap[4] = s.nheap;
                     }
                     wave_sync();
-                    if (can_fast) pl_resolve_fast_wave(m, p, w, s, dims, cn, nchild);
+                    if (can_fast) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild);
                 }
                 if (wave >= w0) {
                     double cm, sm;
@@ -1254,10 +1267,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     // colliding shots hit within their first 21 samples (all within 32); the later chunks then never
                     // run. The checking waves meet at a software barrier so that the decision sees every round-0 result.
                     const int head = min(total, nw * PL_WPOSE0);
+                    const long long t_s0 = PH_NOW();
                     {
                         const int first = wave - w0;
                         if (first < head) do_chunk(first, nw, (head - first + nw - 1) / nw);
                     }
+                    if (PROFILE && tid == 64) s.phase[PH_SHOT_ROUND0] += clock64() - t_s0;
                     if (head < total) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {
@@ -1273,6 +1288,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             do_chunk(base, 1, min(per, total - base));
                         }
                     }
+                    if (PROFILE && tid == 64) s.phase[PH_SHOT_REST] += clock64() - t_s0;
                 }
                 pl_lds_barrier();                                   // (the resolution's global stores need not have landed)
                 if (tid == 0) {
@@ -1298,7 +1314,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (!can_fast && tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
             if (!tried && can_fast) {
-                if (wave == 0) pl_resolve_fast_wave(m, p, w, s, dims, cn, nchild);
+                if (wave == 0) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild);
                 __syncthreads();
             }
             if (s.fast) {
@@ -1451,7 +1467,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             r.rs_L = rs_L; r.rs_start[0] = rs0; r.rs_start[1] = rs1; r.rs_start[2] = rs2; r.rs_dir0 = rs_dir0;
             if (PROFILE) s.phase[PH_FINISH] += clock64() - t_fin;
 #pragma unroll
-            for (int k = 0; k < 10; k++) r.phase_cycles[k] = PROFILE ? s.phase[k] : 0;
+            for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = PROFILE ? s.phase[k] : 0;
         }
         __syncthreads();
     }

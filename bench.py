@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- hybrid-A* plans/s on batched poses (BASELINE.json metric), one process per GPU.
 
-A "step" = one pass of the hot path over one batch: every rank plans its own 256 random
-(start, goal) pairs on the Case1 map (BASELINE config[1]; weak scaling, seeds differ per rank)
-with inputs resident in HBM, then the fixed-stride results are gathered to rank 0 (the only
-collective of the data path, RCCL over xGMI). The map is built once on rank 0 and broadcast
-before the timed region. Pop cap per problem: 1000 (the reference has no cap and needs hours on
-the ~20 % of random pairs whose goal cannot be reached; see DESIGN.md "Workload").
+A "step" = one pass of the hot path over one batch of problems, inputs resident in HBM.
+
+  N = 1 : headline = BASELINE config[1] (Case1 map, 256 random start/goal pairs, pop cap 1000); extras on the same GPU:
+          `batch4096` (north_star's 4 096-pose target workload), `c3` (20 BenchmarkCases x 128), `c5` (dense clutter, RS
+          shot at every pop), the footprint kernel alone, and the CPU port timed on the host.
+  N > 1 : SURVEY 8(e), strong scaling of ONE fixed 4 096-problem set on the Case1 map: rank 0 samples the problems,
+          the map blob and the problems are broadcast (RCCL, untimed set-up), every rank plans the shard that
+          `shard_indices` deals it, and the timed step ends with the all-gather of the result records AND the solved
+          paths (fixed stride max_path x 4 doubles) -- the only data-path collectives. Rank 0 then checks the gathered
+          result against its own single-GPU run of the whole set (shard invariance).
+          AVP_BENCH_FORCE_DIST=1 runs exactly this code path with world size 1 (through RCCL).
+  --workload c3 with N > 1: every rank holds all 20 maps, each map's 128 problems are dealt the same way.
+
+`value` counts COMPLETED searches only (status OK / NO_PATH); problems stopped by the pop cap (ITER_LIMIT; the reference
+has no cap and needs hours on them, DESIGN.md "Workload") are excluded from the numerator and reported separately.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,10 +33,75 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 256
 POP_CAP = 1000
 MAX_NODES = 16384
-HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MAX_PATH = 256
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+N_SIMD = 256 * 4                # SIMDs on the chip
+CLOCK_GHZ = 2.4                 # max shader clock
+CASES = os.path.join(ROOT, "data", "BenchmarkCases")
+
+
+def source_hash():
+    """sha256 over the kernel sources: stamps PMC summaries so that a stale one is refused (profiles/README.md)."""
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "automatedvaletparking_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".hip", ".inc")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class Group:
+    """One map + its problems on this rank's GPU."""
+
+    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP):
+        from automatedvaletparking_amd import _native, path_planner
+        self.m = m
+        self.dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=cap)
+        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=MAX_NODES, max_path=MAX_PATH)
+        self.set_problems(starts, goals)
+
+    def set_problems(self, starts, goals):
+        self.starts, self.goals = np.ascontiguousarray(starts), np.ascontiguousarray(goals)
+        self.n = len(starts)
+        self.st_t, self.go_t = self.dm.dev_tensor(self.starts), self.dm.dev_tensor(self.goals)
+
+
+def sample_pairs(m, dm, n_pairs, rng):
+    """SURVEY 8(d) sampler: footprint-free (HIP check kernel) poses outside every obstacle polygon, paired up."""
+    from automatedvaletparking_amd import sampling
+    free = []
+    while len(free) < 2 * n_pairs:
+        cand = sampling.sample_free_poses(m.boundary, m.case.obs, 8 * min(n_pairs, 512), rng, margin=6.0, reject=False)
+        hit = dm.check_batch(cand)
+        free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
+    poses = np.array(free[:2 * n_pairs])
+    return poses[0::2], poses[1::2]
+
+
+def records(res_t, n):
+    from automatedvaletparking_amd import path_planner
+    return res_t.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:n]
+
+
+def summarize(recs, n_slots, elapsed_per_step):
+    """Throughput figures of one step over the given record arrays (one per group)."""
+    rec = np.concatenate(recs)
+    done = (rec["status"] == 0) | (rec["status"] == 1)
+    pops = int(rec["n_pops"].sum())
+    # slot utilisation: pops / (slots x pops of the busiest slot), per launch, pops-weighted over the launches
+    util_num = util_den = 0
+    for r in recs:
+        per_slot = np.bincount(r["slot"], weights=r["n_pops"], minlength=1)
+        slots = min(n_slots, len(r))
+        util_num += r["n_pops"].sum()
+        util_den += slots * per_slot.max()
+    return {"plans_per_s": float(done.sum()) / elapsed_per_step, "all_problems_per_s": len(rec) / elapsed_per_step,
+            "expansions_per_s": pops / elapsed_per_step, "problems": int(len(rec)), "completed": int(done.sum()),
+            "solved_frac": float((rec["status"] == 0).mean()), "iter_limit_frac": float((rec["status"] == 4).mean()),
+            "slot_utilisation": float(util_num / max(util_den, 1)), "ms_per_step": elapsed_per_step * 1e3}
 
 
 def main():
@@ -34,7 +109,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["auto", "c2", "batch4096", "c3", "c5"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (the PMC passes use it: per-launch counters of one workload)")
     a = ap.parse_args()
 
     import torch
@@ -46,167 +123,296 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
     use_dist = world > 1 or os.environ.get("AVP_BENCH_FORCE_DIST") == "1"     # the env var exercises RCCL with world 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    workload = a.workload if a.workload != "auto" else ("batch4096" if use_dist else "c2")
 
     cfg = config.default_config()
     veh = costmap.Vehicle()
-    m = None
-    if rank == 0:
-        m = costmap.Map(file=os.path.join(ROOT, "data", "BenchmarkCases", "Case1.csv"), discrete_size=cfg["map_discrete_size"])
-    m = avd.broadcast_map(m, src=0)          # RCCL broadcast of the packed costmap (setup, untimed)
-    dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=POP_CAP)
-    bp = path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=256)
 
-    # synthetic poses: SURVEY 8(d) sampler, footprint-free start/goal pairs
-    chk_dm = dm
+    # ---- problem sets (rank 0 builds and samples; the others receive) ------------------------------------------------
+    def build(name):
+        """-> (label, cfg, cap, [(Map, starts, goals)]) on rank 0; maps None elsewhere."""
+        if name in ("c2", "batch4096"):
+            n = 256 if name == "c2" else 4096
+            m = costmap.Map(file=os.path.join(CASES, "Case1.csv"), discrete_size=cfg["map_discrete_size"])
+            dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=POP_CAP)
+            st, go = sample_pairs(m, dm, n, np.random.default_rng(20260927))
+            label = ("Case1 map, 256 random start/goal pairs (config[1]), pop cap 1000" if name == "c2" else
+                     "Case1 map, 4096 random start/goal pairs (north_star target batch), pop cap 1000")
+            return label, cfg, POP_CAP, [(m, st, go)]
+        if name == "c3":
+            out = []
+            for k in range(1, 21):
+                m = costmap.Map(file=os.path.join(CASES, f"Case{k}.csv"), discrete_size=cfg["map_discrete_size"], device="cuda")
+                dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=300)
+                st, go = sample_pairs(m, dm, 128, np.random.default_rng(20260927 + k))
+                out.append((m, st, go))
+            return "all 20 BenchmarkCases x 128 random pairs (config[2]), pop cap 300", cfg, 300, out
+        if name == "c5":
+            import tempfile
+            obs, goal, aisle = sampling.parking_lot_map()
+            with tempfile.TemporaryDirectory() as td:
+                pth = os.path.join(td, "c5.csv")
+                sampling.write_tpcap_csv(pth, (aisle[0] + 8.0, 0.5 * (aisle[2] + aisle[3]), 0.0), goal, obs)
+                m = costmap.Map(file=pth, discrete_size=cfg["map_discrete_size"], device="cuda")
+            c5 = dict(cfg)
+            c5["flag_radius"] = 1e9
+            rng = np.random.default_rng(5)
+            starts = np.stack([rng.uniform(m.boundary[0] + 4, m.boundary[1] - 4, 1024), rng.uniform(aisle[2] + 1.2, aisle[3] - 1.2, 1024),
+                               rng.choice([0.0, np.pi], 1024) + rng.normal(0, 0.05, 1024)], 1)
+            return "parking lot, 120 obstacles, 1024 starts, RS shot at every pop (config[4]), pop cap 300", c5, 300, [(m, starts, np.tile(np.array(goal), (1024, 1)))]
+        raise ValueError(name)
 
-    def gpu_check(x, y, t):
-        return bool(chk_dm.check_batch(np.array([[x, y, t]]))[0])
-
-    rng = np.random.default_rng(20260927 + rank)
-    free = []
-    while len(free) < 2 * BATCH:
-        cand = sampling.sample_free_poses(m.boundary, m.case.obs, 8 * BATCH, rng, margin=6.0, reject=False)
-        hit = dm.check_batch(cand)                      # footprint vs obstacle edges: the HIP kernel
-        free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
-    poses = np.array(free[:2 * BATCH])
-    starts, goals = poses[0::2], poses[1::2]
-    st_t, go_t = dm.dev_tensor(starts), dm.dev_tensor(goals)
-
-    rec_stride = path_planner.RESULT_DTYPE.itemsize
-    gathered = torch.empty((world, BATCH, rec_stride), dtype=torch.uint8, device=f"cuda:{local}") if use_dist else None
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        res, paths, _ = bp.plan_dev(st_t, go_t, want_paths=True)
-        if i is not None:
-            ev[i][1].record()
+    def timed_steps(step_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        torch.cuda.synchronize()
         if use_dist:
-            avd.all_gather_rows(res[:BATCH], out=gathered)   # final gather of the solved records (RCCL all-gather)
-        return res, paths
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step_fn()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, out
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
+    # ---- headline -----------------------------------------------------------------------------------------------------
+    label, wcfg, cap, sets = build(workload) if rank == 0 else (None, None, None, None)
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        res, paths = step(i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    rec = res.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:BATCH]
-    pops_local = int(rec["n_pops"].sum())
-    if use_dist:
-        pt = torch.tensor([pops_local], dtype=torch.int64, device=f"cuda:{local}")
-        dist.all_reduce(pt)
-        pops_total = int(pt.item())
+        meta = [label, wcfg, cap, len(sets) if rank == 0 else 0]
+        dist.broadcast_object_list(meta, src=0)
+        label, wcfg, cap, nsets = meta
+        groups_full = []
+        for g in range(nsets):
+            m = avd.broadcast_map(sets[g][0] if rank == 0 else None, src=0)          # RCCL broadcast of the packed costmap
+            prob = torch.as_tensor(np.concatenate([sets[g][1], sets[g][2]], 1), device=dev) if rank == 0 else None
+            nprob = torch.tensor([len(sets[g][1]) if rank == 0 else 0], dtype=torch.int64, device=dev)
+            dist.broadcast(nprob, src=0)
+            if rank != 0:
+                prob = torch.empty((int(nprob.item()), 6), dtype=torch.float64, device=dev)
+            dist.broadcast(prob, src=0)                                               # ... and of the problem set
+            pr = prob.cpu().numpy()
+            groups_full.append((m, pr[:, :3].copy(), pr[:, 3:].copy()))
     else:
-        pops_total = pops_local
+        groups_full = sets
+
+    ev_k = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps + a.warmup)]
+    ev_i = [0]
+
+    if not use_dist:
+        groups = [Group(m, veh, wcfg, st, go, local, cap) for (m, st, go) in groups_full]
+
+        def step():
+            outs = []
+            e0, e1 = ev_k[ev_i[0] % len(ev_k)]
+            ev_i[0] += 1
+            e0.record()
+            for g in groups:
+                outs.append(g.bp.plan_dev(g.st_t, g.go_t, want_paths=True))
+            e1.record()
+            return outs
+
+        elapsed, outs = timed_steps(step, a.steps, a.warmup)
+        recs = [records(o[0], g.n) for o, g in zip(outs, groups)]
+        shard_invariant = None
+    else:
+        # shard: problems dealt by decreasing start-goal distance; equal shard size (padded with start == goal problems)
+        groups, idxs, pers = [], [], []
+        for (m, st, go) in groups_full:
+            idx = avd.shard_indices(st, go, rank, world)
+            per = (len(st) + world - 1) // world
+            pad = per - len(idx)
+            s_l = np.concatenate([st[idx], np.tile(go[:1], (pad, 1))]) if pad else st[idx]
+            g_l = np.concatenate([go[idx], np.tile(go[:1], (pad, 1))]) if pad else go[idx]
+            groups.append(Group(m, veh, wcfg, s_l, g_l, local, cap))
+            idxs.append(np.concatenate([idx, -np.ones(pad, np.int64)]))
+            pers.append(per)
+        rec_stride = path_planner.RESULT_DTYPE.itemsize
+        gat_r = [torch.empty((world, per, rec_stride), dtype=torch.uint8, device=dev) for per in pers]
+        gat_p = [torch.empty((world, per, MAX_PATH, 4), dtype=torch.float64, device=dev) for per in pers]
+        idx_t = [avd.all_gather_rows(torch.as_tensor(ix, device=dev)).cpu().numpy().reshape(-1) for ix in idxs]
+
+        def step():
+            e0, e1 = ev_k[ev_i[0] % len(ev_k)]
+            ev_i[0] += 1
+            e0.record()
+            for k, g in enumerate(groups):
+                res, paths, _ = g.bp.plan_dev(g.st_t, g.go_t, want_paths=True)
+                if k == len(groups) - 1:
+                    e1.record()
+                avd.all_gather_rows(res, out=gat_r[k])       # final gather of the records ...
+                avd.all_gather_rows(paths, out=gat_p[k])     # ... and of the solved paths (RCCL all-gather over xGMI)
+            return None
+
+        elapsed, _ = timed_steps(step, a.steps, a.warmup)
+        recs, shard_invariant = [], None
+        slots_per_gpu = int(_native.lib().avp_plan_default_slots(groups[0].dm.h))
+        if rank == 0:
+            shard_invariant = True
+            for k, (m, st, go) in enumerate(groups_full):
+                flat_r = gat_r[k].reshape(-1, rec_stride).cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)
+                flat_p = gat_p[k].reshape(-1, MAX_PATH, 4).cpu().numpy()
+                flat_r = flat_r.copy()
+                flat_r["slot"] += (np.arange(len(flat_r)) // pers[k]).astype(np.int32) * slots_per_gpu     # slot ids are per GPU
+                keep = idx_t[k] >= 0
+                order = np.argsort(idx_t[k][keep])
+                rec_all, path_all = flat_r[keep][order], flat_p[keep][order]
+                recs.append(rec_all)
+                # the same set on this GPU alone (untimed): the sharded result must be identical
+                ref = Group(m, veh, wcfg, st, go, local, cap)
+                r_res, r_paths, _ = ref.bp.plan_dev(ref.st_t, ref.go_t, want_paths=True)
+                r_rec, r_paths = records(r_res, ref.n), r_paths.cpu().numpy()
+                for name in ("status", "n_pops", "n_astar", "n_final", "n_checks", "n_rs", "n_closed", "n_open", "rs_L"):
+                    shard_invariant &= bool(np.array_equal(rec_all[name], r_rec[name]))
+                for i in range(ref.n):
+                    nf = int(r_rec["n_final"][i])
+                    shard_invariant &= bool(np.array_equal(path_all[i, :nf], r_paths[i, :nf]))
+            assert shard_invariant, "sharded result differs from the single-GPU result"
 
     if rank == 0:
-        plans = BATCH * world * a.steps
-        value = plans / elapsed
-        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-        # algorithmic bytes of one plan_kernel launch: U2 per pop + U3 per heuristic sweep
-        B_cc = 16 * dm.P + 25
-        alg = (float(rec["n_checks"].sum()) * B_cc
-               + 240.0 * float((rec["n_pops"].astype(np.float64) * (rec["n_closed"] + rec["n_open"]) / 2).sum())
-               + 680.0 * float(rec["n_pops"].sum()) + 16.0 * float(rec["h_cells"].sum()))
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
-        out = {
-            "metric": "hybrid-A* plans/sec, batched poses", "value": value, "unit": "plans/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Case1 map, 256 random start/goal pairs per GPU (config[1]), pop cap 1000",
-                       "batch_per_gpu": BATCH, "pop_cap": POP_CAP, "obstacle_points": dm.P, "parallelism": f"shard{world}"},
-            "expansions_per_s": pops_total * a.steps / elapsed,
-            "solved_frac": float((rec["status"] == 0).mean()), "iter_limit_frac": float((rec["status"] == 4).mean()),
-            "solved_plans_per_s": value * float((rec["status"] == 0).mean()),
-            "roofline": {"kernel": "plan_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launch_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg},
-        }
-        # secondary: the per-GPU share of north_star's target configuration (4096 poses over 8 GPUs = 512 per GPU):
-        # the persistent workgroups keep pulling problems, so a larger batch hides the long searches better
-        if os.environ.get("AVP_BENCH_SKIP_512") != "1":       # (the PMC passes skip it: per-launch traffic of the 256 batch only)
-            big_s = torch.cat([st_t, st_t.flip(0)]).contiguous()
-            big_g = torch.cat([go_t, go_t]).contiguous()
-            bp.plan_dev(big_s, big_g, want_paths=True)
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(2):
-                bp.plan_dev(big_s, big_g, want_paths=True)
-            torch.cuda.synchronize()
-            tb = (time.perf_counter() - tb) / 2
-            out["batch512"] = {"workload": "512 pairs per GPU on the Case1 map (the 256 starts re-paired with the goals), pop cap 1000",
-                               "plans_per_s": 512 / tb, "ms_per_step": tb * 1e3}
-        # secondary: the footprint-collision kernel alone (north_star's >= 40 % target), measured live
-        n_chk = 1 << 20
-        cp = np.stack([rng.uniform(m.boundary[0] + 6, m.boundary[1] - 6, n_chk), rng.uniform(m.boundary[2] + 6, m.boundary[3] - 6, n_chk),
-                       rng.uniform(-np.pi, np.pi, n_chk)], 0)
-        ct = dm.dev_tensor(cp)
-        co = dm.empty(n_chk, torch.uint8)
-        dm.check_batch_dev(ct[0], ct[1], ct[2], out=co)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dm.check_batch_dev(ct[0], ct[1], ct[2], out=co)
-        e1.record()
-        torch.cuda.synchronize()
-        cms = e0.elapsed_time(e1) / 10
-        cg = n_chk * B_cc / (cms * 1e-3) / 1e9
-        out["roofline_check"] = {"kernel": "check_distance_kernel", "bound": "hbm", "achieved": cg, "peak": HBM_PEAK_GBPS,
-                                 "unit": "GB/s", "frac": cg / HBM_PEAK_GBPS, "traffic": None, "launch_ms": cms,
-                                 "checks_per_s": n_chk / (cms * 1e-3), "bytes_per_check": B_cc}
-        if world == 1 and not a.no_cpu_baseline:
-            from oracle import oracle
-            o = oracle.Oracle(m, veh, cfg, max_pops=POP_CAP)
-            t1 = time.perf_counter()
-            pops_cpu = 0
-            for s_, g_ in zip(starts, goals):
-                pops_cpu += o.plan(s_, g_, max_trace=1)["n_pops"]
-            tc = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": BATCH / tc, "unit": "plans/s", "cores": 1, "kind": "port",
-                                   "sample": f"the same {BATCH} problems, pop cap {POP_CAP}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s",
-                                   "expansions_per_s": pops_cpu / tc}
-            # the same port on every host core: one problem per thread (ctypes releases the GIL; the C code has no shared state)
-            from concurrent.futures import ThreadPoolExecutor
-            ncore = os.cpu_count() or 1
-            t2 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=ncore) as ex:
-                list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=1)["n_pops"], zip(starts, goals)))
-            tm = time.perf_counter() - t2
-            out["cpu_baseline_all_cores"] = {"value": BATCH / tm, "unit": "plans/s", "cores": ncore, "kind": "port",
-                                             "sample": f"the same {BATCH} problems, one per thread, {tm:.1f} s"}
-        # HBM traffic per launch from the committed PMC passes of this same command (profiles/README.md)
+        n_slots = int(_native.lib().avp_plan_default_slots(groups[0].dm.h))
+        head = summarize(recs, n_slots * (world if use_dist else 1), elapsed / a.steps)
+        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_k[a.warmup:a.warmup + a.steps]])) if a.steps else 0.0
+        rec = np.concatenate(recs)
+        P = groups[0].dm.P
+        B_cc = 16 * P + 25
+        # algorithmic bytes of the launch(es) (SURVEY 8d): U2 per pop (checks + the reference's linear list scans + 680 B)
+        # + U3 per heuristic sweep. The list-scan term is what the reference READS; the kernel replaces those scans by an
+        # O(1) pose hash and never moves these bytes -- it is reported separately and left out of `frac_without_list_scan`.
+        t_checks = float(rec["n_checks"].sum()) * B_cc
+        t_scan = 240.0 * float((rec["n_pops"].astype(np.float64) * (rec["n_closed"] + rec["n_open"]) / 2).sum())
+        t_pop = 680.0 * float(rec["n_pops"].sum())
+        t_h = 16.0 * float(rec["h_cells"].sum())
+        scale = (1.0 / world) if use_dist else 1.0           # per launch on ONE GPU
+        alg = (t_checks + t_scan + t_pop + t_h) * scale
+        pmc = None
         try:
-            import glob
-            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
-            pj = json.load(open(pmc))
-            out["roofline"]["traffic"] = pj["plan_kernel"]["hbm_bytes_per_launch_corrected"]
-            out["roofline_check"]["traffic"] = pj["check_distance_kernel<true>"]["hbm_bytes_per_launch_corrected"]
-            out["roofline"]["traffic_source"] = out["roofline_check"]["traffic_source"] = os.path.relpath(pmc, ROOT)
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            pmc = pj if pj.get("source_hash") == source_hash() else {"stale": True}
         except Exception:
             pass
+        rl = {"kernel": "plan_kernel", "launch_ms": kernel_ms,
+              "algorithmic_bytes_per_launch": alg,
+              "algorithmic_terms": {"footprint_checks": t_checks * scale, "reference_list_scans": t_scan * scale,
+                                    "per_pop_state": t_pop * scale, "heuristic_field": t_h * scale},
+              "hbm_algorithmic_GBps": alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
+              "frac_hbm_algorithmic": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel_ms else None,
+              "frac_hbm_without_list_scan": (alg - t_scan * scale) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel_ms else None,
+              "bound": "valu", "unit": "G SIMD-cycles/s", "peak": N_SIMD * CLOCK_GHZ, "achieved": None, "frac": None, "traffic": None}
+        if pmc and not pmc.get("stale") and workload == "c2" and "plan_kernel" in pmc:
+            pk = pmc["plan_kernel"]
+            # VALU-busy SIMD cycles per launch (SQ_ACTIVE_INST_VALU counts quad-cycles) over THIS run's launch time
+            rl["achieved"] = pk["valu_active_simd_cycles_per_launch"] / (kernel_ms * 1e-3) / 1e9
+            rl["frac"] = rl["achieved"] / rl["peak"]
+            rl["traffic"] = pk.get("hbm_bytes_per_launch_corrected")
+            rl["wait_frac"] = pk.get("wait_any_frac")
+            rl["cycles_per_pop"] = pk.get("cycles_per_pop")
+            rl["pmc_source"] = "profiles/r02_pmc_summary.json (source hash %s)" % pmc["source_hash"]
+        elif pmc and pmc.get("stale"):
+            rl["pmc_source"] = "profiles/r02_pmc_summary.json is STALE (kernel sources changed): PMC-derived fields left null"
+        out = {
+            "metric": "hybrid-A* plans/sec, batched poses", "value": head["plans_per_s"], "unit": "plans/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if use_dist else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": label, "problems": head["problems"], "pop_cap": cap, "obstacle_points": P,
+                       "parallelism": f"shard{world}" + (" (records + paths all-gathered in the timed step)" if use_dist else "")},
+            "value_counts": "completed searches (status OK or NO_PATH); ITER_LIMIT problems are excluded",
+            "all_problems_per_s": head["all_problems_per_s"], "expansions_per_s": head["expansions_per_s"],
+            "solved_frac": head["solved_frac"], "iter_limit_frac": head["iter_limit_frac"],
+            "slot_utilisation": head["slot_utilisation"], "shard_invariant": shard_invariant,
+            "roofline": rl,
+        }
+
+        if world == 1 and not use_dist and not a.no_extras:
+            # ---- extras on the same GPU: the other BASELINE workloads ------------------------------------------------
+            for name in ("batch4096", "c3", "c5"):
+                if name == workload:
+                    continue
+                lab, xcfg, xcap, xsets = build(name)
+                xg = [Group(m, veh, xcfg, st, go, local, xcap) for (m, st, go) in xsets]
+
+                def xstep():
+                    return [g.bp.plan_dev(g.st_t, g.go_t, want_paths=True) for g in xg]
+
+                xstep()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    xo = xstep()
+                torch.cuda.synchronize()
+                xe = (time.perf_counter() - t0) / 2
+                xs = summarize([records(o[0], g.n) for o, g in zip(xo, xg)], n_slots, xe)
+                xs["workload"] = lab
+                out[name] = xs
+                del xg
+            # ---- the footprint-collision kernel alone ----------------------------------------------------------------
+            dm = groups[0].dm
+            m = groups[0].m
+            rng = np.random.default_rng(1)
+            n_chk = 1 << 20
+            cp = np.stack([rng.uniform(m.boundary[0] + 6, m.boundary[1] - 6, n_chk), rng.uniform(m.boundary[2] + 6, m.boundary[3] - 6, n_chk),
+                           rng.uniform(-np.pi, np.pi, n_chk)], 0)
+            ct = dm.dev_tensor(cp)
+            co = dm.empty(n_chk, torch.uint8)
+            dm.check_batch_dev(ct[0], ct[1], ct[2], out=co)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dm.check_batch_dev(ct[0], ct[1], ct[2], out=co)
+            e1.record()
+            torch.cuda.synchronize()
+            cms = e0.elapsed_time(e1) / 10
+            rc = {"kernel": "check_distance_kernel", "launch_ms": cms, "checks_per_s": n_chk / (cms * 1e-3), "bytes_per_check_reference": B_cc,
+                  "hbm_algorithmic_GBps": n_chk * B_cc / (cms * 1e-3) / 1e9,
+                  "note": "the reference formulation reads every obstacle point per check (16P+25 B); the kernel keeps the map in LDS and moves 25 B/check of HBM, so its bound is VALU/LDS issue, not HBM",
+                  "hbm_traffic_GBps": n_chk * 25 / (cms * 1e-3) / 1e9, "frac_hbm_traffic": n_chk * 25 / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  "bound": "valu", "unit": "G SIMD-cycles/s", "peak": N_SIMD * CLOCK_GHZ, "achieved": None, "frac": None, "traffic": None}
+            if pmc and not pmc.get("stale") and "check_distance_kernel" in pmc:
+                ck = pmc["check_distance_kernel"]
+                rc["achieved"] = ck["valu_active_simd_cycles_per_launch"] / (cms * 1e-3) / 1e9
+                rc["frac"] = rc["achieved"] / rc["peak"]
+                rc["traffic"] = ck.get("hbm_bytes_per_launch_corrected")
+                rc["lds_busy_frac"] = ck.get("lds_busy_frac")
+                rc["lds_bank_conflict_frac"] = ck.get("lds_bank_conflict_frac")
+            out["roofline_check"] = rc
+            if not a.no_cpu_baseline:
+                from oracle import oracle
+                g0 = groups[0]
+                o = oracle.Oracle(g0.m, veh, wcfg, max_pops=cap)
+                nb = min(g0.n, 256)
+                t1 = time.perf_counter()
+                pops_cpu = done_cpu = 0
+                for s_, g_ in zip(g0.starts[:nb], g0.goals[:nb]):
+                    w = o.plan(s_, g_, max_trace=1)
+                    pops_cpu += w["n_pops"]
+                    done_cpu += w["status"] in (0, 1)
+                tc = time.perf_counter() - t1
+                out["cpu_baseline"] = {"value": done_cpu / tc, "unit": "plans/s", "cores": 1, "kind": "port",
+                                       "sample": f"the first {nb} problems of the headline workload, pop cap {cap}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s; completed searches only, like `value`",
+                                       "all_problems_per_s": nb / tc, "expansions_per_s": pops_cpu / tc}
+                from concurrent.futures import ThreadPoolExecutor
+                ncore = os.cpu_count() or 1
+                t2 = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=ncore) as ex:
+                    st_all = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=1)["status"], zip(g0.starts[:nb], g0.goals[:nb])))
+                tm = time.perf_counter() - t2
+                out["cpu_baseline_all_cores"] = {"value": sum(s in (0, 1) for s in st_all) / tm, "unit": "plans/s", "cores": ncore, "kind": "port",
+                                                 "sample": f"the same {nb} problems, one per thread, {tm:.1f} s"}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -154,9 +154,12 @@ typedef struct avp_plan_result {
     double rs_start[3];      /* sample 0 of the last RS shot = pose of the last popped node        */
     int32_t rs_dir0;         /* its direction flag                                                 */
     int32_t slot;            /* the persistent workgroup (0 .. n_slots-1) that ran the problem      */
-    int64_t phase_cycles[10];/* diagnostics, avp_plan_batch_profile only (else 0): shader cycles per phase of the
-                                problem (init, heap pop, -, -, speculative resolution || shot checks, children ||
-                                sub-steps, RS words .. replay, rest of the resolution, of which sweep, finish) */
+    int64_t phase_cycles[16];/* diagnostics, avp_plan_batch_profile only (else 0): shader cycles per phase of the
+                                problem: 0 init, 1 heap pop, 2-3 wave-0 resolution: classify, node/hash writes, 4 speculative
+                                resolution || shot checks (wall), 5 children || sub-steps (wall), 6 RS words .. replay (wall),
+                                7 rest of the resolution, 8 of which sweep, 9 finish, 10 wave-0 resolution: heap pushes,
+                                11 RS words until their barrier, 12 wave-0 children stage, 13-14 shot checks round 0 / all
+                                rounds (wave 1), 15 spare */
 } avp_plan_result;
 
 /*

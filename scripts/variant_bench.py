@@ -79,7 +79,8 @@ if not a.no_profile and hasattr(_native.lib(), "avp_plan_batch_profile"):
         rp = resp.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:256]
         cap = rp["status"] == 4
         ph = rp["phase_cycles"].astype(np.float64)
-        names = ["init", "pop", "-", "-", "resolve||shot", "children||substeps", "rs_words..replay", "slow_resolve", "(sweep)", "finish"]
+        names = ["init", "pop", "res_classify", "res_write", "resolve||shot", "children||substeps", "rs_words..replay", "slow_resolve", "(sweep)", "finish",
+                 "res_push", "rs_words_only", "children_w0", "shot_round0", "shot_all", "-"]
         out["phase_cyc_per_pop"] = {n: round(float(ph[cap, k].mean() / 1000), 0) for k, n in enumerate(names) if n != "-"}
         out["cyc_per_pop"] = round(float(ph[cap][:, [1, 4, 5, 6, 7]].sum(axis=1).mean() / 1000), 0)
         one = rp["n_pops"] == 1

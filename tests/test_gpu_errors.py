@@ -50,5 +50,12 @@ def test_problem_statuses(vehicle, cfg):
     # wrapper-level mapping
     pl = path_planner.PathPlanner(config=cfg, map=m, vehicle=vehicle)
     pl._batch = tiny
+    # CAPACITY is not an error of the reference (it has no limits): a_star_plan repeats the search with a doubled
+    # arena / path buffer until it fits, and returns the reference's Case1 path (85 pops, 30 way-points)
+    final_path, astar_path, rs_path = pl.a_star_plan()
+    assert len(final_path) == 30 and rs_path.ctypes == ["L", "R", "L", "R"]
+    # ... while statuses that have no reference outcome still raise
+    pl2 = path_planner.PathPlanner(config=cfg, map=m, vehicle=vehicle)
+    pl2._batch = path_planner.BatchPlanner(_native.DeviceMap(m, vehicle, cfg, max_pops=5), n_slots=1)
     with pytest.raises(RuntimeError):
-        pl.a_star_plan()
+        pl2.a_star_plan()
