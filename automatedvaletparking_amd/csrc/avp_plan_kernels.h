@@ -199,7 +199,9 @@ struct MapTabs { const double* X; const double* Y; const uint64_t* bits; };
 
 #define PL_WPOSE 8                    // poses per wave per collision pass
 #define PL_WPOSE0 3                   // ... in the first round over the shot's samples
-#define PL_WQCAP 1024                 // (pose, point) candidates per wave
+#ifndef PL_WQCAP
+#define PL_WQCAP (PL_THREADS >= 512 ? 1024 : 512)   // (pose, point) candidates per wave; more fall back to the lane-per-pose walk
+#endif
 struct PlWaveChk {
     Footprint fp[PL_WPOSE];
     int16_t rng[PL_WPOSE][4];         // ixlo, ixhi, iylo, iyhi
@@ -239,6 +241,7 @@ struct PlShared {
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
+    int32_t frames_gen;               // pop number whose RS frames (and schedule) wave 0 has published
     long long phase[PH_COUNT];
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
@@ -255,7 +258,6 @@ struct PlShared {
     uint8_t w_acc[PL_RSQ * 46];       // word accepted by set_path
     uint8_t w_err[PL_RSQ];            // assertion L >= 0.01 failed for an accepted word
     double w_l[PL_RSQ * 46][5];
-    double w_Ln[PL_RSQ * 46];         // normalised length of an accepted word
     double w_Lm[PL_RSQ * 46];         // its length in metres (L / maxc)
     // RS sampling: per output index the last writer (length argument, segment), segment origins
     int32_t smp_hi, smp_point_num;
@@ -265,7 +267,8 @@ struct PlShared {
     // wave-local cooperative collision passes: every wave owns a scratch area (no workgroup barrier inside)
     int32_t chk_qover;
     PlWaveChk wchk[PL_THREADS / 64];
-    uint32_t chk_hit[PL_CHK_MAX];     // result per pose of the current pass
+    uint32_t chk_hit[PL_MAXCHILD * 4];   // hit flag per sub-step pose of the current pop
+    int32_t next_cur, have_next;      // node popped ahead by wave 0 at the end of its resolution (see pl_resolve_fast_wave)
 };
 
 static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
@@ -313,48 +316,71 @@ AVP_D void pl_hash_put_atomic(const PlanWs& w, int64_t hashCap, int32_t pos, dou
 // ---- CPython heapq on node positions, key = node.f (Node.__lt__ hybrid_a_star.py:61-68) ---------
 // The key is stored next to the position (one load per comparison); an in-place improvement of an
 // open node updates both copies and, like the reference (:224-230), does NOT restore the heap order.
-AVP_D void pl_heap_set(const PlanWs& w, int32_t pos, PlHeapEnt e) { w.heap[pos] = e; w.nodes[e.node].heap_pos = pos; }
+AVP_D PlHeapEnt pl_heap_get(const PlanWs& w, const PlShared& s, int32_t pos) { return w.heap[pos]; }
+AVP_D void pl_heap_set(const PlanWs& w, PlShared& s, int32_t pos, PlHeapEnt e) { w.heap[pos] = e; w.nodes[e.node].heap_pos = pos; }
+AVP_D void pl_heap_set_key(const PlanWs& w, PlShared& s, int32_t pos, double f) { w.heap[pos].f = f; }
 // (the item being moved is passed in registers: re-reading a slot this thread has just written would put
 // two global round trips on the serial path of every push / pop)
-AVP_D void pl_siftdown(const PlanWs& w, int32_t startpos, int32_t pos, const PlHeapEnt newitem)
+AVP_D void pl_siftdown(const PlanWs& w, PlShared& s, int32_t startpos, int32_t pos, const PlHeapEnt newitem)
 {
     while (pos > startpos) {
         const int32_t parentpos = (pos - 1) >> 1;
-        const PlHeapEnt parent = w.heap[parentpos];
-        if (newitem.f < parent.f) { pl_heap_set(w, pos, parent); pos = parentpos; continue; }
+        const PlHeapEnt parent = pl_heap_get(w, s, parentpos);
+        if (newitem.f < parent.f) { pl_heap_set(w, s, pos, parent); pos = parentpos; continue; }
         break;
     }
-    pl_heap_set(w, pos, newitem);
+    pl_heap_set(w, s, pos, newitem);
 }
-AVP_D void pl_siftup(const PlanWs& w, int32_t pos, int32_t endpos, const PlHeapEnt newitem)
+AVP_D void pl_siftup(const PlanWs& w, PlShared& s, int32_t pos, int32_t endpos, const PlHeapEnt newitem)
 {
     const int32_t startpos = pos;
     int32_t childpos = 2 * pos + 1;
     while (childpos < endpos) {
         const int32_t rightpos = childpos + 1;
-        PlHeapEnt c = w.heap[childpos];
+        PlHeapEnt c = pl_heap_get(w, s, childpos);
         if (rightpos < endpos) {
-            const PlHeapEnt r = w.heap[rightpos];
+            const PlHeapEnt r = pl_heap_get(w, s, rightpos);
             if (!(c.f < r.f)) { childpos = rightpos; c = r; }
         }
-        pl_heap_set(w, pos, c);
+        pl_heap_set(w, s, pos, c);
         pos = childpos;
         childpos = 2 * pos + 1;
     }
-    pl_siftdown(w, startpos, pos, newitem);
+    pl_siftdown(w, s, startpos, pos, newitem);
 }
 AVP_D void pl_heap_push(const PlanWs& w, PlShared& s, uint32_t node, double f)
 {
     PlHeapEnt e; e.f = f; e.node = node; e.pad = 0;
     s.nheap++;
-    pl_siftdown(w, 0, s.nheap - 1, e);
+    pl_siftdown(w, s, 0, s.nheap - 1, e);
+}
+// heappush by a whole wave (all 64 lanes call it with the same arguments; nheap = the entry count BEFORE the push, held
+// in a register by every lane). _siftdown only ever compares the new item with the ancestors of its slot, and those do
+// not change while it climbs: lane i fetches ancestor i of the slot (one round trip for the whole root path instead of
+// one per level), a ballot finds the first ancestor the item does not beat, the ancestors below it move down one step
+// each (in parallel) and the item lands in the freed slot -- the same array the serial loop produces.
+AVP_D void pl_heap_push_wave(const PlanWs& w, int32_t nheap, uint32_t node, double f)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t slot1 = (uint32_t)nheap + 1u;                 // 1-based index of the new slot
+    const int depth = 31 - __clz(slot1);                          // number of ancestors
+    // 1-based ancestor i+1 of the slot = slot1 >> (i + 1); its child on the path = slot1 >> i
+    const int32_t mine = (int32_t)(slot1 >> (lane < 31 ? lane : 31)) - 1;           // path[i]   (0-based)
+    const int32_t par = (int32_t)(slot1 >> (lane < 30 ? lane + 1 : 31)) - 1;       // path[i+1]
+    PlHeapEnt anc; anc.f = 0.0; anc.node = 0; anc.pad = 0;
+    const bool act = lane < depth;
+    if (act) anc = w.heap[par];
+    const unsigned long long stop = __ballot(act && !(f < anc.f));
+    const int j = stop ? __ffsll((unsigned long long)stop) - 1 : depth;   // the item ends at path[j]
+    if (lane < j) { w.heap[mine] = anc; w.nodes[anc.node].heap_pos = mine; }
+    if (lane == j) { PlHeapEnt e; e.f = f; e.node = node; e.pad = 0; w.heap[mine] = e; w.nodes[node].heap_pos = mine; }
 }
 AVP_D uint32_t pl_heap_pop(const PlanWs& w, PlShared& s)
 {
-    const PlHeapEnt lastelt = w.heap[--s.nheap];
+    const PlHeapEnt lastelt = pl_heap_get(w, s, --s.nheap);
     if (s.nheap) {
-        const PlHeapEnt ret = w.heap[0];
-        pl_siftup(w, 0, s.nheap, lastelt);
+        const PlHeapEnt ret = pl_heap_get(w, s, 0);
+        pl_siftup(w, s, 0, s.nheap, lastelt);
         return ret.node;
     }
     return lastelt.node;
@@ -574,14 +600,17 @@ static __device__ const int8_t PL_SCHED_WORDS[9][8] = { { 18, 19, 20, 21, -1, -1
                                                         { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 }, { 6, 7, 8, 9, -1, -1, -1, -1 },
                                                         { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 }, { 42, 43, 44, 45, -1, -1, -1, -1 } };
 static __device__ const int32_t PL_SCHED_COST[9] = { 106, 85, 78, 60, 60, 59, 45, 43, 30 };
-__device__ __noinline__ void pl_rs_build_schedule(PlShared& s, int nq)      // (a leaf call: runs once, must not be unrolled into the kernel body)
+__device__ __noinline__ void pl_rs_build_schedule(PlShared& s, int nq, int chk_waves)      // (a leaf call: runs once, must not be unrolled into the kernel body)
 {
     // solvers by descending cost (x100 cycles per call of one wave, scripts/microbench/rs_words.hip on MI355X):
     // LRLRn, LRLRp (tauOmega: 5 sin/cos + acos + atan2), SLS (two nearly-CR tan), LRL, LRSL, LSR, LRSR, LSL, LRSLR
     // (runs once per workgroup and per child count, on one thread; its work arrays live in LDS: no stack objects)
     const int nwave = PL_THREADS / 64;
+    // chk_waves > 0: the words follow the children stage without a workgroup barrier, so the waves arrive at different
+    // times (x100 cycles, measured with avp_plan_batch_profile): wave 0 after the children poses, waves 1 .. chk_waves
+    // after their sub-step collision pass, the others at once -- the longest solvers go to the waves that are free first
 #pragma nounroll
-    for (int w = 0; w < nwave; w++) { s.sched_load[w] = 0; s.sched_rounds[w] = 0; }
+    for (int w = 0; w < nwave; w++) { s.sched_load[w] = chk_waves <= 0 ? 0 : w == 0 ? 106 : w <= chk_waves ? 150 : 4; s.sched_rounds[w] = 0; }
 #pragma nounroll
     for (int i = 0; i < PL_SCHED_ROUNDS * PL_THREADS; i++) s.sched[i] = 0xffff;
     int maxround = 0;
@@ -618,7 +647,7 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose, bo
             pose((int)threadIdx.x, x, y, th);
             s.frame[threadIdx.x] = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
         }
-        if (threadIdx.x == PL_THREADS - 1 && s.sched_cnt != nq) pl_rs_build_schedule(s, nq);
+        if (threadIdx.x == PL_THREADS - 1 && s.sched_cnt != nq) pl_rs_build_schedule(s, nq, 0);
         __syncthreads();
     }
     for (int t = threadIdx.x; t < s.sched_n; t += PL_THREADS) {
@@ -673,7 +702,7 @@ AVP_D void pl_rs_accept_group(PlShared& s, const avp_params& p, int q, int g)
         if (!ok || dup || L >= 1000.0) continue;
         if (!(L >= 0.01)) { s.w_err[q] = 1; continue; }
         accmask |= 1u << j;
-        s.w_acc[slot] = 1; s.w_Ln[slot] = L; s.w_Lm[slot] = L / p.maxc;
+        s.w_acc[slot] = 1; s.w_Lm[slot] = L / p.maxc;
     }
 }
 
@@ -707,7 +736,10 @@ AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
     out.t[3] = 3 < W.n ? W.d : (int8_t)-1; out.t[4] = 4 < W.n ? W.e : (int8_t)-1;
 #pragma unroll
     for (int i = 0; i < AVP_RS_MAXSEG; i++) out.l[i] = s.w_l[q * 46 + wd][i];
-    out.L = s.w_Ln[q * 46 + wd];
+    double Ln = 0;                                   // the winner's normalised length: the same sum set_path formed (rs_curve.py:145)
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) Ln = Ln + fabs(out.l[i]);
+    out.L = Ln;
     return 0;
 }
 
@@ -902,7 +934,7 @@ __device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // s.fast (preset to 1) reports whether the pop was resolved here; when it is 0 nothing has been modified.
 template <bool PROFILE>
 AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const PlanWs& w, PlShared& s, const PlanDims& dims,
-                                const PlNode& cn, int nchild)
+                                const PlNode& cn, int nchild, bool pop_ahead)
 {
     const long long t_r0 = PH_NOW();
     // Per-child state stays in the registers of the child's lane; the order dependent parts read it with ballots
@@ -971,26 +1003,43 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     wave_sync();
     const long long t_r2 = PH_NOW();
-    // heap pushes / in-place improvements in child order (lane 0; the operands come from the children's lanes)
+    // heap pushes / in-place improvements in child order; the operands come from the children's lanes, every push is
+    // done by the whole wave (pl_heap_push_wave), an improvement by lane 0
     unsigned long long todo = m_open | __ballot(cls == CL_IMPROVE);
+    int32_t nheap = s.nheap;
     while (todo) {
         const int i = __ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1;
         const int icls = __shfl(cls, i, 64), ipos = __shfl(pos, i, 64), ifound = __shfl(found, i, 64);
         const double if_ = __shfl(cf, i, 64), ig = __shfl(cg, i, 64), ih = __shfl(ch_, i, 64);
-        if (lane == 0) {
-            if (icls == CL_NEW_OPEN) pl_heap_push(w, s, (uint32_t)ipos, if_);
-            else {
-                PlNode& ch = w.nodes[ifound];
-                ch.f = if_; ch.g = ig; ch.h = ih;
-                ch.parent_index = cn.index; ch.parent_pos = cur;
-                ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
-                w.heap[ch.heap_pos].f = if_;      // current slot: earlier pushes of this pop may have moved it
-            }
+        if (icls == CL_NEW_OPEN) {
+            pl_heap_push_wave(w, nheap, (uint32_t)ipos, if_);
+            nheap++;
+        } else if (lane == 0) {
+            PlNode& ch = w.nodes[ifound];
+            ch.f = if_; ch.g = ig; ch.h = ih;
+            ch.parent_index = cn.index; ch.parent_pos = cur;
+            ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
+            pl_heap_set_key(w, s, ch.heap_pos, if_);      // current slot: earlier pushes of this pop may have moved it
         }
+        // the next push / improvement reads entries and heap_pos fields this one has written (other lanes' stores)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wave_sync();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (lane == 0) s.nheap = nheap;
+    wave_sync();
+    const long long t_r3 = PH_NOW();
+    // Pop ahead: the open list is final for this pop, so lane 0 takes the next node off it right away instead of at the
+    // top of the next iteration behind two workgroup barriers (the other waves are still checking the shot). If the shot
+    // then succeeds the search is over and only the open-list COUNT is reported, which the caller restores.
+    if (lane == 0 && pop_ahead && s.nheap > 0) {
+        const uint32_t c = pl_heap_pop(w, s);
+        s.next_cur = (int32_t)c; s.have_next = 1;
+        w.nodes[c].state = 3;
     }
     wave_sync();
-    if (PROFILE && threadIdx.x == 0) { const long long t_r3 = clock64(); s.phase[PH_RES_CLASSIFY] += t_r1 - t_r0; s.phase[PH_RES_WRITE] += t_r2 - t_r1; s.phase[PH_RES_PUSH] += t_r3 - t_r2; }
+    if (PROFILE && threadIdx.x == 0) { s.phase[PH_RES_CLASSIFY] += t_r1 - t_r0; s.phase[PH_RES_WRITE] += t_r2 - t_r1; s.phase[PH_RES_PUSH] += t_r3 - t_r2; s.phase[PH_SPARE] += clock64() - t_r3; }
 }
 
 template <bool STAGE, bool PROFILE>
@@ -1008,7 +1057,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.frames_gen = -1; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll
@@ -1036,6 +1085,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     if (tid == 0) s.mt = mt;
     const int nchild = 2 * p.n_steer;
     const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
+    int32_t gen = 0;
 
     for (;;) {
         __syncthreads();
@@ -1051,7 +1101,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         for (int64_t i = tid; i < dims.hashCap; i += PL_THREADS) w.hash[i] = 0;
         if (tid == 0) {
             s.status = 0; s.done = 0;
-            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0;
+            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
             s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
             for (int k = 0; k < PH_COUNT; k++) s.phase[k] = 0;
             s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
@@ -1084,7 +1134,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
             { const long long t_pop = PH_NOW();
             if (tid == 0) {
-                if (s.nheap == 0) { s.status = 1; }
+                if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }     // popped ahead by wave 0 (n_pops < max_pops held there)
+                else if (s.nheap == 0) { s.status = 1; }
                 else if (n_pops >= max_pops) { s.status = 4; }
                 else {
                     const uint32_t c = pl_heap_pop(w, s);
@@ -1103,6 +1154,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : s.k_steer[cn.steer_i];
             }
             n_pops++;
+            gen++;                                   // pop counter of this workgroup over all its problems (hand-over flags)
 
             // ---- children poses (expand_node :134-151) + try_reach_goal radius test (:308-312) ----------
             const long long t_d = PH_NOW();
@@ -1130,8 +1182,15 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 c.rs_err = 0;
                 c.L = 0;
                 if (one_pass) s.frame[tid + 1] = rs_frame(c.x, c.y, c.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            } else if (one_pass && tid == PL_THREADS - 2) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1);
+            } else if (one_pass && tid == nchild) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            else if (one_pass && tid == nchild + 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1, min(PL_THREADS / 64 - 2, (nchild * p.n_sub + PL_WPOSE - 1) / PL_WPOSE));
+            if (one_pass && tid < 64) {
+                // wave 0 publishes the frames (and, the first time, the schedule): the other waves start on the words as
+                // soon as they are through with their sub-step checks -- no workgroup barrier between the two stages
+                wave_sync();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (tid == 0) *(volatile int32_t*)&s.frames_gen = gen;
+            }
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
@@ -1139,8 +1198,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const int nwave = PL_THREADS / 64;
             const int nsubs = nchild * p.n_sub;
             {
-                const int nw = nwave - 2;
-                const int per = max(1, min(PL_WPOSE, (nsubs + nw - 1) / nw));      // spread the poses evenly over the waves
+                // full passes (PL_WPOSE poses) on as few waves as possible: the cost of a collision pass hardly depends on
+                // its pose count, and every wave that does not check starts on the Reeds-Shepp words at once
+                const int nw = min(nwave - 2, (nsubs + PL_WPOSE - 1) / PL_WPOSE);
+                const int per = max(1, min(PL_WPOSE, (nsubs + nw - 1) / nw));
                 if (wave >= 1 && wave <= nw) {
                     for (int base = (wave - 1) * per; base < nsubs; base += nw * per) {
                         const int cnt = min(per, nsubs - base);
@@ -1156,9 +1217,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     }
                 }
             }
-            __syncthreads();
-            for (int t = tid; t < nsubs; t += PL_THREADS)
-                if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
+            if (one_pass) {
+                if (tid >= 64) {
+                    if (lane == 0) while (*(volatile int32_t*)&s.frames_gen != gen) __builtin_amdgcn_s_sleep(1);
+                    wave_sync();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+            } else __syncthreads();
             const long long t_e = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_CHILD] += t_e - t_d;
 
@@ -1176,6 +1241,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
                     }, one_pass);
                     if (PROFILE && tid == 0) s.phase[PH_RS_WORDS] += clock64() - t_e;
+                    if (base == 0) {
+                        // (behind the words' barrier: every sub-step check has landed) first colliding sub-step per child
+                        for (int t = tid; t < nsubs; t += PL_THREADS)
+                            if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
+                    }
                     // set_path and arg-min, a whole query per wave (20 lanes run its type groups, then the wave folds):
                     // no cross-wave hand-over. Wave 0 owns the shot (query 0 of the first pass) and goes straight on to
                     // the sampler's index bookkeeping; the last wave, after its children, walks the chain of segment origins as
@@ -1243,12 +1313,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         s.snap[0] = s.nnodes; s.snap[1] = s.n_checks; s.snap[2] = s.n_rs; s.snap[3] = s.nclosed; s.snap[4] = s.nheap;
                     }
                     wave_sync();
-                    if (can_fast) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild);
+                    if (can_fast) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
                 }
                 if (wave >= w0) {
                     double cm, sm;
                     avp_sincos(-cn.th, sm, cm);
-                    // chunk = samples base, base + stride, ... (cnt of them); hit flags land in s.chk_hit[nsubs + sample]
+                    // chunk = samples base, base + stride, ... (cnt of them); hit flags land in the wave's own wchk.hit[]
                     auto do_chunk = [&](int base, int stride, int cnt) {
                         double tx = 0.0, ty = 0.0, tth = 0.0;
                         const int mine = base + lane * stride;
@@ -1314,7 +1384,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (!can_fast && tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
             if (!tried && can_fast) {
-                if (wave == 0) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild);
+                if (wave == 0) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
                 __syncthreads();
             }
             if (s.fast) {
@@ -1369,7 +1439,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             const double new_f = hval + new_g;
                             if (new_f < ch.f) {
                                 ch.f = new_f; ch.g = new_g; ch.h = hval;
-                                w.heap[ch.heap_pos].f = new_f;
+                                pl_heap_set_key(w, s, ch.heap_pos, new_f);
                                 ch.parent_index = cn.index; ch.parent_pos = s.cur;
                                 ch.forward = (int8_t)is_forward; ch.steer_i = (int8_t)si;
                             }

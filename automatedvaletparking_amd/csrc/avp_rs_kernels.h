@@ -28,7 +28,7 @@ enum { RS_S = 0, RS_L = 1, RS_R = 2 };
 // each body exists once. Same arithmetic, same results; only the code layout changes. The collision kernels
 // (avp_check_kernels.h, included before this header) keep the inlined forms.
 #ifndef PL_LIBM_CALLS
-#define PL_LIBM_CALLS 0
+#define PL_LIBM_CALLS 1
 #endif
 #if PL_LIBM_CALLS && defined(__HIP_DEVICE_COMPILE__)
 struct AvpSinCos { double s, c; };

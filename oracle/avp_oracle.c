@@ -34,6 +34,15 @@
 static int g_portable = 0;
 ORC_API void orc_set_portable(int v) { g_portable = v; }
 ORC_API int orc_get_portable(void) { return g_portable; }
+/* What-if switch for the heuristic Dijkstra (test instrumentation; default 0 = the reference's behaviour): the
+ * reference lowers the distance of an open cell IN PLACE without restoring the heap order (compute_h.py:226-227), so a
+ * cell is occasionally popped one step early. With g_dij_reheap = 1 the decrease is followed by the sift-up a correct
+ * decrease-key performs, i.e. cells are popped in exact (distance, id) order -- the order the device's bucketed sweep
+ * realises. tests/test_dijkstra_stale_key.py measures what the two orders can differ in (nothing but the hit/miss
+ * classification of a few later queries; never a distance, never a pop trace). */
+static int g_dij_reheap = 0;
+ORC_API void orc_set_dij_reheap(int v) { g_dij_reheap = v; }
+ORC_API int orc_get_dij_reheap(void) { return g_dij_reheap; }
 #define ATAN2(y, x) (g_portable ? avp_atan2((y), (x)) : atan2((y), (x)))
 #define ASIN(x) (g_portable ? avp_asin(x) : asin(x))
 #define ACOS(x) (g_portable ? avp_acos(x) : acos(x))
@@ -768,7 +777,12 @@ static void dij_add(dij_t *d, double gx, double gy, int64_t priority, int64_t fa
     int32_t *s = imap_slot(&d->seen, index, 0);
     if (s) {
         grid_t *g = &d->pool[*s];
-        if (g->in_heap && g->dist > priority) { g->dist = priority; g->father = father_id; }
+        if (g->in_heap && g->dist > priority) {
+            g->dist = priority; g->father = father_id;
+            if (g_dij_reheap) {
+                for (int64_t q = 0; q < d->nheap; q++) if (d->heap[q] == *s) { dheap_siftdown(d, 0, q); break; }
+            }
+        }
     } else {
         int32_t gi = dij_new_grid(d, index, gx, gy, priority, father_id);
         d->pool[gi].in_heap = 1;

@@ -79,6 +79,8 @@ def lib():
         L.orc_dij_dump.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.orc_set_portable.argtypes = [C.c_int]
         L.orc_get_portable.restype = C.c_int
+        L.orc_set_dij_reheap.argtypes = [C.c_int]
+        L.orc_get_dij_reheap.restype = C.c_int
         L.orc_plan.restype = C.c_int32
         L.orc_split_path.restype = C.c_int32
         _LIB = L
@@ -87,6 +89,40 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class exact_dijkstra_order:
+    """Context manager (what-if instrumentation): the heuristic Dijkstra restores the heap order after an in-place
+    decrease-key, i.e. pops cells in exact (distance, id) order like the device's bucketed sweep, instead of
+    reproducing the reference's occasionally one-step-early pops (compute_h.py:226-227)."""
+
+    def __init__(self, on: bool = True):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        self.prev = lib().orc_get_dij_reheap()
+        lib().orc_set_dij_reheap(self.on)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_dij_reheap(self.prev)
+
+
+class device_arithmetic:
+    """Context manager: the oracle configured exactly as the device computes -- portable atan2/asin/acos/tan
+    (`portable_libm`) and exact (distance, id) pop order in the heuristic Dijkstra (`exact_dijkstra_order`). The GPU
+    parity tests compare against this mode with no tolerance at all; what the two switches change relative to the
+    reference-faithful default is measured on the CPU (tests/test_oracle_portable.py, tests/test_dijkstra_stale_key.py)."""
+
+    def __enter__(self):
+        self.a, self.b = portable_libm(), exact_dijkstra_order()
+        self.a.__enter__()
+        self.b.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.b.__exit__(*a)
+        self.a.__exit__(*a)
 
 
 class portable_libm:

@@ -26,7 +26,7 @@ def same(r, w):
     if not np.array_equal(t[:, :10], wt[:len(t), :10]):
         return False
     c = r.counters
-    if any(c[k] != w[k] for k in ("n_closed", "n_open", "global_index", "n_rs", "n_checks")):
+    if any(c[k] != w[k] for k in ("n_closed", "n_open", "global_index", "n_rs", "n_checks")) or c["h_misses"] != w["n_dij_calls"]:
         return False
     if r.status == 0 and not np.array_equal(np.asarray(r.final_path), np.asarray(w["final_path"])):
         return False
@@ -61,7 +61,7 @@ def plan_and_compare(m, veh, cfg, starts, goals, cap=CAP, threads=THREADS, max_n
     t_gpu = time.perf_counter() - t0
     o = oracle.Oracle(m, veh, cfg, max_pops=cap)
     t1 = time.perf_counter()
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         with ThreadPoolExecutor(threads) as ex:
             ws = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=cap), zip(starts, goals)))
     t_cpu = time.perf_counter() - t1

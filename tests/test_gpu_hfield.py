@@ -1,6 +1,8 @@
-"""Heuristic field on the device vs the heapq-exact oracle Dijkstra (compute_h.py restatement):
-per-query distances, hit/miss classification, the closed set and every closed distance, for maps with
-and without aliased grid ids and for goals near the map edges (wormhole rows)."""
+"""Heuristic field on the device vs the oracle Dijkstra (compute_h.py restatement) in exact (distance, id) pop order
+(`oracle.exact_dijkstra_order`, the order the bucketed sweep realises): per-query distances, hit/miss classification,
+the closed set and every closed distance are IDENTICAL -- no tolerance -- for maps with and without aliased grid ids
+and for goals near the map edges (wormhole rows). Exact order vs the reference's stale-key order is bounded on the
+CPU on all 20 maps by tests/test_dijkstra_stale_key.py."""
 import numpy as np
 import pytest
 
@@ -15,6 +17,11 @@ def _run(k, goal, queries, vehicle, cfg):
     m = case_map_from_gold(k)
     dm = _native.DeviceMap(m, vehicle, cfg)
     o = oracle.Oracle(m, vehicle, cfg)
+    with oracle.exact_dijkstra_order():
+        return _run_exact(o, dm, goal, queries)
+
+
+def _run_exact(o, dm, goal, queries):
     dj = o.dijkstra(goal[0], goal[1])
     want_d, want_miss = [], []
     for i, (x, y) in enumerate(queries):
@@ -33,8 +40,7 @@ def _run(k, goal, queries, vehicle, cfg):
     r = dm.hfield_queries(goal, queries[:len(want_d)], force[:len(want_d)])
     assert r["info"][0] == 0
     assert list(r["d"]) == want_d
-    # hit/miss may differ by the reference's one-step-early pops (stale heap keys); distances never do
-    assert sum(abs(int(a) - int(b)) for a, b in zip(r["miss"], want_miss)) <= 1
+    assert list(r["miss"]) == want_miss
     ids, dist, _, _ = dj.dump()
     # every cell the reference closed has the same distance on the device
     first = {}
@@ -56,7 +62,7 @@ def _run(k, goal, queries, vehicle, cfg):
     closed_ref = set(first.keys())
     closed_ref.discard(goal_id) if int(gd[goal_id]) == 0x7fffffff or (int(gd[goal_id]), goal_id) > (dF, idF) else None
     diff = closed_dev ^ closed_ref
-    assert len(diff) <= 2, (len(diff), sorted(diff)[:6])
+    assert not diff, (len(diff), sorted(diff)[:6])
     return r
 
 

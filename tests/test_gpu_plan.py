@@ -1,6 +1,7 @@
 """HIP hybrid-A* planner.
 
-(1) vs the CPU oracle in portable-libm mode (identical arithmetic): EVERYTHING is bit exact --
+(1) vs the CPU oracle in device arithmetic (oracle.device_arithmetic: portable libm + exact Dijkstra pop order):
+    EVERYTHING is bit exact, no tolerance anywhere --
     pop trace (node index, parent, grid id, pose, g, h, f, gear), counters, paths, RS tail.
 (2) vs the reference's golden traces (glibc arithmetic): the north_star bar -- popped grid ids
     bit exact, way-points within 1e-6 -- except the golden problems listed in
@@ -40,10 +41,10 @@ def _assert_same_as_oracle(res, w):
     c = res.counters
     for k in ("n_closed", "n_open", "global_index", "n_rs", "n_checks"):
         assert c[k] == w[k], (k, c[k], w[k])
-    # sweep extensions: equal, except that the reference's in-place decrease-key without re-heapify
-    # (compute_h.py:226-227) occasionally pops a cell one step early, which turns one later query from
-    # "miss" into "hit" there (observed: 1 problem in 256, no effect on any distance or on the trace)
-    assert abs(c["h_misses"] - w["n_dij_calls"]) <= 2
+    # sweep extensions (Dijkstra.compute_path calls): exact -- the oracle runs in device arithmetic, i.e. with exact
+    # (distance, id) pop order in the heuristic Dijkstra; what that order can change relative to the reference's
+    # stale-key pops is bounded on the CPU by tests/test_dijkstra_stale_key.py (never a distance, never a trace)
+    assert c["h_misses"] == w["n_dij_calls"]
     if res.status in (0, 1):
         assert np.array_equal(res.astar_path, w["astar_path"])
         assert np.array_equal(res.final_path, w["final_path"])
@@ -69,7 +70,7 @@ def test_golden_problems(path, vehicle, cfg):
     bp = path_planner.BatchPlanner(dm, n_slots=1, max_nodes=1 << 19)
     res = bp.plan(st[None, :], go[None, :], max_trace=cap)[0]
     o = oracle.Oracle(m, vehicle, cfgp, max_pops=cap)
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         w = o.plan(st, go, max_trace=cap)
     _assert_same_as_oracle(res, w)
     # reference bar
@@ -102,7 +103,7 @@ def test_batch_256_case1_vs_oracle(vehicle, cfg):
     bp = path_planner.BatchPlanner(dm, max_nodes=16384)
     res = bp.plan(starts, goals, max_trace=cap)
     bad = []
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         for i, r in enumerate(res):
             w = o.plan(starts[i], goals[i], max_trace=cap)
             try:
@@ -127,7 +128,7 @@ def test_circle_checker_plan(vehicle, cfg):
     dm = _native.DeviceMap(m, vehicle, cfgc, max_pops=3000)
     res = path_planner.BatchPlanner(dm, n_slots=1).plan([[c.x0, c.y0, c.theta0]], [[c.xf, c.yf, c.thetaf]], max_trace=3000)[0]
     o = oracle.Oracle(m, vehicle, cfgc, max_pops=3000)
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         w = o.plan([c.x0, c.y0, c.theta0], [c.xf, c.yf, c.thetaf], max_trace=3000)
     _assert_same_as_oracle(res, w)
 
@@ -169,7 +170,7 @@ def test_random_pairs_other_maps_vs_oracle(k, vehicle, cfg):
     starts, goals = poses[0::2], poses[1::2]
     dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
     res = path_planner.BatchPlanner(dm, max_nodes=8192).plan(starts, goals, max_trace=cap)
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         for i, r in enumerate(res):
             _assert_same_as_oracle(r, o.plan(starts[i], goals[i], max_trace=cap))
 
@@ -195,7 +196,7 @@ def test_config_variants_vs_oracle(over, vehicle, cfg):
     goals = np.concatenate([goals, [[m.case.xf, m.case.yf, m.case.thetaf]]])
     dm = _native.DeviceMap(m, vehicle, c2, max_pops=cap)
     res = path_planner.BatchPlanner(dm, max_nodes=8192).plan(starts, goals, max_trace=cap)
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         for i, r in enumerate(res):
             _assert_same_as_oracle(r, o.plan(starts[i], goals[i], max_trace=cap))
 
@@ -222,7 +223,7 @@ def test_large_map_tables_not_in_lds(vehicle, cfg, tmp_path):
     starts = free[0:12:2]
     goals = starts + np.stack([rng.uniform(-9, 9, 6), rng.uniform(-9, 9, 6), rng.uniform(-1, 1, 6)], 1)
     res = path_planner.BatchPlanner(dm, max_nodes=4096, n_slots=3).plan(starts, goals, max_trace=cap)
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         for i, r in enumerate(res):
             _assert_same_as_oracle(r, o.plan(starts[i], goals[i], max_trace=cap))
 

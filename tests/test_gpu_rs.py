@@ -33,7 +33,7 @@ def test_rs_bit_exact_vs_portable_oracle(vehicle, cfg):
     q1[500:600] = q0[500:600]                      # start == goal: the reference's assertion
     q0 = np.concatenate([q0, g4["q0"]])
     q1 = np.concatenate([q1, g4["q1"]])
-    with oracle.portable_libm():
+    with oracle.device_arithmetic():
         want = o.rs_optimal(q0, q1, maxpts=192)
     got = dm.rs_optimal_batch(q0, q1, maxpts=192)
     _assert_identical(got, want)
