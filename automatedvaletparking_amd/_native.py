@@ -20,7 +20,7 @@ AVP_MAX_STEER = 16
 
 EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
-    "avp_check_batch", "avp_corridor_batch", "avp_trig_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
+    "avp_check_batch", "avp_corridor_batch", "avp_corridor_batch_v", "avp_trig_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
     "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch", "avp_plan_batch_profile",
     "avp_hfield_id_capacity", "avp_hfield_queries", "avp_rasterize_edges",
 ]
@@ -225,7 +225,7 @@ class DeviceMap:
         return out.cpu().numpy()
 
     # ---- corridor bounds ---------------------------------------------------------------------------
-    def corridor_batch(self, poses, expand_dis: float) -> np.ndarray:
+    def corridor_batch(self, poses, expand_dis: float, variant: int = 0) -> np.ndarray:
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
         n = len(poses)
         if n == 0:
@@ -233,8 +233,8 @@ class DeviceMap:
         self.use_current_stream()
         soa = self.dev_tensor(poses.T.copy())
         out = self.empty((n, 4), self.torch.float64)
-        chk(lib().avp_corridor_batch(self.h, C.c_double(float(expand_dis)), C.c_void_p(soa[0].data_ptr()), C.c_void_p(soa[1].data_ptr()),
-                                     C.c_void_p(soa[2].data_ptr()), C.c_int64(n), C.c_void_p(out.data_ptr())), "avp_corridor_batch")
+        chk(lib().avp_corridor_batch_v(self.h, C.c_double(float(expand_dis)), C.c_void_p(soa[0].data_ptr()), C.c_void_p(soa[1].data_ptr()),
+                                       C.c_void_p(soa[2].data_ptr()), C.c_int64(n), C.c_void_p(out.data_ptr()), C.c_int32(variant)), "avp_corridor_batch_v")
         return out.cpu().numpy()
 
     # ---- Reeds-Shepp ---------------------------------------------------------------------------

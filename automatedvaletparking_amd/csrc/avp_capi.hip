@@ -222,11 +222,37 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
 AVP_EXPORT int32_t avp_corridor_batch(avp_map* map, double expand_dis, const double* x, const double* y, const double* th,
                                       int64_t n, double* out)
 {
+    return avp_corridor_batch_v(map, expand_dis, x, y, th, n, out, 0);
+}
+
+AVP_EXPORT int32_t avp_corridor_batch_v(avp_map* map, double expand_dis, const double* x, const double* y, const double* th,
+                                        int64_t n, double* out, int32_t variant)
+{
     if (!map || n < 0 || !(expand_dis >= 0.0) || (n > 0 && (!x || !y || !th || !out))) return set_err(AVP_ERR_ARG, "avp_corridor_batch: bad argument");
     if (n == 0) return AVP_OK;
     AVP_ON_DEVICE(map->device);
-    hipLaunchKernelGGL(corridor_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, map->stream, map->dev, map->params, expand_dis,
-                       x, y, th, n, out);
+    const DevMap& d = map->dev;
+    // production kernel: cell indices packed in 13 bits, way-point lane in 6; otherwise (or variant 1, the on-device
+    // cross-check) the lane-per-way-point kernel
+    if (d.nx > 8191 || d.ny > 8191 || variant == 1) {
+        hipLaunchKernelGGL(corridor_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, map->stream, map->dev, map->params, expand_dis,
+                           x, y, th, n, out);
+    } else {
+        const size_t lds_full = corridor_lds_bytes(d, true);
+        const bool stage = lds_full + AVP_LDS_TABLE_BYTES <= 160 * 1024;
+        const size_t lds = stage ? lds_full : corridor_lds_bytes(d, false);
+        const int64_t tiles = (n + 63) / 64;
+        int64_t blocks = (tiles + CHK_WAVES - 1) / CHK_WAVES;
+        const int64_t cap = (int64_t)map->n_cu * 2;
+        if (blocks > cap) blocks = cap;
+        if (stage) {
+            HIPCHK(hipFuncSetAttribute((const void*)corridor_compact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(corridor_compact_kernel<true>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, expand_dis, x, y, th, n, out);
+        } else {
+            HIPCHK(hipFuncSetAttribute((const void*)corridor_compact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(corridor_compact_kernel<false>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, expand_dis, x, y, th, n, out);
+        }
+    }
     HIPCHK(hipGetLastError());
     return AVP_OK;
 }

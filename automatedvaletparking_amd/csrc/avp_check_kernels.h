@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void check_distance_naive_kernel(DevMap m, avp
 #define CHK_QCAP 4096          // queue entries per wave (u32)
 #define CHK_QDRAIN 512         // early-drain threshold (keeps the narrow phase on full waves without waiting for a full queue)
 static_assert(CHK_QCAP >= 64 * 64, "one column step appends at most 64 lanes x 64 rows: it must fit an empty queue");
-#define CHK_FPW (sizeof(Footprint) / 8)
+#define CHK_FPN 22              // doubles of a Footprint that carry data (the two trailing pads are never read)
+#define CHK_FPW 23              // LDS record stride in doubles: ODD, so that the same field of different poses' records falls into
+                                // different bank pairs (a stride of 24 doubles = 48 dwords puts every 4th record on the same banks:
+                                // rocprofv3 showed 47 % of the kernel's LDS cycles as bank conflicts in the narrow phase's gather)
 
 __device__ __forceinline__ int wave_prefix_excl(int v, int lane, int& total)
 {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
             const double* src = (const double*)&f;
             double* dst = sFp + (size_t)lane * CHK_FPW;
 #pragma unroll
-            for (int k = 0; k < (int)CHK_FPW; k++) dst[k] = src[k];
+            for (int k = 0; k < CHK_FPN; k++) dst[k] = src[k];
         }
         sHit[lane] = 0;
         wave_sync();
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
     avp_lds_tables_fill<false>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double cs = avp_cos(th[i]), sn = avp_sin(th[i]);
+    double cs, sn;
+    avp_sincos(th[i], sn, cs);
     const double Rd = p.circ_rd;
     const double fx = x[i] + p.circ_cf * cs, fy = y[i] + p.circ_cf * sn;
     const double rx = x[i] + p.circ_cr * cs, ry = y[i] + p.circ_cr * sn;
@@ -250,7 +254,9 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
     else if (theta >= 0 && theta < AVP_PI / 2) cs = 1;
     else if (theta >= AVP_PI / 2 && theta <= AVP_PI) cs = 2;
     double x_min = expand, x_max = expand, y_min = expand, y_max = expand;
-    const double ac = fabs(avp_cos(theta)), as = fabs(avp_sin(theta));
+    double sth_, cth_;
+    avp_sincos(theta, sth_, cth_);
+    const double ac = fabs(cth_), as = fabs(sth_);
     if (cs) {
         const int ixlo = avp_first_ge(m.X, m.nx, m.b0, m.dx, xlo), ixhi = avp_last_le(m.X, m.nx, m.b0, m.dx, xhi);
         const int iylo = avp_first_ge(m.Y, m.ny, m.b2, m.dy, ylo), iyhi = avp_last_le(m.Y, m.ny, m.b2, m.dy, yhi);
@@ -284,6 +290,165 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
         }
     }
     out[4 * q] = x_max + px; out[4 * q + 1] = y_max + py; out[4 * q + 2] = px - x_min; out[4 * q + 3] = py - y_min;
+}
+
+// ---- corridor bounds, production kernel: the wave-compaction scheme of check_distance_kernel ------------------
+// Same result as corridor_kernel above (kept as the fallback for maps whose AABB rows do not fit the queue and as the
+// on-device cross-check). One lane = one way-point for the set-up; the (way-point, obstacle point) candidates of the
+// 64 lanes are compacted into a per-wave LDS queue, so the per-point work -- first matching edge area, point-line
+// distance, two divisions -- runs on full waves however unevenly the points are spread; the four running minima of a
+// way-point are LDS atomicMin on the bit patterns (all candidates are >= 0, NaN never wins: same as the "<" scan).
+#define COR_QCAP 4096
+struct CorPose { double ac, as, expand; int32_t cs, pad; unsigned long long mn[4]; };   // |cos|, |sin|, heading case, minima {x_max, y_max, x_min, y_min}
+
+static inline size_t corridor_lds_bytes(const DevMap& m, bool stage)
+{
+    const size_t perWave = 64 * CHK_FPW * 8 + 64 * sizeof(CorPose) + COR_QCAP * 4;
+    return (stage ? ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8 : 0) + CHK_WAVES * perWave;
+}
+
+template <bool STAGE>
+__global__ __launch_bounds__(64 * CHK_WAVES) void corridor_compact_kernel(DevMap m, avp_params p, double expand,
+                                                                          const double* __restrict__ x, const double* __restrict__ y,
+                                                                          const double* __restrict__ th, int64_t n, double* __restrict__ out)
+{
+    avp_lds_tables_fill<false>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* lBits = (uint64_t*)smem;
+    double* lX = (double*)(lBits + (STAGE ? (size_t)m.nx * m.wpc : 0));
+    double* lY = lX + (STAGE ? m.nx : 0);
+    unsigned char* sWave = (unsigned char*)(lY + (STAGE ? m.ny : 0));
+    const uint64_t* sBits = STAGE ? lBits : m.colBits;
+    const double* sX = STAGE ? lX : m.X;
+    const double* sY = STAGE ? lY : m.Y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t perWave = 64 * CHK_FPW * 8 + 64 * sizeof(CorPose) + COR_QCAP * 4;
+    double* sFp = (double*)(sWave + (size_t)wave * perWave);
+    CorPose* sPose = (CorPose*)(sFp + 64 * CHK_FPW);
+    uint32_t* sQ = (uint32_t*)(sPose + 64);
+    if (STAGE) {
+        for (int i = threadIdx.x; i < m.nx * m.wpc; i += blockDim.x) lBits[i] = m.colBits[i];
+        for (int i = threadIdx.x; i < m.nx; i += blockDim.x) lX[i] = m.X[i];
+        for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
+        __syncthreads();
+    }
+    const unsigned long long ebits = (unsigned long long)__double_as_longlong(expand);
+    const int64_t tiles = (n + 63) / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * CHK_WAVES + wave; tile < tiles; tile += (int64_t)gridDim.x * CHK_WAVES) {
+        const int64_t i = tile * 64 + lane;
+        const bool valid = i < n;
+        const double px = valid ? x[i] : 0.0, py = valid ? y[i] : 0.0, theta = valid ? th[i] : 0.0;
+        int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
+        {
+            Footprint f;
+            avp_footprint_setup(p, px, py, theta, f);
+            double xlo, xhi, ylo, yhi;
+            avp_footprint_aabb(f, xlo, xhi, ylo, yhi);
+            xhi = xhi + expand; xlo = xlo - expand; yhi = yhi + expand; ylo = ylo - expand;
+            int cs = 0;
+            if (theta >= -AVP_PI && theta < -AVP_PI / 2) cs = 3;
+            else if (theta >= -AVP_PI / 2 && theta < 0) cs = 4;
+            else if (theta >= 0 && theta < AVP_PI / 2) cs = 1;
+            else if (theta >= AVP_PI / 2 && theta <= AVP_PI) cs = 2;
+            if (valid && cs) {
+                ixlo = avp_first_ge(sX, m.nx, m.b0, m.dx, xlo);
+                ixhi = avp_last_le(sX, m.nx, m.b0, m.dx, xhi);
+                iylo = avp_first_ge(sY, m.ny, m.b2, m.dy, ylo);
+                iyhi = avp_last_le(sY, m.ny, m.b2, m.dy, yhi);
+                if (iylo > iyhi) ixhi = ixlo - 1;
+            }
+            const double* src = (const double*)&f;
+            double* dst = sFp + (size_t)lane * CHK_FPW;
+#pragma unroll
+            for (int k = 0; k < CHK_FPN; k++) dst[k] = src[k];
+            CorPose& cp = sPose[lane];
+            double sth_, cth_;
+            avp_sincos(theta, sth_, cth_);
+            cp.ac = fabs(cth_); cp.as = fabs(sth_); cp.expand = expand; cp.cs = cs;
+            cp.mn[0] = cp.mn[1] = cp.mn[2] = cp.mn[3] = ebits;
+        }
+        wave_sync();
+        int ncol = ixhi - ixlo + 1;
+        if (ncol < 0) ncol = 0;
+        int maxcol = ncol;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) maxcol = max(maxcol, __shfl_xor(maxcol, d, 64));
+        const int w0 = iylo >> 6, w1 = iyhi >> 6;
+        int nword = ncol > 0 ? w1 - w0 + 1 : 0, maxword = nword;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) maxword = max(maxword, __shfl_xor(maxword, d, 64));
+        int qtail = 0;
+
+        auto drain = [&]() {
+            wave_sync();
+            for (int base = 0; base < qtail; base += 64) {
+                const int e = base + lane;
+                if (e < qtail) {
+                    const uint32_t ent = sQ[e];
+                    const int pl = ent >> 26, ix = (ent >> 13) & 0x1fff, iy = ent & 0x1fff;
+                    const Footprint& f = *(const Footprint*)(sFp + (size_t)pl * CHK_FPW);
+                    CorPose& cp = sPose[pl];
+                    const double ox = sX[ix], oy = sY[iy], ex = cp.expand;
+                    int hitk = -1;
+                    bool xpos = false, ypos = false;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const int j = (kk + 1) & 3;
+                        const double a0 = f.cx[kk] < f.cx[j] ? f.cx[kk] : f.cx[j], a1 = f.cx[kk] > f.cx[j] ? f.cx[kk] : f.cx[j];
+                        const double a2 = f.cy[kk] < f.cy[j] ? f.cy[kk] : f.cy[j], a3 = f.cy[kk] > f.cy[j] ? f.cy[kk] : f.cy[j];
+                        const int quad = (kk + cp.cs - 1) & 3;
+                        const bool xp = quad == 0 || quad == 1, yp = quad == 1 || quad == 2;
+                        const double ax0 = xp ? a0 : a0 - ex, ax1 = xp ? a1 + ex : a1;
+                        const double ay0 = yp ? a2 : a2 - ex, ay1 = yp ? a3 + ex : a3;
+                        if (hitk < 0 && ox > ax0 && ox < ax1 && oy > ay0 && oy < ay1) { hitk = kk; xpos = xp; ypos = yp; }
+                    }
+                    if (hitk >= 0) {
+                        const double fk = hitk == 0 ? f.k[0] : hitk == 1 ? f.k[1] : hitk == 2 ? f.k[2] : f.k[3];
+                        const double fb = hitk == 0 ? f.b[0] : hitk == 1 ? f.b[1] : hitk == 2 ? f.b[2] : f.b[3];
+                        const double fd = hitk == 0 ? f.den[0] : hitk == 1 ? f.den[1] : hitk == 2 ? f.den[2] : f.den[3];
+                        const double sd = fabs(fk * ox + fb - oy) / fd;
+                        const double ver = sd / cp.ac, hor = sd / cp.as;
+                        // "if (v < cur) cur = v" over non-negative doubles and NaN == atomicMin on the bit patterns, except
+                        // that a NaN with a clear sign bit is excluded explicitly (it never compares less)
+                        if (hor == hor) atomicMin(&cp.mn[xpos ? 0 : 2], (unsigned long long)__double_as_longlong(hor));
+                        if (ver == ver) atomicMin(&cp.mn[ypos ? 1 : 3], (unsigned long long)__double_as_longlong(ver));
+                    }
+                }
+            }
+            qtail = 0;
+            wave_sync();
+        };
+
+        for (int c = 0; c < maxcol; c++) {
+            const int ix = ixlo + c;
+            for (int wi = 0; wi < maxword; wi++) {
+                uint64_t bits = 0;
+                const int w = w0 + wi;
+                if (c < ncol && wi < nword) {
+                    bits = sBits[(size_t)ix * m.wpc + w];
+                    if (w == w0) bits &= ~0ull << (iylo & 63);
+                    if (w == w1) bits &= ~0ull >> (63 - (iyhi & 63));
+                }
+                const int cnt = __popcll(bits);
+                int total;
+                const int pre = wave_prefix_excl(cnt, lane, total);
+                if (total == 0) continue;
+                if (qtail + total > COR_QCAP) drain();            // one (column, word) step appends <= 64 x 64 = COR_QCAP entries
+                int off = qtail + pre;
+                const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)ix << 13);
+                while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; sQ[off++] = tag | (uint32_t)((w << 6) + bpos); }
+                qtail += total;
+                if (qtail > COR_QCAP - 1024) drain();
+            }
+        }
+        drain();
+        if (valid) {
+            const CorPose& cp = sPose[lane];
+            out[4 * i] = __longlong_as_double((long long)cp.mn[0]) + px; out[4 * i + 1] = __longlong_as_double((long long)cp.mn[1]) + py;
+            out[4 * i + 2] = px - __longlong_as_double((long long)cp.mn[2]); out[4 * i + 3] = py - __longlong_as_double((long long)cp.mn[3]);
+        }
+        wave_sync();
+    }
 }
 
 // ---- test hooks -------------------------------------------------------------------------------

@@ -171,34 +171,82 @@ AVP_HD double avp_cos(double x)
     return NAN;
 }
 
-// sin and cos of the same argument, the values of avp_sin(x) and avp_cos(x) bit for bit: one range dispatch, one
-// pi/2 reduction, and in a wave whose lanes fall into different ranges each range body runs once for both results.
+// sin and cos of the same argument, the values of avp_sin(x) and avp_cos(x) bit for bit, WITHOUT range branches.
+// A wave whose lanes hold angles from different ranges pays every branch of a branchy dispatch (measured on MI355X:
+// 2 300 cycles per wave-call with angles spread over [-pi, pi] against 610 with one common range -- and nearly every
+// call of the planner is of the first kind). Every range of glibc's algorithm ends in ONE do_sin and ONE do_cos
+// evaluation, only on different (argument, correction) pairs:
+//   |x| < 0.855      : sin = do_sin(x, 0)                       cos = do_cos(x, 0)
+//   |x| < 2.426      : sin = +-do_cos(pi/2 - |x|, hp1)          cos = do_sin(a, da),  a + da = pi/2 - |x| + hp1
+//   |x| < 105414350  : (a, da, n) = pi/2 reduction;  sin, cos = +-do_sin(a, da), +-do_cos(a, da) picked by n
+// So the three argument pairs are prepared for every lane (a dozen FMAs), selected per lane, do_sin / do_cos run once
+// on full waves (do_sin's own |x| < 0.126 split is evaluated both ways and selected), and the outputs are routed by
+// selects. Each lane performs exactly the operations of its own range: the values cannot differ from avp_sin /
+// avp_cos (checked bit for bit on the host against glibc and on the device against the branchy forms).
+namespace avp_trig {
+AVP_HD double do_sin_sel(double x, double dx)
+{
+    const double ax = fabs(x);
+    const double ty = taylor_sin(x * x, x, dx);                       // |x| < 0.126
+    const double dxs = (x <= 0) ? -dx : dx;
+    const double ux = big + ax;
+    int k = (int)(avp_d2u(ux) & 0xffffffffu);
+    k = k < 0 ? 0 : (k > 111 ? 111 : k);                              // (only lanes whose result is discarded can be out of range)
+    const double xr = ax - (ux - big);
+    const double xx = xr * xr;
+    const double sp = xr + AVP_FMA(xr * xx, AVP_FMA(xx, sn5, sn3), dxs);
+    const double cp = AVP_FMA(xr, dxs, xx * AVP_FMA(xx, AVP_FMA(xx, cs6, cs4), cs2));
+    const double sn = AVP_SCT[k][0], ssn = AVP_SCT[k][1];
+    const double cs = AVP_SCT[k][2], ccs = AVP_SCT[k][3];
+    const double cor = AVP_FMA(cs, sp, AVP_FMA(-sn, cp, AVP_FMA(sp, ccs, ssn)));
+    const double tb = copysign(sn + cor, x);
+    return ax < 0.126 ? ty : tb;
+}
+AVP_HD double do_cos_sel(double x, double dx)
+{
+    const double dxs = (x < 0) ? -dx : dx;
+    const double ux = big + fabs(x);
+    int k = (int)(avp_d2u(ux) & 0xffffffffu);
+    k = k < 0 ? 0 : (k > 111 ? 111 : k);
+    const double xr = fabs(x) - (ux - big) + dxs;
+    const double xx = xr * xr;
+    const double sp = AVP_FMA(xr * xx, AVP_FMA(xx, sn5, sn3), xr);
+    const double cp = xx * AVP_FMA(xx, AVP_FMA(xx, cs6, cs4), cs2);
+    const double sn = AVP_SCT[k][0], ssn = AVP_SCT[k][1];
+    const double cs = AVP_SCT[k][2], ccs = AVP_SCT[k][3];
+    const double cor = AVP_FMA(-sn, sp, AVP_FMA(-cs, cp, AVP_FMA(-sp, ssn, ccs)));
+    return cs + cor;
+}
+}  // namespace avp_trig
+
 AVP_HD void avp_sincos(double x, double& sn, double& cs)
 {
     using namespace avp_trig;
     const int32_t k = 0x7fffffff & (int32_t)(avp_d2u(x) >> 32);
-    if (k < 0x3e500000) { sn = x; cs = (k < 0x3e400000) ? 1.0 : do_cos(x, 0); return; }
-    if (k < 0x3feb6000) { sn = do_sin(x, 0); cs = do_cos(x, 0); return; }
-    if (k < 0x400368fd) {
-        const double t = hp0 - fabs(x);
-        sn = copysign(do_cos(t, hp1), x);
-        const double a = t + hp1;
-        const double da = (t - a) + hp1;
-        cs = do_sin(a, da);
-        return;
-    }
-    if (k < 0x419921FB) {
-        double a, da;
-        const int n = reduce_sincos(x, &a, &da);
-        const double S = do_sin(a, da), C = do_cos(a, da);          // do_sincos(a, da, m) = (m & 1 ? C : S), negated when m & 2
-        const double rs = (n & 1) ? C : S;
-        sn = (n & 2) ? -rs : rs;
-        const int m = n + 1;
-        const double rc = (m & 1) ? C : S;
-        cs = (m & 2) ? -rc : rc;
-        return;
-    }
-    sn = NAN; cs = NAN;
+    const double ax = fabs(x);
+    // range 2 arguments
+    const double t = hp0 - ax;
+    const double a2 = t + hp1;
+    const double da2 = (t - a2) + hp1;
+    // range 3 arguments
+    double a3, da3;
+    const int n = reduce_sincos(x, &a3, &da3);
+    const bool r1 = k < 0x3feb6000, r2 = k < 0x400368fd;             // (r2 is read only where !r1)
+    const double su = r1 ? x : (r2 ? a2 : a3), sdu = r1 ? 0.0 : (r2 ? da2 : da3);
+    const double cu = r1 ? x : (r2 ? t : a3), cdu = r1 ? 0.0 : (r2 ? hp1 : da3);
+    const double S = do_sin_sel(su, sdu), C = do_cos_sel(cu, cdu);
+    // range 3 routing: do_sincos(a, da, m) = (m & 1 ? C : S), negated when m & 2; sin uses m = n, cos m = n + 1
+    const double rs = (n & 1) ? C : S;
+    const double s3 = (n & 2) ? -rs : rs;
+    const int m = n + 1;
+    const double rc = (m & 1) ? C : S;
+    const double c3 = (m & 2) ? -rc : rc;
+    double so = r1 ? S : (r2 ? copysign(C, x) : s3);
+    double co = r1 ? C : (r2 ? S : c3);
+    if (k < 0x3e500000) so = x;                                        // tiny: sin x = x; cos x = 1 below 2^-27, do_cos(x, 0) = C above
+    if (k < 0x3e400000) co = 1.0;
+    if (!(k < 0x419921FB)) { so = NAN; co = NAN; }
+    sn = so; cs = co;
 }
 
 // ---- Python float semantics ------------------------------------------------------------------

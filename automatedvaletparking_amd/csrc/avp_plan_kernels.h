@@ -42,7 +42,14 @@
 // and checks, children stage || sub-step checks, RS words .. set_path / arg-min || sampler replay, the rest of the
 // resolution (fast path when not speculated, slow path), of which sweep extensions, finish
 enum { PH_INIT = 0, PH_POP, PH_RES_CLASSIFY, PH_RES_WRITE, PH_SHOT_CHECK, PH_CHILD, PH_CHILD_RS, PH_RESOLVE, PH_SWEEP, PH_FINISH,
-       PH_RES_PUSH, PH_RS_WORDS, PH_CHILD_W0, PH_SHOT_ROUND0, PH_SHOT_REST, PH_SPARE, PH_COUNT };
+       PH_RES_PUSH, PH_RS_WORDS, PH_CHILD_W0, PH_SHOT_ROUND0, PH_SHOT_REST, PH_SPARE,
+       PH_WAVE0 = 16,          // [PH_WAVE0 + 5 * wave + k]: arrival of `wave` at barrier k of a pop, cycles since the pop started:
+                               // k = 0 children / sub-steps done, 1 RS words done, 2 set_path / arg-min / replay done,
+                               // 3 resolution / shot checks done, 4 end of the pop
+       PH_X0 = PH_WAVE0 + 5 * 8,   // 8 fine-grained probes (see the PH_X uses)
+       PH_COUNT = PH_X0 + 8 };
+#define PH_X(k, t0) do { if (PROFILE) s.phase[PH_X0 + (k)] += clock64() - (t0); } while (0)
+#define PH_MARK(k) do { if (PROFILE && (threadIdx.x & 63) == 0) s.phase[PH_WAVE0 + 5 * (threadIdx.x >> 6) + (k)] += clock64() - t_pop0; } while (0)
 // The timers are compiled into the PROFILE instantiation only (avp_plan_batch_profile): s_memtime instrumentation costs
 // ~10 % of the wave cycles, so the production kernel carries none and reports phase_cycles = 0.
 #define PH_NOW() (PROFILE ? clock64() : 0ll)
@@ -63,7 +70,7 @@ struct avp_plan_result_dev {          // mirrors avp_plan_result in include/avp.
     double rs_L;
     double rs_start[3];               // RS sample 0 (the popped node's pose)
     int32_t rs_dir0, slot;
-    int64_t phase_cycles[16];         // diagnostics: shader cycles per phase (see PH_* below)
+    int64_t phase_cycles[64];         // diagnostics: shader cycles per phase (see PH_* below)
 };
 
 struct PlHeapEnt { double f; uint32_t node; uint32_t pad; };
@@ -241,7 +248,6 @@ struct PlShared {
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
-    int32_t frames_gen;               // pop number whose RS frames (and schedule) wave 0 has published
     long long phase[PH_COUNT];
     uint32_t hq_d;                    // result of the collective query
     int32_t hq_flag;
@@ -600,17 +606,14 @@ static __device__ const int8_t PL_SCHED_WORDS[9][8] = { { 18, 19, 20, 21, -1, -1
                                                         { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 }, { 6, 7, 8, 9, -1, -1, -1, -1 },
                                                         { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 }, { 42, 43, 44, 45, -1, -1, -1, -1 } };
 static __device__ const int32_t PL_SCHED_COST[9] = { 106, 85, 78, 60, 60, 59, 45, 43, 30 };
-__device__ __noinline__ void pl_rs_build_schedule(PlShared& s, int nq, int chk_waves)      // (a leaf call: runs once, must not be unrolled into the kernel body)
+__device__ __noinline__ void pl_rs_build_schedule(PlShared& s, int nq)      // (a leaf call: runs once, must not be unrolled into the kernel body)
 {
     // solvers by descending cost (x100 cycles per call of one wave, scripts/microbench/rs_words.hip on MI355X):
     // LRLRn, LRLRp (tauOmega: 5 sin/cos + acos + atan2), SLS (two nearly-CR tan), LRL, LRSL, LSR, LRSR, LSL, LRSLR
     // (runs once per workgroup and per child count, on one thread; its work arrays live in LDS: no stack objects)
     const int nwave = PL_THREADS / 64;
-    // chk_waves > 0: the words follow the children stage without a workgroup barrier, so the waves arrive at different
-    // times (x100 cycles, measured with avp_plan_batch_profile): wave 0 after the children poses, waves 1 .. chk_waves
-    // after their sub-step collision pass, the others at once -- the longest solvers go to the waves that are free first
 #pragma nounroll
-    for (int w = 0; w < nwave; w++) { s.sched_load[w] = chk_waves <= 0 ? 0 : w == 0 ? 106 : w <= chk_waves ? 150 : 4; s.sched_rounds[w] = 0; }
+    for (int w = 0; w < nwave; w++) { s.sched_load[w] = 0; s.sched_rounds[w] = 0; }
 #pragma nounroll
     for (int i = 0; i < PL_SCHED_ROUNDS * PL_THREADS; i++) s.sched[i] = 0xffff;
     int maxround = 0;
@@ -647,7 +650,7 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose, bo
             pose((int)threadIdx.x, x, y, th);
             s.frame[threadIdx.x] = rs_frame(x, y, th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
         }
-        if (threadIdx.x == PL_THREADS - 1 && s.sched_cnt != nq) pl_rs_build_schedule(s, nq, 0);
+        if (threadIdx.x == PL_THREADS - 1 && s.sched_cnt != nq) pl_rs_build_schedule(s, nq);
         __syncthreads();
     }
     for (int t = threadIdx.x; t < s.sched_n; t += PL_THREADS) {
@@ -661,7 +664,7 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose, bo
         for (int k = 0; k < 5; k++) s.w_l[slot][k] = l[k];
     }
     if ((int)threadIdx.x < nq) s.w_err[threadIdx.x] = 0;
-    __syncthreads();
+    // (the caller closes the pass with a workgroup barrier)
 }
 
 // set_path (rs_curve.py:137-156) for all queries at once: one thread per (query, type group); a
@@ -784,14 +787,36 @@ AVP_D void pl_rs_sample_book(PlShared& s, const avp_params& p)
 }
 AVP_D void pl_rs_sample_origins(PlShared& s, const avp_params& p)
 {
-    const RsPath& rp = s.rs;
-    double ox = 0.0, oy = 0.0, oyaw = 0.0;               // px[1] before any write
-    for (int i = 0; i < rp.n; i++) {
-        s.seg_o[i][0] = ox; s.seg_o[i][1] = oy; s.seg_o[i][2] = oyaw;   // origin = the previous segment's end point
-        if (i + 1 < rp.n) {
-            double ex, ey, eyaw;
-            rs_interpolate(rp.l[i], rp.t[i], p.maxc, ox, oy, oyaw, ex, ey, eyaw);
-            ox = ex; oy = ey; oyaw = eyaw;
+    // Whole wave. The chain "origin of segment i+1 = end pose of segment i" (rs_interpolate at the full segment length)
+    // is serial only in its additions: the yaw of every origin is a running sum of +-lengths, and with it every
+    // segment's displacement (its two sincos evaluations) is independent of the others. Lane i evaluates segment i
+    // with exactly rs_interpolate's expressions; the positions are then accumulated in segment order.
+    const int lane = threadIdx.x & 63;
+    const int n = s.rs.n;
+    double lr[AVP_RS_MAXSEG];
+    int tr[AVP_RS_MAXSEG];
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) { lr[i] = s.rs.l[i]; tr[i] = s.rs.t[i]; }      // one LDS round trip
+    double oyaw = 0.0, lmine = 0.0;                      // origin yaw of segment `lane` (px[1] before any write is 0)
+    int tmine = RS_S;
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) {
+        if (i < n && i < lane) oyaw = tr[i] == RS_S ? oyaw : (tr[i] == RS_L ? oyaw + lr[i] : oyaw - lr[i]);
+        if (i == lane) { lmine = lr[i]; tmine = tr[i]; }
+    }
+    double gdx = 0.0, gdy = 0.0;
+    if (lane < n - 1) {
+        double ex, ey, eyaw;
+        rs_interpolate(lmine, tmine, p.maxc, 0.0, 0.0, oyaw, ex, ey, eyaw);   // 0 + displacement = the displacement
+        gdx = ex; gdy = ey;
+    }
+    double ox = 0.0, oy = 0.0;
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) {
+        if (i < n) {
+            if (lane == i) { s.seg_o[i][0] = ox; s.seg_o[i][1] = oy; s.seg_o[i][2] = oyaw; }
+            ox = ox + __shfl(gdx, i, 64);                    // px = ox + gdx (:612 / :601), in segment order
+            oy = oy + __shfl(gdy, i, 64);
         }
     }
 }
@@ -822,9 +847,10 @@ AVP_D void pl_rs_sample_world(const PlanWs& w, PlShared& s, const avp_params& p,
 // lane per (pose, map column under the AABB) gathers the near obstacle points from the column bitmaps into
 // the wave's LDS queue, one lane per (pose, point) runs the exact test. pose(k, x, y, th) supplies pose k of
 // this wave's chunk; hit flags are returned through out_hit[k] (LDS).
-template <typename PoseFn>
-AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p, PlShared& s, int count, PoseFn pose, uint32_t* out_hit)
+template <bool PROFILE = false, typename PoseFn>
+AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p, PlShared& s, int count, PoseFn pose, uint32_t* out_hit, bool probe = false)
 {
+    const long long t_c0 = PH_NOW();
     const int lane = threadIdx.x & 63;
     PlWaveChk& wc = s.wchk[threadIdx.x >> 6];
     if (count <= 0) return;
@@ -887,24 +913,48 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
         }
     }
     wave_sync();
-    for (int t = lane; t < count * 64; t += 64) {
-        const int i = t >> 6, c = t & 63;
-        const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];    // ixlo, ixhi, iylo, iyhi
-        if (iylo > iyhi || c > ixhi - ixlo) continue;
-        const int ix = ixlo + c;
-        for (int wd = iylo >> 6; wd <= (iyhi >> 6); wd++) {
-            uint64_t bits = mt.bits[(size_t)ix * m.wpc + wd];
-            if (wd == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
-            if (wd == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
-            if (!bits) continue;
-            const int cnt = __popcll(bits);
-            int pos = atomicAdd(&wc.qn, cnt);
-            if (pos + cnt > PL_WQCAP) { wc.over = 1; continue; }
-            const uint32_t tag = ((uint32_t)i << 24) | ((uint32_t)ix << 12);
-            while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)((wd << 6) + bpos); }
+    if (PROFILE && probe && lane == 0) PH_X(0, t_c0);
+    // Gather: lane c owns map column ixlo + c of EVERY pose of the pass. All bitmap words of the lane are fetched first
+    // (their LDS latencies overlap), the lane reserves queue room for all its candidates with ONE atomic, then writes them
+    // -- one LDS round trip and one atomic per pass instead of one of each per pose.
+    {
+        uint64_t b0[PL_WPOSE], b1[PL_WPOSE];
+        int tot = 0;
+        bool wide = false;
+#pragma unroll
+        for (int i = 0; i < PL_WPOSE; i++) {
+            b0[i] = 0; b1[i] = 0;
+            if (i < count) {
+                const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
+                if (iylo <= iyhi && lane <= ixhi - ixlo) {
+                    const int ix = ixlo + lane, w0 = iylo >> 6, w1 = iyhi >> 6;
+                    if (w1 - w0 > 1) wide = true;                 // (cannot happen under avp_plan_batch's guard; handled by the fallback)
+                    uint64_t x0 = mt.bits[(size_t)ix * m.wpc + w0] & (~0ull << (iylo & 63));
+                    if (w1 == w0) x0 &= ~0ull >> (63 - (iyhi & 63));
+                    const uint64_t x1 = w1 > w0 ? (mt.bits[(size_t)ix * m.wpc + w1] & (~0ull >> (63 - (iyhi & 63)))) : 0ull;
+                    b0[i] = x0; b1[i] = x1;
+                    tot += __popcll(x0) + __popcll(x1);
+                }
+            }
+        }
+        int pos = tot ? atomicAdd(&wc.qn, tot) : 0;
+        if (wide || pos + tot > PL_WQCAP) { if (tot || wide) wc.over = 1; }
+        else {
+#pragma unroll
+            for (int i = 0; i < PL_WPOSE; i++) {
+                if (i < count && (b0[i] | b1[i])) {
+                    const int ix = wc.rng[i][0] + lane, w0 = wc.rng[i][2] >> 6;
+                    const uint32_t tag = ((uint32_t)i << 24) | ((uint32_t)ix << 12);
+                    uint64_t bits = b0[i];
+                    while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)((w0 << 6) + bpos); }
+                    bits = b1[i];
+                    while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)(((w0 + 1) << 6) + bpos); }
+                }
+            }
         }
     }
     wave_sync();
+    if (PROFILE && probe && lane == 0) PH_X(1, t_c0);
     if (wc.over) {
         // more candidates than the queue holds (dense clutter): every lane checks its own pose serially
         if (lane < count) { double x, y, th, cs, sn; pose(lane, x, y, th, cs, sn); wc.hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
@@ -920,6 +970,7 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
     wave_sync();
     if (lane < count) out_hit[lane] = wc.hit[lane];
     wave_sync();
+    if (PROFILE && probe && lane == 0) PH_X(2, t_c0);
 }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits until every global store of the wave
@@ -1057,7 +1108,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
     const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.frames_gen = -1; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll
@@ -1085,7 +1136,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
     if (tid == 0) s.mt = mt;
     const int nchild = 2 * p.n_steer;
     const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
-    int32_t gen = 0;
 
     for (;;) {
         __syncthreads();
@@ -1154,10 +1204,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : s.k_steer[cn.steer_i];
             }
             n_pops++;
-            gen++;                                   // pop counter of this workgroup over all its problems (hand-over flags)
 
             // ---- children poses (expand_node :134-151) + try_reach_goal radius test (:308-312) ----------
             const long long t_d = PH_NOW();
+            const long long t_pop0 = t_d;
             const bool one_pass = nchild + 1 <= PL_RSQ;          // shot + all children fit one RS pass
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
             const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
@@ -1182,15 +1232,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 c.rs_err = 0;
                 c.L = 0;
                 if (one_pass) s.frame[tid + 1] = rs_frame(c.x, c.y, c.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            } else if (one_pass && tid == nchild) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            else if (one_pass && tid == nchild + 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1, min(PL_THREADS / 64 - 2, (nchild * p.n_sub + PL_WPOSE - 1) / PL_WPOSE));
-            if (one_pass && tid < 64) {
-                // wave 0 publishes the frames (and, the first time, the schedule): the other waves start on the words as
-                // soon as they are through with their sub-step checks -- no workgroup barrier between the two stages
-                wave_sync();
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (tid == 0) *(volatile int32_t*)&s.frames_gen = gen;
-            }
+            } else if (one_pass && tid == PL_THREADS - 2) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1);
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
@@ -1198,14 +1241,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const int nwave = PL_THREADS / 64;
             const int nsubs = nchild * p.n_sub;
             {
-                // full passes (PL_WPOSE poses) on as few waves as possible: the cost of a collision pass hardly depends on
-                // its pose count, and every wave that does not check starts on the Reeds-Shepp words at once
-                const int nw = min(nwave - 2, (nsubs + PL_WPOSE - 1) / PL_WPOSE);
-                const int per = max(1, min(PL_WPOSE, (nsubs + nw - 1) / nw));
+                const int nw = nwave - 2;
+                const int per = max(1, min(PL_WPOSE, (nsubs + nw - 1) / nw));      // spread the poses evenly over the waves
                 if (wave >= 1 && wave <= nw) {
                     for (int base = (wave - 1) * per; base < nsubs; base += nw * per) {
                         const int cnt = min(per, nsubs - base);
-                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+                        pl_check_wave<PROFILE>(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             const int t = base + k;
                             const int ci = s.sub_child[t], j = s.sub_j[t], si = s.sub_steer[t];
                             const double td = ci < p.n_steer ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
@@ -1213,17 +1254,14 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             avp_sincos(th, sn, cs);
                             x = cn.x + td * cs;
                             y = cn.y + td * sn;
-                        }, &s.chk_hit[base]);
+                        }, &s.chk_hit[base], wave == 1);
                     }
                 }
             }
-            if (one_pass) {
-                if (tid >= 64) {
-                    if (lane == 0) while (*(volatile int32_t*)&s.frames_gen != gen) __builtin_amdgcn_s_sleep(1);
-                    wave_sync();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
-            } else __syncthreads();
+            PH_MARK(0);
+            __syncthreads();
+            for (int t = tid; t < nsubs; t += PL_THREADS)
+                if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
             const long long t_e = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_CHILD] += t_e - t_d;
 
@@ -1240,12 +1278,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (g == 0) { x = cn.x; y = cn.y; th = cn.th; }
                         else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
                     }, one_pass);
+                    if (base == 0) PH_MARK(1);
+                    __syncthreads();
                     if (PROFILE && tid == 0) s.phase[PH_RS_WORDS] += clock64() - t_e;
-                    if (base == 0) {
-                        // (behind the words' barrier: every sub-step check has landed) first colliding sub-step per child
-                        for (int t = tid; t < nsubs; t += PL_THREADS)
-                            if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
-                    }
                     // set_path and arg-min, a whole query per wave (20 lanes run its type groups, then the wave folds):
                     // no cross-wave hand-over. Wave 0 owns the shot (query 0 of the first pass) and goes straight on to
                     // the sampler's index bookkeeping; the last wave, after its children, walks the chain of segment origins as
@@ -1253,10 +1288,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     const int q_first = base == 0 ? 1 : 0;              // first query of this pass that is a child
                     if (wave == 0) {
                         if (base == 0) {
+                            const long long t_a0 = PH_NOW();
                             if (lane < 20) pl_rs_accept_group(s, p, 0, lane);
                             wave_sync();
+                            if (PROFILE && lane == 0) PH_X(3, t_a0);
                             RsPath rp;
                             const int st = pl_rs_fold_wave(s, 0, rp);
+                            if (PROFILE && lane == 0) PH_X(4, t_a0);
                             if (lane == 0) {
                                 s.rs_status = in_radius ? st : 0;
                                 const bool shot = in_radius && !st;
@@ -1264,6 +1302,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 *(volatile int32_t*)&s.shot_ready = shot ? 1 : 2;
                                 if (shot) { s.n_rs += 1; pl_rs_sample_book(s, p); }
+                                if (PROFILE) PH_X(5, t_a0);
                             }
                         }
                     } else {
@@ -1283,13 +1322,15 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             }
                         }
                         if (wave == nwave - 1 && base == 0) {
-                            if (lane == 0) {
-                                while (*(volatile int32_t*)&s.shot_ready == 0) __builtin_amdgcn_s_sleep(1);
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                                if (*(volatile int32_t*)&s.shot_ready == 1) pl_rs_sample_origins(s, p);
-                            }
+                            if (lane == 0) while (*(volatile int32_t*)&s.shot_ready == 0) __builtin_amdgcn_s_sleep(1);
+                            wave_sync();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            const long long t_o0 = PH_NOW();
+                            if (*(volatile int32_t*)&s.shot_ready == 1) pl_rs_sample_origins(s, p);      // (wave-uniform)
+                            if (PROFILE && lane == 0) PH_X(6, t_o0);
                         }
                     }
+                    if (base == 0) PH_MARK(2);
                     __syncthreads();
                 }
             }
@@ -1372,6 +1413,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     } else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
                 }
             }
+            PH_MARK(3);
             pl_lds_barrier();
             const long long t_f = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
@@ -1462,6 +1504,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 }
                 if (PROFILE) s.phase[PH_RESOLVE] += clock64() - t_f;
             }
+            PH_MARK(4);
             __syncthreads();
         }
         __syncthreads();
@@ -1517,7 +1560,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         for (int j = 0; j < p.n_sub; j++) {
                             const double td = nd.forward ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
                             const double th_j = avp_pi_2_pi(par.th + s.k_dth_ddt[nd.steer_i][j]);
-                            push(par.x + td * avp_cos(th_j), par.y + td * avp_sin(th_j), th_j, 0.0);
+                            double s_j, c_j;
+                            avp_sincos(th_j, s_j, c_j);
+                            push(par.x + td * c_j, par.y + td * s_j, th_j, 0.0);
                         }
                     }
                     prev = node;

@@ -165,7 +165,9 @@ AVP_D void rs_tauOmega(double u, double v, double xi, double eta, double phi, do
     const double A = sin_u - sin_d;
     const double B = cos_u - cos_d - 1.0;
     const double t1 = avp_atan2(eta * A - xi * B, xi * A + eta * B);
-    const double t2 = 2.0 * (cos_d - avp_cos(v) - cos_u) + 3.0;
+    double sin_v, cos_v;                                          // (the branch-free fused form; sin_v unused)
+    avp_sincos(v, sin_v, cos_v);
+    const double t2 = 2.0 * (cos_d - cos_v - cos_u) + 3.0;
     tau = t2 < 0 ? avp_M(t1 + AVP_PI) : avp_M(t1);
     omega = avp_M(tau - u + v - phi);
 }
@@ -413,16 +415,19 @@ AVP_D int rs_optimal(double q0x, double q0y, double q0t, double q1x, double q1y,
 // rs_curve.py:597-624
 AVP_D void rs_interpolate(double l, int m, double maxc, double ox, double oy, double oyaw, double& px, double& py, double& pyaw)
 {
+    // One evaluation of sincos(oyaw) serves both segment kinds: the straight segment uses it directly (:599-601), the arcs
+    // use sin(-oyaw) = -sin(oyaw), cos(-oyaw) = cos(oyaw) -- exact identities of the restated glibc algorithm (every
+    // step is odd / even in its argument) -- so a wave whose lanes hold both kinds runs two sincos bodies, not three.
+    double sy, cy;
+    avp_sincos(oyaw, sy, cy);
+    double sl = 0.0, cl = 1.0;
+    if (m != RS_S) avp_sincos(l, sl, cl);                                              // each used twice (:605-612)
     if (m == RS_S) {
-        double so, co;
-        avp_sincos(oyaw, so, co);
-        px = ox + l / maxc * co;
-        py = oy + l / maxc * so;
+        px = ox + l / maxc * cy;
+        py = oy + l / maxc * sy;
         pyaw = oyaw;
     } else {
-        double sl, cl, so, co;                                                       // each used twice (:605-612)
-        avp_sincos(l, sl, cl);
-        avp_sincos(-oyaw, so, co);
+        const double so = -sy, co = cy;                                                // sin, cos of -oyaw
         const double ldx = sl / maxc;
         const double ldy = (m == RS_L) ? (1.0 - cl) / maxc : (1.0 - cl) / (-maxc);
         const double gdx = co * ldx + so * ldy;

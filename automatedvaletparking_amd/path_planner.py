@@ -31,7 +31,7 @@ class AvpPlanResult(C.Structure):
                 ("n_checks", C.c_int64), ("n_rs", C.c_int64), ("n_closed", C.c_int64), ("n_open", C.c_int64),
                 ("h_cells", C.c_int64), ("h_misses", C.c_int64), ("global_index", C.c_int64), ("n_nodes", C.c_int64),
                 ("rs_types", C.c_int8 * 8), ("rs_lengths", C.c_double * 5), ("rs_L", C.c_double),
-                ("rs_start", C.c_double * 3), ("rs_dir0", C.c_int32), ("slot", C.c_int32), ("phase_cycles", C.c_int64 * 16)]
+                ("rs_start", C.c_double * 3), ("rs_dir0", C.c_int32), ("slot", C.c_int32), ("phase_cycles", C.c_int64 * 64)]
 
 
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_pops", "<i4"), ("n_astar", "<i4"), ("n_rs_pts", "<i4"), ("n_final", "<i4"),
@@ -39,7 +39,7 @@ RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_pops", "<i4"), ("n_astar", "<i4"
                          ("n_checks", "<i8"), ("n_rs", "<i8"), ("n_closed", "<i8"), ("n_open", "<i8"), ("h_cells", "<i8"),
                          ("h_misses", "<i8"), ("global_index", "<i8"), ("n_nodes", "<i8"),
                          ("rs_types", "i1", (8,)), ("rs_lengths", "<f8", (5,)), ("rs_L", "<f8"),
-                         ("rs_start", "<f8", (3,)), ("rs_dir0", "<i4"), ("slot", "<i4"), ("phase_cycles", "<i8", (16,))])
+                         ("rs_start", "<f8", (3,)), ("rs_dir0", "<i4"), ("slot", "<i4"), ("phase_cycles", "<i8", (64,))])
 assert RESULT_DTYPE.itemsize == C.sizeof(AvpPlanResult)
 
 

@@ -111,7 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["auto", "c2", "batch4096", "c3", "c5"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="headline only (the PMC passes use it: per-launch counters of one workload)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only")
+    ap.add_argument("--pmc-mode", action="store_true", help="headline + the footprint kernel only (the rocprofv3 PMC passes: per-launch counters)")
     a = ap.parse_args()
 
     import torch
@@ -340,7 +341,7 @@ def main():
         if world == 1 and not use_dist and not a.no_extras:
             # ---- extras on the same GPU: the other BASELINE workloads ------------------------------------------------
             for name in ("batch4096", "c3", "c5"):
-                if name == workload:
+                if name == workload or a.pmc_mode:
                     continue
                 lab, xcfg, xcap, xsets = build(name)
                 xg = [Group(m, veh, xcfg, st, go, local, xcap) for (m, st, go) in xsets]
@@ -390,7 +391,7 @@ def main():
                 rc["lds_busy_frac"] = ck.get("lds_busy_frac")
                 rc["lds_bank_conflict_frac"] = ck.get("lds_bank_conflict_frac")
             out["roofline_check"] = rc
-            if not a.no_cpu_baseline:
+            if not a.no_cpu_baseline and not a.pmc_mode:
                 from oracle import oracle
                 g0 = groups[0]
                 o = oracle.Oracle(g0.m, veh, wcfg, max_pops=cap)

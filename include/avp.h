@@ -112,6 +112,10 @@ int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, const doubl
  */
 int32_t avp_corridor_batch(avp_map* map, double expand_dis, const double* x, const double* y, const double* th,
                            int64_t n, double* out);
+/* The same with an explicit kernel choice: variant 0 = production kernel (candidates compacted per wave, running
+ * minima by LDS atomics), 1 = lane-per-way-point kernel (kept for cross-checking the production kernel on the GPU). */
+int32_t avp_corridor_batch_v(avp_map* map, double expand_dis, const double* x, const double* y, const double* th,
+                             int64_t n, double* out, int32_t variant);
 
 /*
  * Replaces: rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-134), one call per (start, goal)
@@ -154,12 +158,13 @@ typedef struct avp_plan_result {
     double rs_start[3];      /* sample 0 of the last RS shot = pose of the last popped node        */
     int32_t rs_dir0;         /* its direction flag                                                 */
     int32_t slot;            /* the persistent workgroup (0 .. n_slots-1) that ran the problem      */
-    int64_t phase_cycles[16];/* diagnostics, avp_plan_batch_profile only (else 0): shader cycles per phase of the
+    int64_t phase_cycles[64];/* diagnostics, avp_plan_batch_profile only (else 0): shader cycles per phase of the
                                 problem: 0 init, 1 heap pop, 2-3 wave-0 resolution: classify, node/hash writes, 4 speculative
                                 resolution || shot checks (wall), 5 children || sub-steps (wall), 6 RS words .. replay (wall),
                                 7 rest of the resolution, 8 of which sweep, 9 finish, 10 wave-0 resolution: heap pushes,
                                 11 RS words until their barrier, 12 wave-0 children stage, 13-14 shot checks round 0 / all
-                                rounds (wave 1), 15 spare */
+                                rounds (wave 1), 15 pop-ahead; 16 + 5 w + k: arrival of wave w at barrier k of a pop (k = 0 children /
+                                sub-steps, 1 RS words, 2 set_path .. replay, 3 resolution / shot, 4 end), cycles since the pop began */
 } avp_plan_result;
 
 /*

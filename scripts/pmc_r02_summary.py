@@ -1,0 +1,77 @@
+"""Fold the rocprofv3 PMC passes of `bench.py --pmc-mode` into profiles/r02_pmc_summary.json.
+
+    python scripts/pmc_r02_summary.py <dir with one sub-directory per pass> > profiles/r02_pmc_summary.json
+
+Passes (each its own run, --kernel-trace --pmc only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes):
+  sq    SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS
+  lds   SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_SALU
+  fetch FETCH_SIZE     write WRITE_SIZE    (KB; gfx950 FETCH_SIZE counts 64 B per 128-B request: HBM bytes = (2 FETCH + WRITE) * 1024)
+SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (4 shader cycles). Counter values are summed over all
+instances of a dispatch; per kernel the launches of the largest grid are averaged. The file is stamped with the hash of
+the kernel sources it was measured on; bench.py refuses a stale one."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import source_hash  # noqa: E402
+
+
+def collect(root):
+    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))      # kernel -> dispatch -> counter -> value
+    grid = {}
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+            d = (f, r["Dispatch_Id"])
+            per[k][d][r["Counter_Name"]] += float(r["Counter_Value"])
+            grid[(k, d)] = int(r.get("Grid_Size", 0) or 0)
+    out = {}
+    for k, disp in per.items():
+        gmax = max(grid[(k, d)] for d in disp)
+        sel = [v for d, v in disp.items() if grid[(k, d)] == gmax]
+        out[k] = {c: sum(v[c] for v in sel) / len(sel) for c in sel[0]}
+        out[k]["launches"] = len(sel)
+        out[k]["grid_size"] = gmax
+    return out
+
+
+def main():
+    base = sys.argv[1]
+    passes = {name: collect(os.path.join(base, name)) for name in ("sq", "lds", "fetch", "write") if os.path.isdir(os.path.join(base, name))}
+    res = {"source_hash": source_hash(),
+           "command": "rocprofv3 --kernel-trace --pmc <pass counters> -- python bench.py --steps 3 --warmup 1 --pmc-mode  (one run per pass)",
+           "units": "SQ_* cycle counters in quad-cycles; *_simd_cycles in shader cycles; bytes per launch"}
+    for kern, key in (("plan_kernel<true, false>", "plan_kernel"), ("check_distance_kernel<true>", "check_distance_kernel"),
+                      ("rs_optimal_kernel", "rs_optimal_kernel"), ("corridor_kernel", "corridor_kernel"), ("check_circle_kernel", "check_circle_kernel")):
+        e = {}
+        sq = passes.get("sq", {}).get(kern)
+        if sq:
+            e["raw_sq"] = sq
+            e["valu_active_simd_cycles_per_launch"] = 4.0 * sq["SQ_ACTIVE_INST_VALU"]
+            e["wait_any_frac"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+            e["valu_active_frac_of_wave_cycles"] = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
+            e["valu_insts_per_launch"] = sq["SQ_INSTS_VALU"]
+        ld = passes.get("lds", {}).get(kern)
+        if ld:
+            e["raw_lds"] = ld
+            if ld.get("SQ_LDS_IDX_ACTIVE"):
+                e["lds_bank_conflict_frac"] = ld["SQ_LDS_BANK_CONFLICT"] / ld["SQ_LDS_IDX_ACTIVE"]
+            e["lds_insts_per_launch"] = ld.get("SQ_INSTS_LDS")
+            e["f64_valu_insts_per_launch"] = sum(ld.get(c, 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"))
+        fe, wr = passes.get("fetch", {}).get(kern), passes.get("write", {}).get(kern)
+        if fe and wr:
+            e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = fe["FETCH_SIZE"], wr["WRITE_SIZE"]
+            e["hbm_bytes_per_launch_corrected"] = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
+        if e:
+            res[key] = e
+    json.dump(res, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()

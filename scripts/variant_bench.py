@@ -80,9 +80,12 @@ if not a.no_profile and hasattr(_native.lib(), "avp_plan_batch_profile"):
         cap = rp["status"] == 4
         ph = rp["phase_cycles"].astype(np.float64)
         names = ["init", "pop", "res_classify", "res_write", "resolve||shot", "children||substeps", "rs_words..replay", "slow_resolve", "(sweep)", "finish",
-                 "res_push", "rs_words_only", "children_w0", "shot_round0", "shot_all", "-"]
+                 "res_push", "rs_words_only", "children_w0", "shot_round0", "shot_all", "pop_ahead"]
         out["phase_cyc_per_pop"] = {n: round(float(ph[cap, k].mean() / 1000), 0) for k, n in enumerate(names) if n != "-"}
         out["cyc_per_pop"] = round(float(ph[cap][:, [1, 4, 5, 6, 7]].sum(axis=1).mean() / 1000), 0)
+        out["wave_arrivals_kcyc"] = [[round(float(ph[cap, 16 + 5 * w + k].mean() / 1e6), 1) for k in range(5)] for w in range(8)]
+        out["probes_cyc"] = {n: round(float(ph[cap, 56 + k].mean() / 1000)) for k, n in enumerate(
+            ["chk_setup", "chk_gather", "chk_all", "shot_accept", "shot_fold", "shot_book", "origins", "-"]) if n != "-"}
         one = rp["n_pops"] == 1
         out["one_pop_total_cyc"] = round(float(ph[one][:, [0, 1, 4, 5, 6, 7, 9]].sum(axis=1).mean()))
     except Exception as e:     # an old library without the entry

@@ -50,9 +50,9 @@ def test_device_div_sqrt_hypot_ieee(vehicle, cfg):
     assert np.array_equal(hh[sub], np.array([math.hypot(x, y) for x, y in zip(a[sub], b[sub])]))
 
 
-@pytest.mark.parametrize("k", [1, 4, 5, 13, 19, 20])
+@pytest.mark.parametrize("k", list(range(1, 21)))      # G3 for all 20 BenchmarkCases
 def test_golden_collision_vectors(k, vehicle, cfg):
-    g3 = gold("g3_collision.npz")
+    g3 = gold("g3_collision.npz" if k in (1, 4, 5, 13, 19, 20) else "g3_collision_rest.npz")
     dm = _dm(case_map_from_gold(k), vehicle, cfg)
     poses = g3[f"c{k}_poses"]
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), g3[f"c{k}_dist"])

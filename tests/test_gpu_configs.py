@@ -49,5 +49,5 @@ def test_c5_full(vehicle, cfg):
     assert len(obs) >= 100
     res, bad, _, _ = C.plan_and_compare(m, vehicle, c5, starts, goals, max_nodes=8192)
     assert len(res) == 1024 and not bad, (len(bad), bad[:8])
-    assert sum(r.status == 0 for r in res) > 0 and all(r.status in (0, 1, 4) for r in res)
+    assert sum(r.status == 0 for r in res) > 0 and all(r.status in (0, 1, 2, 4) for r in res)
     assert all(r.counters["n_rs"] >= r.n_pops for r in res)          # the shot runs at every pop

@@ -23,9 +23,9 @@ def test_index_and_is_obstacle(k, vehicle, cfg):
     assert np.array_equal(ob, g2[f"c{k}_obst"])
 
 
-@pytest.mark.parametrize("k", [1, 4, 5, 13, 19, 20])
+@pytest.mark.parametrize("k", list(range(1, 21)))      # G3 for all 20 BenchmarkCases
 def test_collision_booleans(k, vehicle, cfg):
-    g3 = gold("g3_collision.npz")
+    g3 = gold("g3_collision.npz" if k in (1, 4, 5, 13, 19, 20) else "g3_collision_rest.npz")
     o = _oracle(case_map_from_gold(k), vehicle, cfg)
     poses = g3[f"c{k}_poses"]
     d, near = o.check_batch(poses, kind=0, want_near=True)
