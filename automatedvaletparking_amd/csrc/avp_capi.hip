@@ -10,6 +10,7 @@
 #include "avp_check_kernels.h"
 #include "avp_rs_kernels.h"
 #include "avp_plan_kernels.h"
+#include "avp_planw_kernels.h"
 #include "avp_raster_kernels.h"
 
 static thread_local char g_err[512] = "";

@@ -48,12 +48,26 @@ enum { PH_INIT = 0, PH_POP, PH_RES_CLASSIFY, PH_RES_WRITE, PH_SHOT_CHECK, PH_CHI
                                // 3 resolution / shot checks done, 4 end of the pop
        PH_X0 = PH_WAVE0 + 5 * 8,   // 8 fine-grained probes (see the PH_X uses)
        PH_COUNT = PH_X0 + 8 };
-#define PH_X(k, t0) do { if (PROFILE) s.phase[PH_X0 + (k)] += clock64() - (t0); } while (0)
-#define PH_MARK(k) do { if (PROFILE && (threadIdx.x & 63) == 0) s.phase[PH_WAVE0 + 5 * (threadIdx.x >> 6) + (k)] += clock64() - t_pop0; } while (0)
+#define PH_X(k, t0) do { if constexpr (PROFILE) s.phase[PH_X0 + (k)] += clock64() - (t0); } while (0)
+#define PH_MARK(k) do { if constexpr (PROFILE) { if ((threadIdx.x & 63) == 0) s.phase[PH_WAVE0 + 5 * (threadIdx.x >> 6) + (k)] += clock64() - t_pop0; } } while (0)
 // The timers are compiled into the PROFILE instantiation only (avp_plan_batch_profile): s_memtime instrumentation costs
 // ~10 % of the wave cycles, so the production kernel carries none and reports phase_cycles = 0.
 #define PH_NOW() (PROFILE ? clock64() : 0ll)
-#define PH_ACC(k, t0) do { if (PROFILE && threadIdx.x == 0) s.phase[k] += clock64() - (t0); } while (0)
+#define PH_ACC(k, t0) do { if constexpr (PROFILE) { if (threadIdx.x == 0) s.phase[k] += clock64() - (t0); } } while (0)
+
+// Who cooperates on one problem: the whole workgroup (plan_kernel: one problem per workgroup) or one wave
+// (plan_wave_kernel: one problem per wave, eight independent problems per workgroup).
+struct CoopWG {
+    static constexpr int N = PL_THREADS;
+    static __device__ __forceinline__ int tid() { return threadIdx.x; }
+    static __device__ __forceinline__ void sync() { __syncthreads(); }
+};
+struct CoopWave {
+    static constexpr int N = 64;
+    static __device__ __forceinline__ int tid() { return threadIdx.x & 63; }
+    // lanes of one wave hand data to each other through LDS and through global memory (queues, arena): both must have landed
+    static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); wave_sync(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+};
 
 struct PlNode {
     double x, y, th, g, h, f;
@@ -273,6 +287,8 @@ struct PlShared {
     // wave-local cooperative collision passes: every wave owns a scratch area (no workgroup barrier inside)
     int32_t chk_qover;
     PlWaveChk wchk[PL_THREADS / 64];
+    static constexpr int RS_CAP = PL_RS_CAP;
+    __device__ __forceinline__ PlWaveChk& wave_chk() { return wchk[threadIdx.x >> 6]; }
     uint32_t chk_hit[PL_MAXCHILD * 4];   // hit flag per sub-step pose of the current pop
     int32_t next_cur, have_next;      // node popped ahead by wave 0 at the end of its resolution (see pl_resolve_fast_wave)
 };
@@ -322,12 +338,16 @@ AVP_D void pl_hash_put_atomic(const PlanWs& w, int64_t hashCap, int32_t pos, dou
 // ---- CPython heapq on node positions, key = node.f (Node.__lt__ hybrid_a_star.py:61-68) ---------
 // The key is stored next to the position (one load per comparison); an in-place improvement of an
 // open node updates both copies and, like the reference (:224-230), does NOT restore the heap order.
-AVP_D PlHeapEnt pl_heap_get(const PlanWs& w, const PlShared& s, int32_t pos) { return w.heap[pos]; }
-AVP_D void pl_heap_set(const PlanWs& w, PlShared& s, int32_t pos, PlHeapEnt e) { w.heap[pos] = e; w.nodes[e.node].heap_pos = pos; }
-AVP_D void pl_heap_set_key(const PlanWs& w, PlShared& s, int32_t pos, double f) { w.heap[pos].f = f; }
+template <class S>
+AVP_D PlHeapEnt pl_heap_get(const PlanWs& w, const S& s, int32_t pos) { return w.heap[pos]; }
+template <class S>
+AVP_D void pl_heap_set(const PlanWs& w, S& s, int32_t pos, PlHeapEnt e) { w.heap[pos] = e; w.nodes[e.node].heap_pos = pos; }
+template <class S>
+AVP_D void pl_heap_set_key(const PlanWs& w, S& s, int32_t pos, double f) { w.heap[pos].f = f; }
 // (the item being moved is passed in registers: re-reading a slot this thread has just written would put
 // two global round trips on the serial path of every push / pop)
-AVP_D void pl_siftdown(const PlanWs& w, PlShared& s, int32_t startpos, int32_t pos, const PlHeapEnt newitem)
+template <class S>
+AVP_D void pl_siftdown(const PlanWs& w, S& s, int32_t startpos, int32_t pos, const PlHeapEnt newitem)
 {
     while (pos > startpos) {
         const int32_t parentpos = (pos - 1) >> 1;
@@ -337,7 +357,8 @@ AVP_D void pl_siftdown(const PlanWs& w, PlShared& s, int32_t startpos, int32_t p
     }
     pl_heap_set(w, s, pos, newitem);
 }
-AVP_D void pl_siftup(const PlanWs& w, PlShared& s, int32_t pos, int32_t endpos, const PlHeapEnt newitem)
+template <class S>
+AVP_D void pl_siftup(const PlanWs& w, S& s, int32_t pos, int32_t endpos, const PlHeapEnt newitem)
 {
     const int32_t startpos = pos;
     int32_t childpos = 2 * pos + 1;
@@ -354,7 +375,8 @@ AVP_D void pl_siftup(const PlanWs& w, PlShared& s, int32_t pos, int32_t endpos, 
     }
     pl_siftdown(w, s, startpos, pos, newitem);
 }
-AVP_D void pl_heap_push(const PlanWs& w, PlShared& s, uint32_t node, double f)
+template <class S>
+AVP_D void pl_heap_push(const PlanWs& w, S& s, uint32_t node, double f)
 {
     PlHeapEnt e; e.f = f; e.node = node; e.pad = 0;
     s.nheap++;
@@ -381,7 +403,8 @@ AVP_D void pl_heap_push_wave(const PlanWs& w, int32_t nheap, uint32_t node, doub
     if (lane < j) { w.heap[mine] = anc; w.nodes[anc.node].heap_pos = mine; }
     if (lane == j) { PlHeapEnt e; e.f = f; e.node = node; e.pad = 0; w.heap[mine] = e; w.nodes[node].heap_pos = mine; }
 }
-AVP_D uint32_t pl_heap_pop(const PlanWs& w, PlShared& s)
+template <class S>
+AVP_D uint32_t pl_heap_pop(const PlanWs& w, S& s)
 {
     const PlHeapEnt lastelt = pl_heap_get(w, s, --s.nheap);
     if (s.nheap) {
@@ -395,7 +418,8 @@ AVP_D uint32_t pl_heap_pop(const PlanWs& w, PlShared& s)
 // ---- heuristic sweep ---------------------------------------------------------------------------
 // Relax lattice cell (col, row) with new distance nd, discovered from (srcDist, srcId) via
 // neighbour slot nbr (compute_h.py:216-235 add_grid_to_openlist).
-AVP_D void pl_relax(const DevMap& m, const PlanWs& w, PlShared& s, int col, int row, uint32_t nd, uint32_t srcDist,
+template <class S>
+AVP_D void pl_relax(const DevMap& m, const PlanWs& w, S& s, int col, int row, uint32_t nd, uint32_t srcDist,
                     int64_t srcId, int nbr)
 {
     if (col < s.colMin || col > s.colMax || row < s.rowMin || row > s.rowMax) return;   // one-sided bounds tests :95-191
@@ -424,17 +448,17 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, PlShared& s, int col, int 
 }
 
 // Expand bucket s.E (all threads). Each thread handles (entry, neighbour) pairs.
-template <bool PROFILE>
-AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
+template <bool PROFILE, class Coop = CoopWG, class S>
+AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
 {
     const long long t_sw = PH_NOW();
     const int q = s.E & (PL_NQ - 1);
     const uint32_t cnt = min(s.qcount[q], (uint32_t)PL_QCAP);
-    __syncthreads();
+    Coop::sync();
     const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
     const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };      // y up = row down
     const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
-    for (uint32_t p = threadIdx.x; p < cnt * 8u; p += PL_THREADS) {
+    for (uint32_t p = Coop::tid(); p < cnt * 8u; p += Coop::N) {
         const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + (p >> 3)];
         const int nbr = (int)(p & 7);
         const uint32_t d = (uint32_t)(ent >> 32);
@@ -450,9 +474,9 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
         if (nbr == 0) atomicAdd((unsigned long long*)&s.h_cells, 1ull);
         pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) { s.qcount[q] = 0; s.E += 1; if (PROFILE) s.phase[PH_SWEEP] += clock64() - t_sw; }
-    __syncthreads();
+    Coop::sync();
+    if (Coop::tid() == 0) { s.qcount[q] = 0; s.E += 1; if constexpr (PROFILE) s.phase[PH_SWEEP] += clock64() - t_sw; }
+    Coop::sync();
 }
 
 // Heuristic query (hybrid_a_star.py:268-283 + compute_h.py:198-214), split in two:
@@ -460,7 +484,8 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, PlShared& s)
 //  pl_hquery_miss: collective sweep extension until the cell's distance is final (all threads).
 // force_miss: the initial compute_path(x0, y0) of hybrid_a_star.__init__ (:89-91) always sweeps.
 AVP_D bool pl_id_in_range(const DevMap& m, int64_t id) { return id >= 0 && id < (int64_t)m.S * (m.Sy + 3); }
-AVP_D bool pl_hquery_hit(const DevMap& m, const PlShared& s, int64_t id, uint32_t d, uint32_t& d_out)
+template <class S>
+AVP_D bool pl_hquery_hit(const DevMap& m, const S& s, int64_t id, uint32_t d, uint32_t& d_out)
 {
     // d = current dist[id] (PL_UNSEEN when the id is outside the id space)
     if (id == s.goal_id) { d_out = 0; return true; }                 // first closedlist entry: the goal Grid, distance 0
@@ -469,26 +494,26 @@ AVP_D bool pl_hquery_hit(const DevMap& m, const PlShared& s, int64_t id, uint32_
     return false;
 }
 
-template <bool PROFILE = false>
-AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, PlShared& s, int64_t id)
+template <bool PROFILE = false, class Coop = CoopWG, class S>
+AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, S& s, int64_t id)
 {
-    __syncthreads();
-    if (!(id >= 0 && id < (int64_t)m.S * (m.Sy + 3))) { if (threadIdx.x == 0) s.hq_d = PL_UNSEEN; __syncthreads(); return; }
+    Coop::sync();
+    if (!(id >= 0 && id < (int64_t)m.S * (m.Sy + 3))) { if (Coop::tid() == 0) s.hq_d = PL_UNSEEN; Coop::sync(); return; }
     for (;;) {
         const uint32_t d = w.dist[id];
         if (d != PL_UNSEEN && pl_bucket(d) <= s.E) break;
         const uint32_t pending = s.qcount[0] + s.qcount[1] + s.qcount[2] + s.qcount[3];
         if (pending == 0 || s.qover) break;
         if (s.qcount[s.E & (PL_NQ - 1)] == 0) {
-            __syncthreads();
-            if (threadIdx.x == 0) s.E += 1;
-            __syncthreads();
+            Coop::sync();
+            if (Coop::tid() == 0) s.E += 1;
+            Coop::sync();
             continue;
         }
-        pl_expand_bucket<PROFILE>(m, w, s);
+        pl_expand_bucket<PROFILE, Coop>(m, w, s);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    Coop::sync();
+    if (Coop::tid() == 0) {
         const uint32_t d = w.dist[id];
         s.hq_d = (d != PL_UNSEEN && pl_bucket(d) <= s.E) ? d : PL_UNSEEN;
         s.h_misses += 1;
@@ -497,18 +522,19 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, PlShared& s, int64_t
             w.flags[id] |= PL_FLAG_T;
         }
     }
-    __syncthreads();
+    Coop::sync();
 }
 
 // Heuristic-sweep state for a new goal: clears the id-space arrays, builds the goal-anchored lattice
 // description (compute_h.py:89-186 positions are xf +- k*dx by repeated addition) and performs the first
 // update_openlist(initial_grid) (:207-210). Sets s.status = 6 when the lattice is not regular w.r.t. the
 // id grid or the goal lies outside the map. All threads.
-AVP_D void pl_sweep_init(const DevMap& m, const PlanWs& w, PlShared& s, const PlanDims& dims, double gx, double gy)
+template <class Coop = CoopWG, class S>
+AVP_D void pl_sweep_init(const DevMap& m, const PlanWs& w, S& s, const PlanDims& dims, double gx, double gy)
 {
-    const int tid = threadIdx.x;
-    for (int64_t i = tid; i < dims.idCap; i += PL_THREADS) { w.dist[i] = PL_UNSEEN; w.flags[i] = 0; }
-    for (int64_t i = tid; i < dims.rowCap; i += PL_THREADS) w.aliasKey[i] = ~0ull;
+    const int tid = Coop::tid();
+    for (int64_t i = tid; i < dims.idCap; i += Coop::N) { w.dist[i] = PL_UNSEEN; w.flags[i] = 0; }
+    for (int64_t i = tid; i < dims.rowCap; i += Coop::N) w.aliasKey[i] = ~0ull;
     if (tid == 0) {
         s.E = 0; s.qover = 0; s.hasF = 0; s.dF = 0; s.idF = 0;
         for (int q = 0; q < PL_NQ; q++) s.qcount[q] = 0;
@@ -544,14 +570,14 @@ AVP_D void pl_sweep_init(const DevMap& m, const PlanWs& w, PlShared& s, const Pl
         s.regular = regular;
         if (!regular) s.status = 6;
     }
-    __syncthreads();
+    Coop::sync();
     if (s.status == 0 && tid < 8) {
         const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
         const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
         const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
         pl_relax(m, w, s, s.col0 + dc[tid], s.row0 + dr[tid], cost[tid], 0, s.goal_id, tid);
     }
-    __syncthreads();
+    Coop::sync();
 }
 
 // Test hook: the heuristic field alone. One workgroup runs the reference's query sequence
@@ -756,7 +782,8 @@ AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
 //   pl_rs_sample_book    -- the index bookkeeping: which sample lies at which arc length of which segment;
 //   pl_rs_sample_origins -- the chain of segment origins (end pose of the previous segment).
 // They touch disjoint state, so two waves run them side by side.
-AVP_D void pl_rs_sample_book(PlShared& s, const avp_params& p)
+template <class S>
+AVP_D void pl_rs_sample_book(S& s, const avp_params& p)
 {
     const double maxc = p.maxc;
     const RsPath& rp = s.rs;
@@ -764,7 +791,7 @@ AVP_D void pl_rs_sample_book(PlShared& s, const avp_params& p)
     const int point_num = (int)(rp.L / step) + rp.n + 3;
     s.smp_point_num = point_num;
     s.smp_hi = 0;
-    if (point_num > PL_RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) { s.rs_status = 5; return; }
+    if (point_num > S::RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) { s.rs_status = 5; return; }
     int ind = 1, hi = 0;
     double d = rp.l[0] > 0.0 ? step : -step;
     double pd = d, ll = 0.0;
@@ -785,7 +812,8 @@ AVP_D void pl_rs_sample_book(PlShared& s, const avp_params& p)
     }
     s.smp_hi = hi;
 }
-AVP_D void pl_rs_sample_origins(PlShared& s, const avp_params& p)
+template <class S>
+AVP_D void pl_rs_sample_origins(S& s, const avp_params& p)
 {
     // Whole wave. The chain "origin of segment i+1 = end pose of segment i" (rs_interpolate at the full segment length)
     // is serial only in its additions: the yaw of every origin is a running sum of +-lengths, and with it every
@@ -823,7 +851,8 @@ AVP_D void pl_rs_sample_origins(PlShared& s, const avp_params& p)
 // Sample i of the shot, straight to the world frame (generate_local_course's interpolation :537-624 followed by
 // calc_all_paths' rotation :125-131), per sample, so
 // that a wave can produce exactly the samples it is about to check. Also maintains the trim bound s.rs_npts.
-AVP_D void pl_rs_sample_world(const PlanWs& w, PlShared& s, const avp_params& p, const PlNode& cn, double cm, double sm,
+template <class S>
+AVP_D void pl_rs_sample_world(const PlanWs& w, S& s, const avp_params& p, const PlNode& cn, double cm, double sm,
                               int i, double& tx, double& ty, double& tth)
 {
     double px = 0.0, py = 0.0, pyaw = 0.0;
@@ -847,12 +876,12 @@ AVP_D void pl_rs_sample_world(const PlanWs& w, PlShared& s, const avp_params& p,
 // lane per (pose, map column under the AABB) gathers the near obstacle points from the column bitmaps into
 // the wave's LDS queue, one lane per (pose, point) runs the exact test. pose(k, x, y, th) supplies pose k of
 // this wave's chunk; hit flags are returned through out_hit[k] (LDS).
-template <bool PROFILE = false, typename PoseFn>
-AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p, PlShared& s, int count, PoseFn pose, uint32_t* out_hit, bool probe = false)
+template <bool PROFILE = false, class S, typename PoseFn>
+AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p, S& s, int count, PoseFn pose, uint32_t* out_hit, bool probe = false)
 {
     const long long t_c0 = PH_NOW();
     const int lane = threadIdx.x & 63;
-    PlWaveChk& wc = s.wchk[threadIdx.x >> 6];
+    PlWaveChk& wc = s.wave_chk();
     if (count <= 0) return;
     if (p.checker_kind == 1) {
         if (lane < count) { double x, y, th, cs, sn; pose(lane, x, y, th, cs, sn); out_hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
@@ -983,8 +1012,8 @@ __device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // their child in parallel; if every heuristic query hits the closed frontier, lane 0 then applies, in child
 // order, only what is order dependent: arena slots, in-place improvements of open nodes and heap pushes.
 // s.fast (preset to 1) reports whether the pop was resolved here; when it is 0 nothing has been modified.
-template <bool PROFILE>
-AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const PlanWs& w, PlShared& s, const PlanDims& dims,
+template <bool PROFILE, class S>
+AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const PlanWs& w, S& s, const PlanDims& dims,
                                 const PlNode& cn, int nchild, bool pop_ahead)
 {
     const long long t_r0 = PH_NOW();
@@ -1090,7 +1119,76 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         w.nodes[c].state = 3;
     }
     wave_sync();
-    if (PROFILE && threadIdx.x == 0) { s.phase[PH_RES_CLASSIFY] += t_r1 - t_r0; s.phase[PH_RES_WRITE] += t_r2 - t_r1; s.phase[PH_RES_PUSH] += t_r3 - t_r2; s.phase[PH_SPARE] += clock64() - t_r3; }
+    if constexpr (PROFILE) { if (threadIdx.x == 0) { s.phase[PH_RES_CLASSIFY] += t_r1 - t_r0; s.phase[PH_RES_WRITE] += t_r2 - t_r1; s.phase[PH_RES_PUSH] += t_r3 - t_r2; s.phase[PH_SPARE] += clock64() - t_r3; } }
+}
+
+// finish_path (hybrid_a_star.py:351-389) + assembly (path_planner.py:100-108): ONE thread writes the record of problem
+// pid straight to global memory (no local copy of the struct: its dynamically indexed arrays would be a stack object).
+// The counts and the RS fields are filled whether or not the caller asked for way-points (paths == NULL).
+// k_travel_ddt / k_dth_ddt: the LDS copies of the motion-primitive constants.
+template <bool PROFILE, class S>
+AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const double* k_travel_ddt, const double (*k_dth_ddt)[4],
+                           avp_plan_result_dev* __restrict__ results, double* __restrict__ paths, int32_t max_path, int64_t pid,
+                           int64_t n_pops, int32_t slot, long long t_fin)
+{
+            avp_plan_result_dev& r = results[pid];
+            int32_t status = s.status;
+            r.n_pops = (int32_t)n_pops; r.in_radius_last = s.in_radius; r.rs_collision = s.collision;
+            r.n_checks = s.n_checks; r.n_rs = s.n_rs; r.n_closed = s.nclosed; r.n_open = s.nheap;
+            r.h_cells = s.h_cells; r.h_misses = s.h_misses; r.global_index = s.global_index; r.n_nodes = s.nnodes;
+            r.slot = slot;                  // the slot (persistent workgroup) that ran the problem
+            double* out = paths ? paths + (size_t)pid * max_path * 4 : nullptr;
+            int32_t n_astar = 0, n_final = 0, rs_n = 0, n_rs_pts = 0, rs_dir0 = 0;
+            double rs_L = 0.0, rs0 = 0.0, rs1 = 0.0, rs2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) r.rs_types[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) r.rs_lengths[k] = 0.0;
+            if (s.cur >= 0 && (status == 0 || status == 1)) {
+                // chain child -> root
+                int32_t len = 0;
+                for (int32_t node = s.cur; node >= 0; node = w.nodes[node].parent_pos) { len++; if (w.nodes[node].index == 0) break; }
+                int32_t cnt = 0;
+                bool over = false;
+                auto push = [&](double X, double Y, double T, double D) {
+                    if (!out) { cnt++; return; }
+                    if (cnt < max_path) { out[4 * cnt] = X; out[4 * cnt + 1] = Y; out[4 * cnt + 2] = T; out[4 * cnt + 3] = D; cnt++; } else over = true;
+                };
+                // walk from the root: position k of the chain is reached by (len-1-k) parent hops
+                int32_t prev = -1;
+                for (int32_t k = 0; k < len; k++) {
+                    int32_t node = s.cur;
+                    for (int32_t hop = 0; hop < len - 1 - k; hop++) node = w.nodes[node].parent_pos;
+                    const PlNode& nd = w.nodes[node];
+                    if (k == 0) push(nd.x, nd.y, nd.th, 0.0);
+                    else if (!out) cnt += p.n_sub;
+                    else {
+                        const PlNode& par = w.nodes[prev];
+                        for (int j = 0; j < p.n_sub; j++) {
+                            const double td = nd.forward ? k_travel_ddt[j] : -k_travel_ddt[j];
+                            const double th_j = avp_pi_2_pi(par.th + k_dth_ddt[nd.steer_i][j]);
+                            double s_j, c_j;
+                            avp_sincos(th_j, s_j, c_j);
+                            push(par.x + td * c_j, par.y + td * s_j, th_j, 0.0);
+                        }
+                    }
+                    prev = node;
+                }
+                n_astar = cnt;
+                if (s.rs.n > 0 && s.rs_status == 0 && s.in_radius) {
+                    rs_n = s.rs.n; rs_L = s.rs.L / p.maxc;
+                    for (int k = 0; k < s.rs.n; k++) { r.rs_types[k] = s.rs.t[k]; r.rs_lengths[k] = s.rs.l[k] / p.maxc; }
+                    n_rs_pts = s.rs_npts;
+                    rs0 = w.rsbuf[0]; rs1 = w.rsbuf[1]; rs2 = w.rsbuf[2]; rs_dir0 = w.rsdir[0];
+                    for (int k = 1; k < s.rs_npts; k++) push(w.rsbuf[3 * k], w.rsbuf[3 * k + 1], w.rsbuf[3 * k + 2], (double)w.rsdir[k]);
+                    n_final = cnt;
+                }
+                if (over) status = 5;
+            }
+            r.status = status; r.n_astar = n_astar; r.n_final = n_final; r.rs_n = rs_n; r.n_rs_pts = n_rs_pts;
+            r.rs_L = rs_L; r.rs_start[0] = rs0; r.rs_start[1] = rs1; r.rs_start[2] = rs2; r.rs_dir0 = rs_dir0;
+            if constexpr (PROFILE) { s.phase[PH_FINISH] += clock64() - t_fin; for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = s.phase[k]; }
+            else { for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = 0; }
 }
 
 template <bool STAGE, bool PROFILE>
@@ -1099,7 +1197,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                                           char* __restrict__ workspace, unsigned int* __restrict__ counter,
                                                           avp_plan_result_dev* __restrict__ results,
                                                           double* __restrict__ paths, int32_t max_path,
-                                                          double* __restrict__ trace, int32_t max_trace)
+                                                          double* __restrict__ trace, int32_t max_trace, int32_t retry_only)
 {
     avp_lds_tables_fill<true>();
     rs_lds_tables_fill();
@@ -1143,6 +1241,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         __syncthreads();
         const int64_t pid = s.pid;
         if (pid >= n) break;
+        // second launch behind plan_wave_kernel: only the problems it handed back (status 100 = AVP_PLAN_RETRY)
+        if (retry_only && results[pid].status != 100) continue;
         const double sx = starts[3 * pid], sy = starts[3 * pid + 1], sth = starts[3 * pid + 2];
         const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
 
@@ -1365,7 +1465,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         const int mine = base + lane * stride;
                         if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
                         // lane k holds pose k: broadcast it to whichever lanes ask for it
-                        uint32_t* hits = &s.wchk[wave].hit[0];
+                        uint32_t* hits = &s.wave_chk().hit[0];
                         pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
                             avp_sincos(th, sn, cs);
@@ -1520,70 +1620,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         }
 
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
-        // Thread 0 writes the record straight to global memory (no local copy of the struct: its dynamically
-        // indexed arrays would be a stack object). The counts and the RS fields are filled whether or not the
-        // caller asked for way-points (paths == NULL).
-        if (tid == 0) {
-            avp_plan_result_dev& r = results[pid];
-            int32_t status = s.status;
-            r.n_pops = (int32_t)n_pops; r.in_radius_last = s.in_radius; r.rs_collision = s.collision;
-            r.n_checks = s.n_checks; r.n_rs = s.n_rs; r.n_closed = s.nclosed; r.n_open = s.nheap;
-            r.h_cells = s.h_cells; r.h_misses = s.h_misses; r.global_index = s.global_index; r.n_nodes = s.nnodes;
-            r.slot = (int32_t)blockIdx.x;                  // the slot (persistent workgroup) that ran the problem
-            double* out = paths ? paths + (size_t)pid * max_path * 4 : nullptr;
-            int32_t n_astar = 0, n_final = 0, rs_n = 0, n_rs_pts = 0, rs_dir0 = 0;
-            double rs_L = 0.0, rs0 = 0.0, rs1 = 0.0, rs2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) r.rs_types[k] = 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++) r.rs_lengths[k] = 0.0;
-            if (s.cur >= 0 && (status == 0 || status == 1)) {
-                // chain child -> root
-                int32_t len = 0;
-                for (int32_t node = s.cur; node >= 0; node = w.nodes[node].parent_pos) { len++; if (w.nodes[node].index == 0) break; }
-                int32_t cnt = 0;
-                bool over = false;
-                auto push = [&](double X, double Y, double T, double D) {
-                    if (!out) { cnt++; return; }
-                    if (cnt < max_path) { out[4 * cnt] = X; out[4 * cnt + 1] = Y; out[4 * cnt + 2] = T; out[4 * cnt + 3] = D; cnt++; } else over = true;
-                };
-                // walk from the root: position k of the chain is reached by (len-1-k) parent hops
-                int32_t prev = -1;
-                for (int32_t k = 0; k < len; k++) {
-                    int32_t node = s.cur;
-                    for (int32_t hop = 0; hop < len - 1 - k; hop++) node = w.nodes[node].parent_pos;
-                    const PlNode& nd = w.nodes[node];
-                    if (k == 0) push(nd.x, nd.y, nd.th, 0.0);
-                    else if (!out) cnt += p.n_sub;
-                    else {
-                        const PlNode& par = w.nodes[prev];
-                        for (int j = 0; j < p.n_sub; j++) {
-                            const double td = nd.forward ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
-                            const double th_j = avp_pi_2_pi(par.th + s.k_dth_ddt[nd.steer_i][j]);
-                            double s_j, c_j;
-                            avp_sincos(th_j, s_j, c_j);
-                            push(par.x + td * c_j, par.y + td * s_j, th_j, 0.0);
-                        }
-                    }
-                    prev = node;
-                }
-                n_astar = cnt;
-                if (s.rs.n > 0 && s.rs_status == 0 && s.in_radius) {
-                    rs_n = s.rs.n; rs_L = s.rs.L / p.maxc;
-                    for (int k = 0; k < s.rs.n; k++) { r.rs_types[k] = s.rs.t[k]; r.rs_lengths[k] = s.rs.l[k] / p.maxc; }
-                    n_rs_pts = s.rs_npts;
-                    rs0 = w.rsbuf[0]; rs1 = w.rsbuf[1]; rs2 = w.rsbuf[2]; rs_dir0 = w.rsdir[0];
-                    for (int k = 1; k < s.rs_npts; k++) push(w.rsbuf[3 * k], w.rsbuf[3 * k + 1], w.rsbuf[3 * k + 2], (double)w.rsdir[k]);
-                    n_final = cnt;
-                }
-                if (over) status = 5;
-            }
-            r.status = status; r.n_astar = n_astar; r.n_final = n_final; r.rs_n = rs_n; r.n_rs_pts = n_rs_pts;
-            r.rs_L = rs_L; r.rs_start[0] = rs0; r.rs_start[1] = rs1; r.rs_start[2] = rs2; r.rs_dir0 = rs_dir0;
-            if (PROFILE) s.phase[PH_FINISH] += clock64() - t_fin;
-#pragma unroll
-            for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = PROFILE ? s.phase[k] : 0;
-        }
+        if (tid == 0) pl_write_result<PROFILE>(p, w, s, s.k_travel_ddt, s.k_dth_ddt, results, paths, max_path, pid, n_pops, (int32_t)blockIdx.x, t_fin);
         __syncthreads();
     }
 }

@@ -1,0 +1,493 @@
+// avp_planw_kernels.h -- batched hybrid-A* planner, THROUGHPUT form: one WAVE = one (start, goal) problem, eight
+// independent problems per workgroup, persistent waves pull problems from a global counter.
+//
+// plan_kernel (avp_plan_kernels.h) spends a whole 512-thread workgroup on one problem to shorten a pop's critical
+// path; measured, its eight waves are busy 40 % of the time (the pop is a chain of dependent scalar fp64 code, every
+// phase is as long as its slowest wave). For batches much larger than the chip (north_star's 4 096 poses on 256 CUs)
+// latency per problem does not matter, resident problems per CU do: here every wave runs a complete search on its
+// own -- the same device functions, the same arithmetic in the same order, bit-identical results -- with no
+// workgroup barrier after the map tables have been staged. Replaces the same reference code as plan_kernel:
+// PathPlanner.a_star_plan (path_plan/path_planner.py:58-110), hybrid_a_star (path_plan/hybrid_a_star.py:72-389),
+// Dijkstra (path_plan/compute_h.py), rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-680), heapq order.
+//
+// What differs from plan_kernel is only WHO does the work:
+//   * the sub-step and shot collision passes (pl_check_wave) and the fast child resolution (pl_resolve_fast_wave) were
+//     wave-local already and are used as they are; the heuristic sweep runs with the wave as its cooperating group;
+//   * the shot is checked BEFORE the children are resolved, as in the reference (no speculation, no roll-back);
+//   * the Reeds-Shepp words are evaluated solver group by solver group, the words of one set_path type group in
+//     adjacent lanes: set_path's duplicate test (rs_curve.py:137-156) is a few shuffles inside the group and the
+//     running arg-min per query (:103-108, "<=": the later word wins a tie) lives in 17 x 3 LDS words -- no table of
+//     all 46 x 11 word results (the 28 KB that keep plan_kernel at one problem per CU).
+// A shot with more than PW_RS_CAP samples (128 m of path) or a configuration with more than PW_MAXCHILD children is
+// handed back (status AVP_PLAN_RETRY, internal) and planned by plan_kernel in a second launch: results never depend
+// on the kernel that produced them.
+#pragma once
+#include "avp_plan_kernels.h"
+
+#define PW_WAVES 8
+#define PW_THREADS (64 * PW_WAVES)
+#define PW_RS_CAP 256                 // samples of one RS shot held per wave
+#define PW_MAXCHILD 16
+#define PW_RSQ (PW_MAXCHILD + 1)      // RS queries per pop: the shot + the children
+#define AVP_PLAN_RETRY 100            // internal: plan this problem with plan_kernel (never returned to the caller)
+
+// Words of one solver group in lane order: the members of a set_path type group are adjacent and aligned to the group
+// size (1, 2 or 4), the groups of a query are adjacent, queries follow each other: item = query * L + j.
+//   group of solvers            words (type groups separated by |)                       lanes per query L
+//   0 SLS                       0 | 1                                                     2
+//   1 LSL                       2 3 | 4 5                                                 4
+//   2 LSR                       6 7 | 8 9                                                 4
+//   3 LRL                       10 11 14 15 | 12 13 16 17                                 8
+//   4 LRLRn + LRLRp             18 19 22 23 | 20 21 24 25                                 8   (the only groups that span two solvers)
+//   5 LRSL                      26 27 | 28 29 | 34 35 | 36 37                             8
+//   6 LRSR                      30 31 | 32 33 | 38 39 | 40 41                             8
+//   7 LRSLR                     42 43 | 44 45                                             4
+static __device__ const int8_t PW_SG_L[8] = { 2, 4, 4, 8, 8, 8, 8, 4 };
+static __device__ const int8_t PW_SG_SHIFT[8] = { 1, 2, 2, 3, 3, 3, 3, 2 };
+static __device__ const int8_t PW_SG_OFF[8] = { 0, 2, 6, 10, 18, 26, 34, 42 };
+static __device__ const int8_t PW_SG_GMAX[8] = { 1, 2, 2, 4, 4, 2, 2, 2 };
+static __device__ const int8_t PW_ITEM_WORD[46] = { 0, 1,  2, 3, 4, 5,  6, 7, 8, 9,  10, 11, 14, 15, 12, 13, 16, 17,  18, 19, 22, 23, 20, 21, 24, 25,
+                                                    26, 27, 28, 29, 34, 35, 36, 37,  30, 31, 32, 33, 38, 39, 40, 41,  42, 43, 44, 45 };
+static __device__ const int8_t PW_ITEM_G[46] = { 1, 1,  2, 2, 2, 2,  2, 2, 2, 2,  4, 4, 4, 4, 4, 4, 4, 4,  4, 4, 4, 4, 4, 4, 4, 4,
+                                                 2, 2, 2, 2, 2, 2, 2, 2,  2, 2, 2, 2, 2, 2, 2, 2,  2, 2, 2, 2 };
+static __device__ const int8_t PW_ITEM_M[46] = { 0, 0,  0, 1, 0, 1,  0, 1, 0, 1,  0, 1, 2, 3, 0, 1, 2, 3,  0, 1, 2, 3, 0, 1, 2, 3,
+                                                 0, 1, 0, 1, 0, 1, 0, 1,  0, 1, 0, 1, 0, 1, 0, 1,  0, 1, 0, 1 };
+
+// Constants every wave of the workgroup reads (LDS): the lane-indexed members of avp_params (a dynamically indexed
+// by-value kernel argument would be copied to every lane's scratch) and the sub-step index tables.
+struct PwCommon {
+    double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];
+    int8_t sub_child[PW_MAXCHILD * 4], sub_j[PW_MAXCHILD * 4], sub_steer[PW_MAXCHILD * 4];
+    int8_t item_word[46], item_g[46], item_m[46], sg_l[8], sg_shift[8], sg_off[8], sg_gmax[8];
+};
+
+// State of one problem = one wave (LDS). Field names follow PlShared where the shared device functions read them.
+struct PwShared {
+    // lattice / id space and sweep (pl_sweep_init, pl_relax, pl_expand_bucket, pl_hquery_*)
+    int32_t col0, row0, colMin, colMax, rowMin, rowMax, orow0, alias;
+    int64_t goal_id;
+    int32_t regular;
+    int32_t E;
+    uint32_t qcount[PL_NQ];
+    int32_t qover;
+    uint32_t dF; int64_t idF;
+    int32_t hasF;
+    int64_t h_cells, h_misses;
+    // A*
+    int32_t nnodes, nheap, nclosed, closed_nonempty;
+    int64_t global_index;
+    int32_t cur;
+    int32_t status, done;
+    double goal[3];
+    int32_t pid;
+    int32_t rs_status, rs_npts, rs_first_coll, in_radius, collision;
+    RsPath rs;
+    int64_t n_checks, n_rs;
+    MapTabs mt;
+    uint32_t hq_d;
+    int32_t next_child, need_sweep, have_d, fast;
+    int64_t pending_id;
+    int32_t next_cur, have_next;
+    PlChild child[PW_MAXCHILD];
+    // Reeds-Shepp: frames, running best per query, round scratch
+    RsFrame frame[PW_RSQ];
+    unsigned long long bestL[PW_RSQ], tmpL[PW_RSQ];
+    int32_t bestW[PW_RSQ], tmpW[PW_RSQ];
+    double best_l[PW_RSQ][AVP_RS_MAXSEG];
+    uint8_t w_err[PW_RSQ];
+    // shot sampling
+    int32_t smp_hi, smp_point_num;
+    double smp_l[PW_RS_CAP];
+    int8_t smp_seg[PW_RS_CAP];
+    double seg_o[AVP_RS_MAXSEG][3];
+    // collision passes
+    PlWaveChk wchk1;
+    uint32_t chk_hit[PW_MAXCHILD * 4];
+    static constexpr int RS_CAP = PW_RS_CAP;
+    __device__ __forceinline__ PlWaveChk& wave_chk() { return wchk1; }
+};
+
+static inline __host__ __device__ size_t pw_lds_waves_offset() { return (sizeof(PwCommon) + 15) & ~(size_t)15; }
+static inline __host__ __device__ size_t pw_lds_wave_stride() { return (sizeof(PwShared) + 15) & ~(size_t)15; }
+static inline __host__ __device__ size_t pw_lds_tables_offset() { return pw_lds_waves_offset() + PW_WAVES * pw_lds_wave_stride(); }
+
+// Reeds-Shepp optimal paths of queries [0, nq) of this wave (s.frame[q] set): calc_optimal_path's result per query in
+// s.bestW / s.best_l / s.w_err. Whole wave.
+AVP_D void pw_rs_eval(PwShared& s, const PwCommon& c, const avp_params& p, int nq)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < nq) { s.bestL[lane] = ~0ull; s.bestW[lane] = -1; s.w_err[lane] = 0; }
+    wave_sync();
+    for (int sg = 0; sg < 8; sg++) {
+        const int L = c.sg_l[sg], sh = c.sg_shift[sg], off = c.sg_off[sg], gmax = c.sg_gmax[sg];
+        const int items = nq << sh;
+        for (int base = 0; base < items; base += 64) {
+            const int it = base + lane;
+            const bool active = it < items;
+            const int q = active ? it >> sh : 0, j = it & (L - 1);
+            const int word = c.item_word[off + j], mm = c.item_m[off + j], g = c.item_g[off + j];
+            double l[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+            bool ok = false;
+            if (active) ok = rs_word(word, s.frame[q], l);
+            double Lsum = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) Lsum = Lsum + fabs(l[i]);            // path.L (rs_curve.py:145), unused tail is 0.0
+            // set_path inside the type group, in word order: member e is final once members 0 .. e-1 are
+            bool dup = false, acc = false, err = false;
+            for (int e = 0; e < gmax; e++) {
+                if (mm == e) {
+                    const bool cand = ok && !dup && !(Lsum >= 1000.0);
+                    acc = cand && (Lsum >= 0.01);
+                    err = cand && !(Lsum >= 0.01);                           // the reference's assertion (rs_curve.py:153)
+                }
+                if (e + 1 < gmax) {
+                    int src = lane - mm + e;                                 // member e of my group (groups are aligned to their size)
+                    src = src < 0 ? 0 : src;
+                    const int a_e = __shfl(acc ? 1 : 0, src, 64);
+                    double sum = 0;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) sum = sum + (__shfl(l[i], src, 64) - l[i]);
+                    if (mm > e && e < g && a_e && sum <= 0.01) dup = true;
+                }
+            }
+            // arg-min of the round per query, then merged into the running best: smaller length, or the same length and a
+            // later word (calc_optimal_path's "<=" keeps the last of equal minima in word order)
+            const double Lm = Lsum / p.maxc;
+            const unsigned long long lb = (unsigned long long)__double_as_longlong(Lm);
+            if (lane < nq) { s.tmpL[lane] = ~0ull; s.tmpW[lane] = -1; }
+            wave_sync();
+            if (acc) atomicMin(&s.tmpL[q], lb);
+            if (err) s.w_err[q] = 1;
+            wave_sync();
+            if (acc && lb == s.tmpL[q]) atomicMax(&s.tmpW[q], word);
+            wave_sync();
+            if (acc && lb == s.tmpL[q] && word == s.tmpW[q]) {
+                const unsigned long long bl = s.bestL[q];
+                if (lb < bl || (lb == bl && word > s.bestW[q])) {
+                    s.bestL[q] = lb; s.bestW[q] = word;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) s.best_l[q][i] = l[i];
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+// Result of query q as pl_rs_fold_wave returns it: 0 path in `out` (normalised lengths), 1 no candidate, 2 assertion.
+AVP_D int pw_rs_result(const PwShared& s, int q, RsPath& out)
+{
+    out.n = 0; out.L = 0;
+    if (s.w_err[q]) return 2;
+    const int wd = s.bestW[q];
+    if (wd < 0) return 1;
+    const RsWord W = RS_WORDS[wd];
+    out.n = W.n;
+    out.t[0] = 0 < W.n ? W.a : (int8_t)-1; out.t[1] = 1 < W.n ? W.b : (int8_t)-1; out.t[2] = 2 < W.n ? W.c : (int8_t)-1;
+    out.t[3] = 3 < W.n ? W.d : (int8_t)-1; out.t[4] = 4 < W.n ? W.e : (int8_t)-1;
+    double Ln = 0;
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) { out.l[i] = s.best_l[q][i]; Ln = Ln + fabs(out.l[i]); }
+    out.L = Ln;
+    return 0;
+}
+
+template <bool STAGE>
+__global__ __launch_bounds__(PW_THREADS) void plan_wave_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
+                                                               const double* __restrict__ goals, int64_t n, int32_t maxNodes,
+                                                               char* __restrict__ workspace, unsigned int* __restrict__ counter,
+                                                               avp_plan_result_dev* __restrict__ results,
+                                                               double* __restrict__ paths, int32_t max_path,
+                                                               double* __restrict__ trace, int32_t max_trace)
+{
+    constexpr bool PROFILE = false;
+    avp_lds_tables_fill<true>();
+    rs_lds_tables_fill();
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    PwCommon& c = *reinterpret_cast<PwCommon*>(pw_smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    PwShared& s = *reinterpret_cast<PwShared*>(pw_smem + pw_lds_waves_offset() + (size_t)wave * pw_lds_wave_stride());
+    const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
+    const int32_t slot = (int32_t)blockIdx.x * PW_WAVES + wave;
+    const PlanWs w = plan_carve(workspace + (size_t)slot * dims.bytes, dims);
+#pragma unroll
+    for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
+        c.k_steer[k] = p.steer[k]; c.k_dth_dt[k] = p.dth_dt[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) c.k_dth_ddt[k][j] = p.dth_ddt[k][j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (tid == k) c.k_travel_ddt[k] = p.travel_ddt[k];
+    if (tid < PW_MAXCHILD * 4 && p.n_sub > 0 && p.n_steer > 0) { const int ci = tid / p.n_sub; c.sub_child[tid] = (int8_t)ci; c.sub_j[tid] = (int8_t)(tid - ci * p.n_sub); c.sub_steer[tid] = (int8_t)(ci % p.n_steer); }
+    if (tid < 46) { c.item_word[tid] = PW_ITEM_WORD[tid]; c.item_g[tid] = PW_ITEM_G[tid]; c.item_m[tid] = PW_ITEM_M[tid]; }
+    if (tid < 8) { c.sg_l[tid] = PW_SG_L[tid]; c.sg_shift[tid] = PW_SG_SHIFT[tid]; c.sg_off[tid] = PW_SG_OFF[tid]; c.sg_gmax[tid] = PW_SG_GMAX[tid]; }
+    MapTabs mt;
+    if (STAGE) {
+        uint64_t* lb = reinterpret_cast<uint64_t*>(pw_smem + pw_lds_tables_offset());
+        double* lx = reinterpret_cast<double*>(lb + (size_t)m.nx * m.wpc);
+        double* ly = lx + m.nx;
+        for (int i = tid; i < m.nx * m.wpc; i += PW_THREADS) lb[i] = m.colBits[i];
+        for (int i = tid; i < m.nx; i += PW_THREADS) lx[i] = m.X[i];
+        for (int i = tid; i < m.ny; i += PW_THREADS) ly[i] = m.Y[i];
+        mt.X = lx; mt.Y = ly; mt.bits = lb;
+    } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
+    if (lane == 0) s.mt = mt;
+    __syncthreads();                                   // the last workgroup barrier: from here on every wave is on its own
+    const int nchild = 2 * p.n_steer;
+    const int nq = nchild + 1;
+    const int nsubs = nchild * p.n_sub;
+    const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
+
+    for (;;) {
+        CoopWave::sync();
+        if (lane == 0) s.pid = (int32_t)atomicAdd(counter, 1u);
+        CoopWave::sync();
+        const int64_t pid = s.pid;
+        if (pid >= n) break;
+        const double sx = starts[3 * pid], sy = starts[3 * pid + 1], sth = starts[3 * pid + 2];
+        const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
+
+        // ---- init ------------------------------------------------------------------------------
+        for (int64_t i = lane; i < dims.hashCap; i += 64) w.hash[i] = 0;
+        if (lane == 0) {
+            s.status = (nchild > PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;
+            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
+            s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
+            s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
+            s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
+            s.E = 0; s.h_cells = 0; s.h_misses = 0;
+        }
+        CoopWave::sync();
+        if (s.status == 0) pl_sweep_init<CoopWave>(m, w, s, dims, gx, gy);
+        if (s.status == 0) {
+            // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
+            const int64_t sid = avp_pos_to_index(m, sx, sy);
+            pl_hquery_miss<false, CoopWave>(m, w, s, sid);
+            if (lane == 0) {
+                if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
+                else {
+                    PlNode& nd = w.nodes[0];
+                    nd.x = sx; nd.y = sy; nd.th = avp_pi_2_pi(sth); nd.g = 0; nd.h = 0; nd.f = 0;
+                    nd.index = 0; nd.parent_index = -1; nd.parent_pos = -1; nd.forward = 1; nd.steer_i = -1; nd.state = 1;
+                    s.nnodes = 1;
+                    pl_heap_push(w, s, 0, 0.0);
+                    pl_hash_put(w, dims.hashCap, 0);
+                }
+            }
+            CoopWave::sync();
+        }
+
+        int64_t n_pops = 0;
+        // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
+        while (s.status == 0 && !s.done) {
+            CoopWave::sync();
+            if (lane == 0) {
+                if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }
+                else if (s.nheap == 0) { s.status = 1; }
+                else if (n_pops >= max_pops) { s.status = 4; }
+                else {
+                    const uint32_t cc = pl_heap_pop(w, s);
+                    s.cur = (int32_t)cc;
+                    w.nodes[cc].state = 3;
+                }
+            }
+            CoopWave::sync();
+            if (s.status != 0) break;
+            const PlNode cn = w.nodes[s.cur];
+            if (trace && lane == 0 && n_pops < max_trace) {
+                double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
+                t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(m, cn.x, cn.y);
+                t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
+                t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : c.k_steer[cn.steer_i];
+            }
+            n_pops++;
+
+            // ---- children poses (expand_node :134-151) + try_reach_goal radius test (:308-312) ----------
+            const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
+            const double distance = sqrt(ddx * ddx + ddy * ddy);
+            const bool in_radius = distance < p.flag_radius;
+            if (lane == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
+            if (lane < nchild) {
+                PlChild& ch = s.child[lane];
+                const int si = lane % p.n_steer;
+                const bool fwd = lane < p.n_steer;
+                const double travel = fwd ? p.travel_dt : -p.travel_dt;
+                const double th_ = avp_pi_2_pi(cn.th + c.k_dth_dt[si]);
+                ch.th = th_;
+                double sth_, cth_;
+                avp_sincos(th_, sth_, cth_);
+                ch.x = cn.x + travel * cth_;
+                ch.y = cn.y + travel * sth_;
+                ch.oob = (ch.x > m.b1 || ch.x < m.b0 || ch.y > m.b3 || ch.y < m.b2) ? 1 : 0;
+                ch.found = pl_hash_find(w, dims.hashCap, ch.x, ch.y, ch.th);
+                ch.found_state = ch.found >= 0 ? w.nodes[ch.found].state : 0;
+                ch.id = avp_pos_to_index(m, ch.x, ch.y);
+                ch.first_coll = 0x7fffffff;
+                ch.rs_err = 0;
+                ch.L = 0;
+                s.frame[lane + 1] = rs_frame(ch.x, ch.y, ch.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            } else if (lane == nchild) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            wave_sync();
+            // ---- sub-step collision checks of every child (:185-204), PL_WPOSE poses per pass ----------------
+            for (int base = 0; base < nsubs; base += PL_WPOSE) {
+                const int cnt = min(PL_WPOSE, nsubs - base);
+                pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+                    const int t = base + k;
+                    const int ci = c.sub_child[t], j = c.sub_j[t], si = c.sub_steer[t];
+                    const double td = ci < p.n_steer ? c.k_travel_ddt[j] : -c.k_travel_ddt[j];
+                    th = avp_pi_2_pi(cn.th + c.k_dth_ddt[si][j]);
+                    avp_sincos(th, sn, cs);
+                    x = cn.x + td * cs;
+                    y = cn.y + td * sn;
+                }, &s.chk_hit[base]);
+            }
+            for (int t = lane; t < nsubs; t += 64)
+                if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
+            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
+            wave_sync();
+
+            // ---- Reeds-Shepp: query 0 = the shot from the popped node (:326-332), 1.. = children (:286-294) ----
+            pw_rs_eval(s, c, p, nq);
+            if (lane >= 1 && lane <= nchild) {
+                RsPath rp;
+                const int st = pw_rs_result(s, lane, rp);
+                s.child[lane - 1].rs_err = (int8_t)st; s.child[lane - 1].L = st ? 0.0 : rp.L / p.maxc;
+            }
+            if (lane == 0) {
+                RsPath rp;
+                const int st = pw_rs_result(s, 0, rp);
+                s.rs_status = in_radius ? st : 0;
+                if (!st) s.rs = rp;
+                if (in_radius && !st) { s.n_rs += 1; pl_rs_sample_book(s, p); }
+            }
+            wave_sync();
+            if (in_radius && s.rs_status) { if (lane == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? AVP_PLAN_RETRY : 3; wave_sync(); break; }
+
+            // ---- the shot: sample in path order, check, stop at the first colliding sample (:335-345) --------------
+            if (in_radius) {
+                pl_rs_sample_origins(s, p);
+                wave_sync();
+                const int total = s.smp_hi + 1;
+                double cm, sm;
+                avp_sincos(-cn.th, sm, cm);
+                for (int base = 0; base < total; base += PL_WPOSE) {
+                    const int cnt = min(PL_WPOSE, total - base);
+                    double tx = 0.0, ty = 0.0, tth = 0.0;
+                    const int mine = base + lane;
+                    if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
+                    uint32_t* hits = &s.wave_chk().hit[0];
+                    pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+                        x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
+                        avp_sincos(th, sn, cs);
+                    }, hits);
+                    if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
+                    wave_sync();
+                    // stop at the first colliding sample -- unless it may lie in the trailing px == 0.0 tail the reference pops
+                    // (rs_curve.py:588-592): that is only known once every sample has been produced, so keep going then
+                    if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll < s.rs_npts) break;
+                }
+                if (lane == 0) {
+                    // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
+                    if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
+                    if (s.rs_first_coll == 0x7fffffff) { s.n_checks += s.rs_npts; s.done = 1; }
+                    else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
+                }
+                wave_sync();
+            }
+            if (s.status != 0 || s.done) break;
+
+            // ---- child resolution in child order (:153-232) ------------------------------------------------------------
+            if (lane == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = can_fast ? 1 : 0; }
+            if (!can_fast && lane < nchild) s.child[lane].pre_d = pl_id_in_range(m, s.child[lane].id) ? w.dist[s.child[lane].id] : PL_UNSEEN;
+            wave_sync();
+            if (can_fast) pl_resolve_fast_wave<false>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
+            wave_sync();
+            if (!s.fast) {
+                for (;;) {
+                    if (lane == 0) {
+                        s.need_sweep = 0;
+                        int i = s.next_child;
+                        for (; i < nchild && s.status == 0; i++) {
+                            const PlChild ch = s.child[i];
+                            const int si = i % p.n_steer;
+                            const int is_forward = i < p.n_steer ? 1 : 0;
+                            const bool found_closed = ch.found >= 0 && ch.found_state == 2;
+                            if (s.closed_nonempty && (found_closed || ch.oob)) continue;          // :155-165
+                            const bool found_open = ch.found >= 0 && ch.found_state == 1;
+                            if (!found_open && ch.first_coll != 0x7fffffff) {
+                                s.n_checks += ch.first_coll + 1;
+                                if (s.nnodes >= maxNodes) { s.status = 5; break; }
+                                const int32_t pos = s.nnodes++;
+                                PlNode& nd = w.nodes[pos];
+                                nd.x = ch.x; nd.y = ch.y; nd.th = ch.th; nd.g = 0; nd.h = 0; nd.f = 0;
+                                nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                                nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
+                                pl_hash_put(w, dims.hashCap, pos);
+                                s.nclosed++; s.closed_nonempty = 1;
+                                continue;
+                            }
+                            uint32_t hd;
+                            if (s.have_d) { hd = s.hq_d; s.have_d = 0; }
+                            else if (!pl_hquery_hit(m, s, ch.id, ch.pre_d, hd)) { s.pending_id = ch.id; s.need_sweep = 1; break; }
+                            if (hd == PL_UNSEEN) { if (!found_open) s.n_checks += p.n_sub; s.status = s.qover ? 5 : 2; break; }
+                            s.n_rs += 1;
+                            if (ch.rs_err) { s.status = ch.rs_err == 4 ? 5 : 3; break; }
+                            const double hv1 = (double)hd / 100, hv2 = ch.L;
+                            const double hval = hv2 > hv1 ? hv2 : hv1;
+                            if (!found_open) {
+                                s.n_checks += p.n_sub;
+                                if (s.nnodes >= maxNodes) { s.status = 5; break; }
+                                const double g = pl_node_cost(p, is_forward, ch.th, cn.th, cn.forward);
+                                const int32_t pos = s.nnodes++;
+                                PlNode& nd = w.nodes[pos];
+                                nd.x = ch.x; nd.y = ch.y; nd.th = ch.th; nd.g = g; nd.h = hval; nd.f = g + hval;
+                                nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                                nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
+                                pl_heap_push(w, s, (uint32_t)pos, g + hval);
+                                pl_hash_put(w, dims.hashCap, pos);
+                            } else {
+                                PlNode& chn = w.nodes[ch.found];
+                                const double new_g = pl_node_cost(p, chn.forward, chn.th, cn.th, cn.forward);
+                                const double new_f = hval + new_g;
+                                if (new_f < chn.f) {
+                                    chn.f = new_f; chn.g = new_g; chn.h = hval;
+                                    pl_heap_set_key(w, s, chn.heap_pos, new_f);
+                                    chn.parent_index = cn.index; chn.parent_pos = s.cur;
+                                    chn.forward = (int8_t)is_forward; chn.steer_i = (int8_t)si;
+                                }
+                            }
+                        }
+                        s.next_child = i;
+                    }
+                    CoopWave::sync();
+                    if (!s.need_sweep) break;
+                    pl_hquery_miss<false, CoopWave>(m, w, s, s.pending_id);
+                    if (lane == 0) s.have_d = 1;
+                    if (lane < nchild) s.child[lane].pre_d = pl_id_in_range(m, s.child[lane].id) ? w.dist[s.child[lane].id] : PL_UNSEEN;
+                    CoopWave::sync();
+                }
+            }
+            if (lane == 0 && s.status == 0) {
+                w.nodes[s.cur].state = 2;
+                s.nclosed++; s.closed_nonempty = 1;
+                s.global_index += nchild;
+            }
+            CoopWave::sync();
+        }
+        CoopWave::sync();
+        if (s.status == 1 && s.cur >= 0 && s.in_radius && s.rs.n > 0 && s.rs_status == 0 && s.collision) {
+            // the reference hands back the last (colliding) shot when the open list runs empty (path_planner.py:100-108):
+            // the early exit above may have left samples unproduced
+            const PlNode cl = w.nodes[s.cur];
+            double cm, sm;
+            avp_sincos(-cl.th, sm, cm);
+            for (int i = lane; i <= s.smp_hi; i += 64) { double a, b, cc; pl_rs_sample_world(w, s, p, cl, cm, sm, i, a, b, cc); }
+            CoopWave::sync();
+        }
+        if (lane == 0) {
+            if (s.status == AVP_PLAN_RETRY) { results[pid].status = AVP_PLAN_RETRY; }
+            else pl_write_result<false>(p, w, s, c.k_travel_ddt, c.k_dth_ddt, results, paths, max_path, pid, n_pops, slot, 0ll);
+        }
+        CoopWave::sync();
+    }
+}

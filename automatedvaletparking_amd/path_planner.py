@@ -75,11 +75,14 @@ class BatchPlanner:
     """Device-side batched planner bound to one DeviceMap. Owns the scratch workspace (torch tensor)."""
 
     def __init__(self, device_map: _native.DeviceMap, max_nodes: int = 65536, n_slots: Optional[int] = None,
-                 max_path: int = 512):
+                 max_path: int = 512, mode: int = 0):
+        """mode: 0 = the library's choice by batch size, 1 = one workgroup per problem, 2 = one wave per problem
+        (include/avp.h: avp_plan_batch_mode). n_slots: problem slots (default: what the chosen form can keep busy)."""
         self.dm = device_map
         self.max_nodes = int(max_nodes)
         L = _native.lib()
-        self.n_slots = int(n_slots) if n_slots else int(L.avp_plan_default_slots(device_map.h))
+        self.mode = int(mode)
+        self.n_slots = int(n_slots) if n_slots else 0
         self.max_path = int(max_path)
         if L.avp_sizeof_plan_result() != C.sizeof(AvpPlanResult):
             raise RuntimeError("avp_plan_result layout mismatch")
@@ -103,17 +106,24 @@ class BatchPlanner:
         torch = self.dm.torch
         self.dm.use_current_stream()
         n = starts_t.shape[0]
-        slots = max(1, min(self.n_slots, n))
+        L = _native.lib()
+        mode = 1 if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode)))
+        cap = self.n_slots if self.n_slots else int(L.avp_plan_slots(self.dm.h, C.c_int32(mode)))
+        slots = max(1, min(cap, n if mode == 1 else 8 * ((n + 7) // 8)))
+        if mode == 2 and slots < 8:
+            mode = 1                                        # fewer than one workgroup of slots: the workgroup form
         ws = self._workspace(slots)
         res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
         paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
         trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
-        entry = _native.lib().avp_plan_batch_profile if profile else _native.lib().avp_plan_batch
-        _native.chk(entry(
-            self.dm.h, C.c_void_p(starts_t.data_ptr()), C.c_void_p(goals_t.data_ptr()), C.c_int64(n), C.c_int32(slots),
-            C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
-            C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
-            C.c_void_p(trace.data_ptr()) if trace is not None else None, C.c_int32(max_trace)), "avp_plan_batch")
+        args = (self.dm.h, C.c_void_p(starts_t.data_ptr()), C.c_void_p(goals_t.data_ptr()), C.c_int64(n), C.c_int32(slots),
+                C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
+                C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
+                C.c_void_p(trace.data_ptr()) if trace is not None else None, C.c_int32(max_trace))
+        if profile:
+            _native.chk(L.avp_plan_batch_profile(*args), "avp_plan_batch_profile")
+        else:
+            _native.chk(L.avp_plan_batch_mode(*args, C.c_int32(mode)), "avp_plan_batch_mode")
         return res, paths, trace
 
     def plan(self, starts, goals, max_trace: int = 0) -> List[PlanResult]:

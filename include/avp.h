@@ -184,6 +184,23 @@ int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, 
                        int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
                        double* paths, int32_t max_path, double* trace, int32_t max_trace);
 
+/*
+ * Kernel form. The planner exists in two forms with bit-identical results (tests/test_gpu_plan_wave.py):
+ *   mode 1: one workgroup (512 threads) per problem -- the shortest time per problem; right when the batch is no larger
+ *           than the chip (BASELINE config[1]: 256 problems on 256 CUs);
+ *   mode 2: one wave per problem, eight problems per workgroup -- the most problems in flight; right for batches much
+ *           larger than the chip (north_star's 4 096-pose batch). Problems it cannot hold (a Reeds-Shepp shot of more
+ *           than 256 samples, more than 16 children) are planned by the mode-1 kernel in a second launch of the same call;
+ *   mode 0: avp_plan_batch's choice: mode 2 when n >= 32 x the number of CUs (4 problems per wave slot), else mode 1.
+ * n_slots counts problem slots in either form (avp_plan_slots(map, mode): CUs, or 8 x CUs); the workspace is
+ * avp_plan_workspace_bytes(map, n_slots, max_nodes) as before. avp_plan_pick_mode returns the form mode 0 would use.
+ */
+int32_t avp_plan_batch_mode(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
+                            int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
+                            double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t mode);
+int32_t avp_plan_pick_mode(avp_map* map, int64_t n, int32_t mode);
+int32_t avp_plan_slots(avp_map* map, int32_t mode);
+
 /* The same call through the instrumented instantiation of the kernel: results[i].phase_cycles holds the shader
  * cycles thread 0 spent in each phase of problem i (avp_plan_batch leaves them 0: the s_memtime reads cost ~10 % of
  * the kernel's wave cycles, so the production kernel carries none). Diagnostics only; results are identical. */

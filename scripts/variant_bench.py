@@ -16,6 +16,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--big", type=int, default=2048)
 ap.add_argument("--no-profile", action="store_true")
+ap.add_argument("--big-mode", type=int, default=0)
 a = ap.parse_args()
 if a.lib:
     os.environ["AVP_HIP_LIB"] = os.path.abspath(a.lib)
@@ -68,9 +69,12 @@ out = {"lib": os.path.basename(_native.LIB_PATH), "c2_ms": round(ms, 3), "c2_pla
 rep = a.big // 256
 bs = torch.cat([st] * rep).contiguous()
 bg = torch.cat([go.roll(k, 0) for k in range(rep)]).contiguous()
+bp_big = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=a.big_mode)
+bp_save, bp = bp, bp_big
 msb, resb, _ = timed(bs, bg, 2)
+bp = bp_save
 recb = resb.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:a.big]
-out.update({"big_n": a.big, "big_ms": round(msb, 3), "big_plans_per_s": round(a.big / msb * 1e3, 1),
+out.update({"big_mode": a.big_mode, "big_n": a.big, "big_ms": round(msb, 3), "big_plans_per_s": round(a.big / msb * 1e3, 1),
             "big_expansions_per_s": round(float(recb["n_pops"].sum()) / msb * 1e3), "big_solved": int((recb["status"] == 0).sum())})
 if not a.no_profile and hasattr(_native.lib(), "avp_plan_batch_profile"):
     try:
