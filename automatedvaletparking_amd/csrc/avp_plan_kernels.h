@@ -219,7 +219,15 @@ enum { CL_SKIP = 0, CL_NEW_CLOSED = 1, CL_NEW_OPEN = 2, CL_IMPROVE = 3, CL_KEEP 
 struct MapTabs { const double* X; const double* Y; const uint64_t* bits; };
 
 #define PL_WPOSE 8                    // poses per wave per collision pass
+#ifndef PL_WPOSE0
 #define PL_WPOSE0 3                   // ... in the first round over the shot's samples
+#endif
+#ifndef PL_SHOT_WAVES
+#define PL_SHOT_WAVES 8               // waves that sample and check the shot (at most; wave 0 is busy with the resolution)
+#endif
+#ifndef PL_SUB_WAVES
+#define PL_SUB_WAVES 6                // waves that check the sub-step poses (waves 1 ..)
+#endif
 #ifndef PL_WQCAP
 #define PL_WQCAP (PL_THREADS >= 512 ? 1024 : 512)   // (pose, point) candidates per wave; more fall back to the lane-per-pose walk
 #endif
@@ -1341,7 +1349,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const int nwave = PL_THREADS / 64;
             const int nsubs = nchild * p.n_sub;
             {
-                const int nw = nwave - 2;
+                const int nw = min(nwave - 2, PL_SUB_WAVES);
                 const int per = max(1, min(PL_WPOSE, (nsubs + nw - 1) / nw));      // spread the poses evenly over the waves
                 if (wave >= 1 && wave <= nw) {
                     for (int base = (wave - 1) * per; base < nsubs; base += nw * per) {
@@ -1447,7 +1455,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             // stops at the first colliding sample (:335-345), typically among the first few.
             if (in_radius) {
                 const int total = s.smp_hi + 1;                 // entries past smp_hi are unset = popped by the trim
-                const int w0 = can_fast ? 1 : 0, nw = nwave - w0;
+                const int w0 = can_fast ? 1 : 0, nw = min(nwave - w0, PL_SHOT_WAVES);
                 if (wave == 0) {
                     if (lane == 0) {
                         s.fast = can_fast ? 1 : 0;
@@ -1456,7 +1464,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     wave_sync();
                     if (can_fast) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
                 }
-                if (wave >= w0) {
+                if (wave >= w0 && wave < w0 + nw) {
                     double cm, sm;
                     avp_sincos(-cn.th, sm, cm);
                     // chunk = samples base, base + stride, ... (cnt of them); hit flags land in the wave's own wchk.hit[]

@@ -85,6 +85,30 @@ def shard_indices(starts: np.ndarray, goals: np.ndarray, rank: int, world: int) 
     return order[rank::world]
 
 
+def shard_problems(starts: np.ndarray, goals: np.ndarray, rank: int, world: int):
+    """This rank's share of one problem set for the strong-scaling step (bench.py): `shard_indices` deals the
+    problems, every rank gets the same number `per` = ceil(n / world) of rows so that the results can travel in ONE
+    all_gather_into_tensor of fixed shape; short shards are padded with start == goal problems (they end at once with
+    status RS_ERROR) whose index is -1. Returns (starts_local, goals_local, idx_padded, per)."""
+    starts = np.asarray(starts, dtype=np.float64).reshape(-1, 3)
+    goals = np.asarray(goals, dtype=np.float64).reshape(-1, 3)
+    idx = shard_indices(starts, goals, rank, world)
+    per = (len(starts) + world - 1) // world
+    pad = per - len(idx)
+    s_l = np.concatenate([starts[idx], np.tile(goals[:1], (pad, 1))]) if pad else starts[idx]
+    g_l = np.concatenate([goals[idx], np.tile(goals[:1], (pad, 1))]) if pad else goals[idx]
+    return np.ascontiguousarray(s_l), np.ascontiguousarray(g_l), np.concatenate([idx, -np.ones(pad, np.int64)]), per
+
+
+def unshard_rows(idx_all: np.ndarray, *blocks):
+    """Undo the deal: idx_all = the gathered padded index vectors (world * per entries, -1 = padding), blocks = gathered
+    arrays whose first axis runs over the same world * per rows. Returns the blocks in original problem order."""
+    idx_all = np.asarray(idx_all).reshape(-1)
+    keep = idx_all >= 0
+    order = np.argsort(idx_all[keep], kind="stable")
+    return [np.asarray(b)[keep][order] for b in blocks]
+
+
 def gather_records(local_idx: np.ndarray, local_rec: np.ndarray, n_total: int, dst: int = 0, device=None) -> Optional[np.ndarray]:
     """Gather fixed-stride float64 records (one row per problem) to rank `dst`, restoring the
     original problem order. local_rec: (len(local_idx), stride). Returns (n_total, stride) on dst."""

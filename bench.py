@@ -56,12 +56,16 @@ def source_hash():
 class Group:
     """One map + its problems on this rank's GPU."""
 
-    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP):
+    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP, mode=0):
+        import ctypes as C
         from automatedvaletparking_amd import _native, path_planner
         self.m = m
         self.dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=cap)
-        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=MAX_NODES, max_path=MAX_PATH)
+        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=mode)
         self.set_problems(starts, goals)
+        L = _native.lib()
+        self.mode = int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(self.n), C.c_int32(mode)))      # 1 workgroup / 2 wave per problem
+        self.slots = int(L.avp_plan_slots(self.dm.h, C.c_int32(self.mode)))
 
     def set_problems(self, starts, goals):
         self.starts, self.goals = np.ascontiguousarray(starts), np.ascontiguousarray(goals)
@@ -87,15 +91,18 @@ def records(res_t, n):
 
 
 def summarize(recs, n_slots, elapsed_per_step):
-    """Throughput figures of one step over the given record arrays (one per group)."""
+    """Throughput figures of one step over the given record arrays (one per group). n_slots: problem slots of the kernel
+    form that ran (CUs for one workgroup per problem, 8 x CUs for one wave per problem), or a list, one per group."""
+    if not isinstance(n_slots, (list, tuple)):
+        n_slots = [n_slots] * len(recs)
     rec = np.concatenate(recs)
     done = (rec["status"] == 0) | (rec["status"] == 1)
     pops = int(rec["n_pops"].sum())
     # slot utilisation: pops / (slots x pops of the busiest slot), per launch, pops-weighted over the launches
     util_num = util_den = 0
-    for r in recs:
+    for r, ns in zip(recs, n_slots):
         per_slot = np.bincount(r["slot"], weights=r["n_pops"], minlength=1)
-        slots = min(n_slots, len(r))
+        slots = min(ns, len(r))
         util_num += r["n_pops"].sum()
         util_den += slots * per_slot.max()
     return {"plans_per_s": float(done.sum()) / elapsed_per_step, "all_problems_per_s": len(rec) / elapsed_per_step,
@@ -230,17 +237,15 @@ def main():
         elapsed, outs = timed_steps(step, a.steps, a.warmup)
         recs = [records(o[0], g.n) for o, g in zip(outs, groups)]
         shard_invariant = None
+        for g in groups:
+            g.kernel_form = g.mode
     else:
         # shard: problems dealt by decreasing start-goal distance; equal shard size (padded with start == goal problems)
         groups, idxs, pers = [], [], []
         for (m, st, go) in groups_full:
-            idx = avd.shard_indices(st, go, rank, world)
-            per = (len(st) + world - 1) // world
-            pad = per - len(idx)
-            s_l = np.concatenate([st[idx], np.tile(go[:1], (pad, 1))]) if pad else st[idx]
-            g_l = np.concatenate([go[idx], np.tile(go[:1], (pad, 1))]) if pad else go[idx]
+            s_l, g_l, idx_pad, per = avd.shard_problems(st, go, rank, world)
             groups.append(Group(m, veh, wcfg, s_l, g_l, local, cap))
-            idxs.append(np.concatenate([idx, -np.ones(pad, np.int64)]))
+            idxs.append(idx_pad)
             pers.append(per)
         rec_stride = path_planner.RESULT_DTYPE.itemsize
         gat_r = [torch.empty((world, per, rec_stride), dtype=torch.uint8, device=dev) for per in pers]
@@ -269,9 +274,7 @@ def main():
                 flat_p = gat_p[k].reshape(-1, MAX_PATH, 4).cpu().numpy()
                 flat_r = flat_r.copy()
                 flat_r["slot"] += (np.arange(len(flat_r)) // pers[k]).astype(np.int32) * slots_per_gpu     # slot ids are per GPU
-                keep = idx_t[k] >= 0
-                order = np.argsort(idx_t[k][keep])
-                rec_all, path_all = flat_r[keep][order], flat_p[keep][order]
+                rec_all, path_all = avd.unshard_rows(idx_t[k], flat_r, flat_p)
                 recs.append(rec_all)
                 # the same set on this GPU alone (untimed): the sharded result must be identical
                 ref = Group(m, veh, wcfg, st, go, local, cap)
@@ -286,7 +289,7 @@ def main():
 
     if rank == 0:
         n_slots = int(_native.lib().avp_plan_default_slots(groups[0].dm.h))
-        head = summarize(recs, n_slots * (world if use_dist else 1), elapsed / a.steps)
+        head = summarize(recs, [g.slots * (world if use_dist else 1) for g in groups], elapsed / a.steps)
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_k[a.warmup:a.warmup + a.steps]])) if a.steps else 0.0
         rec = np.concatenate(recs)
         P = groups[0].dm.P
@@ -330,6 +333,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if use_dist else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "problems": head["problems"], "pop_cap": cap, "obstacle_points": P,
+                       "kernel_form": "one workgroup per problem" if groups[0].mode == 1 else "one wave per problem",
                        "parallelism": f"shard{world}" + (" (records + paths all-gathered in the timed step)" if use_dist else "")},
             "value_counts": "completed searches (status OK or NO_PATH); ITER_LIMIT problems are excluded",
             "all_problems_per_s": head["all_problems_per_s"], "expansions_per_s": head["expansions_per_s"],
@@ -356,10 +360,29 @@ def main():
                     xo = xstep()
                 torch.cuda.synchronize()
                 xe = (time.perf_counter() - t0) / 2
-                xs = summarize([records(o[0], g.n) for o, g in zip(xo, xg)], n_slots, xe)
+                xs = summarize([records(o[0], g.n) for o, g in zip(xo, xg)], [g.slots for g in xg], xe)
                 xs["workload"] = lab
+                xs["kernel_form"] = "one workgroup per problem" if xg[0].mode == 1 else "one wave per problem"
                 out[name] = xs
                 del xg
+            if not a.pmc_mode:
+                # ---- a saturating batch (4 x the 4 096 set, goals re-paired): the chip's sustained expansion rate in both
+                # kernel forms (avp_plan_batch_mode): the workgroup form keeps 256 problems in flight, the wave form 2 048
+                lab, xcfg, xcap, xsets = build("batch4096")
+                mm, st4, go4 = xsets[0]
+                st16 = np.concatenate([st4] * 4)
+                go16 = np.concatenate([np.roll(go4, 17 * k, axis=0) for k in range(4)])
+                sat = {"workload": "Case1 map, 16384 problems (the 4096 starts against 4 rotations of the goals), pop cap 1000"}
+                for mode, key in ((1, "workgroup_per_problem"), (2, "wave_per_problem")):
+                    g16 = Group(mm, veh, xcfg, st16, go16, local, xcap, mode=mode)
+                    g16.bp.plan_dev(g16.st_t, g16.go_t, want_paths=True)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    o16 = g16.bp.plan_dev(g16.st_t, g16.go_t, want_paths=True)
+                    torch.cuda.synchronize()
+                    sat[key] = summarize([records(o16[0], g16.n)], [g16.slots], time.perf_counter() - t0)
+                    del g16
+                out["saturating_batch"] = sat
             # ---- the footprint-collision kernel alone ----------------------------------------------------------------
             dm = groups[0].dm
             m = groups[0].m

@@ -55,8 +55,25 @@ def _worker(rank, world, port, q):
     blk = torch.full((5, 7), rank + 1, dtype=torch.uint8)
     allb = avd.all_gather_rows(blk)
     assert allb.shape == (world, 5, 7) and all(int(allb[r].min()) == r + 1 == int(allb[r].max()) for r in range(world))
+    # bench.py's strong-scaling step (--gpus N): padded equal shards from shard_problems, ONE all-gather of the fixed
+    # stride records and ONE of the solved paths (max_path x 4 doubles), restored to problem order by unshard_rows
+    n13 = 11                                           # not a multiple of the world size: one shard is padded
+    s_l, g_l, idx_pad, per = avd.shard_problems(starts[:n13], goals[:n13], rank, world)
+    max_path = 40
+    rec_l = np.zeros((per, 4))
+    path_l = np.zeros((per, max_path, 4))
+    for i in range(per):
+        r = o.plan(s_l[i], g_l[i], max_trace=1)
+        k = min(len(r["final_path"]), max_path)
+        rec_l[i] = [r["status"], r["n_pops"], k, r["rs_L"]]
+        path_l[i, :k, :3] = r["final_path"][:k]
+    assert all(rec_l[i, 0] == 3 for i in range(per) if idx_pad[i] < 0)          # padding = start == goal problems
+    g_rec = avd.all_gather_rows(torch.as_tensor(rec_l))
+    g_path = avd.all_gather_rows(torch.as_tensor(path_l))
+    g_idx = avd.all_gather_rows(torch.as_tensor(idx_pad))
+    rec13, path13 = avd.unshard_rows(g_idx.numpy().reshape(-1), g_rec.numpy().reshape(-1, 4), g_path.numpy().reshape(-1, max_path, 4))
     if rank == 0:
-        q.put((rec, avd.pack_map_blob(m)))
+        q.put((rec, avd.pack_map_blob(m), rec13, path13))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,7 +88,7 @@ def test_shard_invariance_world2(vehicle, cfg):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    rec2, blob = q.get(timeout=300)
+    rec2, blob, rec13, path13 = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -88,6 +105,11 @@ def test_shard_invariance_world2(vehicle, cfg):
         assert rec2[i, 0] == r["status"] and rec2[i, 1] == r["n_pops"] and rec2[i, 2] == len(r["final_path"])
         k = min(len(r["final_path"]), 64)
         assert np.array_equal(rec2[i, 4:4 + 3 * k], r["final_path"][:k].ravel())
+        if i < 11:                                     # the strong-scaling step's gather: records and paths in problem order
+            k2 = min(len(r["final_path"]), 40)
+            assert list(rec13[i]) == [r["status"], r["n_pops"], k2, r["rs_L"]]
+            assert np.array_equal(path13[i, :k2, :3], r["final_path"][:k2])
+    assert len(rec13) == 11
 
 
 def test_map_blob_roundtrip():
