@@ -157,9 +157,38 @@ class BatchPlanner:
         return out
 
 
+class _OpenListView:
+    """Read-only stand-in for `hybrid_a_star.open_list` (a `queue.PriorityQueue`, reference hybrid_a_star.py:96).
+    The open list lives in the planner's device workspace; what the host knows exactly is its SIZE at the end of the last
+    `a_star_plan()` (`qsize()`, `empty()` -- len(open_list.queue) of the reference, checked against the goldens). The
+    node objects themselves are not mirrored: the device heap is a scratch structure (the kernel resolves the children of
+    the final pop speculatively), so `.queue`, `get()` and `put()` raise instead of returning something subtly different."""
+
+    def __init__(self):
+        self._n = 0
+
+    def qsize(self) -> int:
+        return self._n
+
+    def empty(self) -> bool:
+        return self._n == 0
+
+    def __len__(self) -> int:
+        return self._n
+
+    @property
+    def queue(self):
+        raise NotImplementedError("the open list's nodes stay on the device; only its size is mirrored (qsize())")
+
+    def get(self, *a, **k):
+        raise NotImplementedError("PathPlanner.planner.open_list is a read-only size view")
+
+    put = get
+
+
 class _PlannerView:
     """What the reference exposes as `PathPlanner.planner` (a hybrid_a_star instance): the pieces
-    callers read (`ddt`, `dt`, `collision_checker`, `steering_angle`)."""
+    callers read (`ddt`, `dt`, `collision_checker`, `steering_angle`, `open_list`)."""
 
     def __init__(self, config, vehicle, checker):
         self.config = config
@@ -168,6 +197,7 @@ class _PlannerView:
         self.ddt = config['trajectory_dt']
         self.collision_checker = checker
         self.steering_angle = np.linspace(-vehicle.max_steering_angle, vehicle.max_steering_angle, config['steering_angle_num'])
+        self.open_list = _OpenListView()
 
 
 class PathPlanner:
@@ -217,6 +247,7 @@ class PathPlanner:
             max_nodes, max_path = 2 * max_nodes, 2 * max_path
             big = BatchPlanner(bp.dm, max_nodes=max_nodes, n_slots=1, max_path=max_path)
             r = big.plan([[c.x0, c.y0, c.theta0]], [[c.xf, c.yf, c.thetaf]])[0]
+        self.planner.open_list._n = int(r.counters.get("n_open", 0))
         if r.status in (0, 1):
             if not r.rs_types:
                 raise AttributeError("'NoneType' object has no attribute 'x'")       # path_planner.py:104

@@ -145,6 +145,9 @@ def test_reference_api_case1(vehicle, cfg):
     assert path_info["rs_path"].ctypes == ["L", "R", "L", "R"]
     assert len(path_info["rs_path"].x) == len(g["rs_xyyaw"])
     assert isinstance(original_path[0], list) and isinstance(original_path[0][0], float)
+    # planner.open_list (hybrid_a_star.py:96): a read-only size view; len(open_list.queue) of the reference's run
+    assert pl.planner.open_list.qsize() == int(g["n_open"]) and not pl.planner.open_list.empty()
+    assert pl.planner.ddt == cfg["trajectory_dt"]
 
 
 def test_reference_api_no_path_case20(vehicle, cfg):
