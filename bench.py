@@ -122,6 +122,12 @@ def main():
     ap.add_argument("--pmc-mode", action="store_true", help="headline + the footprint kernel only (the rocprofv3 PMC passes: per-launch counters)")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: everything else that writes to file descriptor 1 (RCCL's version
+    # banner, library chatter) is sent to stderr for the lifetime of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from automatedvaletparking_amd import costmap, config, sampling, _native, path_planner, distributed as avd
@@ -324,7 +330,10 @@ def main():
             rl["frac"] = rl["achieved"] / rl["peak"]
             rl["traffic"] = pk.get("hbm_bytes_per_launch_corrected")
             rl["wait_frac"] = pk.get("wait_any_frac")
-            rl["cycles_per_pop"] = pk.get("cycles_per_pop")
+            try:      # per-pop critical path of the capped problems, from the instrumented kernel (scripts/variant_bench.py)
+                rl["cycles_per_pop"] = json.load(open(os.path.join(ROOT, "profiles", "r02_plan_kernel_phase_cycles.json")))["cyc_per_pop"]
+            except Exception:
+                rl["cycles_per_pop"] = None
             rl["pmc_source"] = "profiles/r02_pmc_summary.json (source hash %s)" % pmc["source_hash"]
         elif pmc and pmc.get("stale"):
             rl["pmc_source"] = "profiles/r02_pmc_summary.json is STALE (kernel sources changed): PMC-derived fields left null"
@@ -437,7 +446,7 @@ def main():
                 tm = time.perf_counter() - t2
                 out["cpu_baseline_all_cores"] = {"value": sum(s in (0, 1) for s in st_all) / tm, "unit": "plans/s", "cores": ncore, "kind": "port",
                                                  "sample": f"the same {nb} problems, one per thread, {tm:.1f} s"}
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -41,14 +41,29 @@ def collect(root):
     return out
 
 
+def durations(root):
+    """Average launch duration [ms] per kernel (largest launches only: the top half by duration) from the kernel traces."""
+    per = defaultdict(list)
+    for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+            per[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    out = {}
+    for k, v in per.items():
+        big = [x for x in v if x >= 0.5 * max(v)]
+        out[k] = {"avg_ms": sum(big) / len(big), "launches": len(big)}
+    return out
+
+
 def main():
     base = sys.argv[1]
     passes = {name: collect(os.path.join(base, name)) for name in ("sq", "lds", "fetch", "write") if os.path.isdir(os.path.join(base, name))}
     res = {"source_hash": source_hash(),
            "command": "rocprofv3 --kernel-trace --pmc <pass counters> -- python bench.py --steps 3 --warmup 1 --pmc-mode  (one run per pass)",
            "units": "SQ_* cycle counters in quad-cycles; *_simd_cycles in shader cycles; bytes per launch"}
+    dur = durations(os.path.join(base, "sq"))
     for kern, key in (("plan_kernel<true, false>", "plan_kernel"), ("check_distance_kernel<true>", "check_distance_kernel"),
-                      ("rs_optimal_kernel", "rs_optimal_kernel"), ("corridor_kernel", "corridor_kernel"), ("check_circle_kernel", "check_circle_kernel")):
+                      ("rs_optimal_kernel", "rs_optimal_kernel"), ("corridor_compact_kernel<true>", "corridor_compact_kernel"), ("check_circle_kernel", "check_circle_kernel")):
         e = {}
         sq = passes.get("sq", {}).get(kern)
         if sq:
@@ -68,6 +83,14 @@ def main():
         if fe and wr:
             e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = fe["FETCH_SIZE"], wr["WRITE_SIZE"]
             e["hbm_bytes_per_launch_corrected"] = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
+        du = dur.get(kern)
+        if du:
+            e["launch_ms_under_rocprof"] = du["avg_ms"]
+            if "valu_active_simd_cycles_per_launch" in e:
+                # fraction of the chip's SIMD cycles (1024 SIMDs x 2.4 GHz) in which a VALU instruction was active
+                e["valu_busy_frac_of_chip"] = e["valu_active_simd_cycles_per_launch"] / (du["avg_ms"] * 1e-3 * 1024 * 2.4e9)
+            if "hbm_bytes_per_launch_corrected" in e:
+                e["hbm_GBps"] = e["hbm_bytes_per_launch_corrected"] / (du["avg_ms"] * 1e-3) / 1e9
         if e:
             res[key] = e
     json.dump(res, sys.stdout, indent=1)

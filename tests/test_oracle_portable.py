@@ -84,3 +84,30 @@ def test_trace_portable_vs_reference(path, vehicle, cfg):
     assert same_ids, name
     if finished:
         assert r["final_path"].shape == g["final_path"].shape and np.abs(r["final_path"] - g["final_path"]).max() < 1e-6, name
+
+
+def test_known_tie_divergence_is_a_one_ulp_swap(vehicle, cfg):
+    """The listed divergence, pinned down on the CPU from the reference's OWN trace: at the first differing pop the
+    reference pops node A then node B whose keys differ by ONE ulp (f = 14.50108653548671 vs ...6712); the portable
+    arithmetic rounds one Reeds-Shepp length of that pair the other way and pops B first. Nothing else differs up to
+    there, and the node popped instead is the reference's very next pop."""
+    import json
+    from automatedvaletparking_amd import costmap
+    from oracle import oracle
+    (name,) = KNOWN_TIE_DIVERGENCE
+    g = np.load(os.path.join(GOLD, name))
+    gp = g["pops"]
+    case = costmap.Case.read(os.path.join(CASES, f"Case{int(g['case'])}.csv"))
+    m = costmap.Map.from_cells(case, g["map_boundary"], int(g["map_nx"]), int(g["map_ny"]), g["map_cells"])
+    c2 = dict(cfg)
+    c2.update(json.loads(str(g["cfg_json"])))
+    with oracle.portable_libm():
+        r = oracle.Oracle(m, vehicle, c2, max_pops=len(gp)).plan(g["start"], g["goal"], max_trace=len(gp) + 8)
+    t = r["trace"]
+    n = min(len(t), len(gp))
+    i = int(np.where(t[:n, 2] != gp[:n, 2])[0][0])
+    assert i == 3506 and np.array_equal(t[:i, :3], gp[:i, :3])                 # identical node / parent / grid id up to the swap
+    fa, fb = float(gp[i, 8]), float(gp[i + 1, 8])                                # the reference's own two keys
+    assert fa < fb and abs(fb - fa) <= np.spacing(fa) * 1.0000001                # exactly one unit in the last place apart
+    assert t[i, 0] == gp[i + 1, 0] and t[i, 2] == gp[i + 1, 2]                   # the port pops the reference's NEXT node first
+    assert abs(float(t[i, 8]) - fb) <= np.spacing(fb)
