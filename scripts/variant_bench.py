@@ -74,7 +74,10 @@ bp_save, bp = bp, bp_big
 msb, resb, _ = timed(bs, bg, 2)
 bp = bp_save
 recb = resb.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:a.big]
-out.update({"big_mode": a.big_mode, "big_n": a.big, "big_ms": round(msb, 3), "big_plans_per_s": round(a.big / msb * 1e3, 1),
+hb = hashlib.sha256()
+for k in ("status", "n_pops", "n_astar", "n_final", "n_checks", "n_rs", "n_closed", "n_open", "h_cells", "global_index", "n_nodes", "rs_L"):
+    hb.update(np.ascontiguousarray(recb[k]).tobytes())
+out.update({"big_digest": hb.hexdigest()[:16], "big_mode": a.big_mode, "big_n": a.big, "big_ms": round(msb, 3), "big_plans_per_s": round(a.big / msb * 1e3, 1),
             "big_expansions_per_s": round(float(recb["n_pops"].sum()) / msb * 1e3), "big_solved": int((recb["status"] == 0).sum())})
 if not a.no_profile and hasattr(_native.lib(), "avp_plan_batch_profile"):
     try:
