@@ -199,19 +199,23 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
             const int64_t blocks = (n + 255) / 256;
             hipLaunchKernelGGL(check_distance_naive_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
         } else {
-            const size_t lds_full = check_distance_lds_bytes(d, true);
-            const bool stage = lds_full + AVP_LDS_TABLE_BYTES <= 160 * 1024;     // static LDS: the trig tables
-            const size_t lds = stage ? lds_full : check_distance_lds_bytes(d, false);
+            // as many waves per workgroup (= per CU) as fit the LDS next to the staged map tables, at least 4; maps whose
+            // tables leave no room for 4 are read through L1/L2 instead, with the full 8 waves
+            int waves = CHK_WAVES;
+            while (waves > 4 && check_distance_lds_bytes(d, true, waves) + AVP_LDS_TABLE_BYTES > 160 * 1024) waves--;
+            const bool stage = check_distance_lds_bytes(d, true, waves) + AVP_LDS_TABLE_BYTES <= 160 * 1024;     // static LDS: the trig tables
+            if (!stage) waves = CHK_WAVES;
+            const size_t lds = check_distance_lds_bytes(d, stage, waves);
             const int64_t tiles = (n + 63) / 64;
-            int64_t blocks = (tiles + CHK_WAVES - 1) / CHK_WAVES;
-            const int64_t cap = (int64_t)map->n_cu * (stage ? 1 : 2);
+            int64_t blocks = (tiles + waves - 1) / waves;
+            const int64_t cap = (int64_t)map->n_cu;
             if (blocks > cap) blocks = cap;
             if (stage) {
                 HIPCHK(hipFuncSetAttribute((const void*)check_distance_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(check_distance_kernel<true>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, x, y, th, n, out);
+                hipLaunchKernelGGL(check_distance_kernel<true>, dim3((unsigned)blocks), dim3(64 * waves), lds, map->stream, d, map->params, x, y, th, n, out);
             } else {
                 HIPCHK(hipFuncSetAttribute((const void*)check_distance_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(check_distance_kernel<false>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, x, y, th, n, out);
+                hipLaunchKernelGGL(check_distance_kernel<false>, dim3((unsigned)blocks), dim3(64 * waves), lds, map->stream, d, map->params, x, y, th, n, out);
             }
         }
     } else
@@ -235,23 +239,29 @@ AVP_EXPORT int32_t avp_corridor_batch_v(avp_map* map, double expand_dis, const d
     const DevMap& d = map->dev;
     // production kernel: cell indices packed in 13 bits, way-point lane in 6; otherwise (or variant 1, the on-device
     // cross-check) the lane-per-way-point kernel
-    if (d.nx > 8191 || d.ny > 8191 || variant == 1) {
+    // the production kernel walks at most three 64-row bitmap words per column: grown AABB height <= 128 rows
+    const double diag_c = sqrt((map->params.fp_xf - map->params.fp_xr) * (map->params.fp_xf - map->params.fp_xr) +
+                               (map->params.fp_yl - map->params.fp_yr) * (map->params.fp_yl - map->params.fp_yr));
+    const bool rows_fit = (diag_c + 2.0 * expand_dis) / d.dy + 3.0 < 128.0;
+    if (d.nx > 8191 || d.ny > 8191 || variant == 1 || !rows_fit) {
         hipLaunchKernelGGL(corridor_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, map->stream, map->dev, map->params, expand_dis,
                            x, y, th, n, out);
     } else {
-        const size_t lds_full = corridor_lds_bytes(d, true);
-        const bool stage = lds_full + AVP_LDS_TABLE_BYTES <= 160 * 1024;
-        const size_t lds = stage ? lds_full : corridor_lds_bytes(d, false);
+        int waves = COR_WAVES;
+        while (waves > 3 && corridor_lds_bytes(d, true, waves) + AVP_LDS_TABLE_BYTES > 160 * 1024) waves--;
+        const bool stage = corridor_lds_bytes(d, true, waves) + AVP_LDS_TABLE_BYTES <= 160 * 1024;
+        if (!stage) waves = COR_WAVES;
+        const size_t lds = corridor_lds_bytes(d, stage, waves);
         const int64_t tiles = (n + 63) / 64;
-        int64_t blocks = (tiles + CHK_WAVES - 1) / CHK_WAVES;
-        const int64_t cap = (int64_t)map->n_cu * 2;
+        int64_t blocks = (tiles + waves - 1) / waves;
+        const int64_t cap = (int64_t)map->n_cu;
         if (blocks > cap) blocks = cap;
         if (stage) {
             HIPCHK(hipFuncSetAttribute((const void*)corridor_compact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(corridor_compact_kernel<true>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, expand_dis, x, y, th, n, out);
+            hipLaunchKernelGGL(corridor_compact_kernel<true>, dim3((unsigned)blocks), dim3(64 * waves), lds, map->stream, d, map->params, expand_dis, x, y, th, n, out);
         } else {
             HIPCHK(hipFuncSetAttribute((const void*)corridor_compact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(corridor_compact_kernel<false>, dim3((unsigned)blocks), dim3(64 * CHK_WAVES), lds, map->stream, d, map->params, expand_dis, x, y, th, n, out);
+            hipLaunchKernelGGL(corridor_compact_kernel<false>, dim3((unsigned)blocks), dim3(64 * waves), lds, map->stream, d, map->params, expand_dis, x, y, th, n, out);
         }
     }
     HIPCHK(hipGetLastError());

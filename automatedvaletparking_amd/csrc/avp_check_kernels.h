@@ -41,10 +41,17 @@ __global__ __launch_bounds__(256) void check_distance_naive_kernel(DevMap m, avp
 }
 
 // ---- production kernel ------------------------------------------------------------------------
-#define CHK_WAVES 4
-#define CHK_QCAP 4096          // queue entries per wave (u32)
-#define CHK_QDRAIN 512         // early-drain threshold (keeps the narrow phase on full waves without waiting for a full queue)
-static_assert(CHK_QCAP >= 64 * 64, "one column step appends at most 64 lanes x 64 rows: it must fit an empty queue");
+#define CHK_WAVES 8             // waves per workgroup, at most: the host launches as many as fit the LDS next to the staged map tables
+#ifndef CHK_QCAP
+#define CHK_QCAP 1024          // queue entries per wave (u32). Small on purpose: the per-wave LDS area (footprints 11.8 KB + queue 4 KB)
+                               // decides how many waves a CU holds, and the kernel is latency bound (rocprofv3: 48 % of the wave cycles
+                               // parked at 4 waves per CU) -- 8 waves with a 1 024-entry queue run 1.6 x as fast as 4 with 4 096
+#endif
+#define CHK_QDRAIN (CHK_QCAP >= 1024 ? 512 : CHK_QCAP / 2)   // early-drain threshold (keeps the narrow phase on full waves without waiting for a full queue)
+#ifndef CHK_COLS
+#define CHK_COLS 8             // map columns per broad-phase step
+#endif
+static_assert(CHK_QCAP >= 64 && (CHK_QCAP & (CHK_QCAP - 1)) == 0, "queue size: a power of two, at least one lane's column (64 rows)");
 #define CHK_FPN 22              // doubles of a Footprint that carry data (the two trailing pads are never read)
 #define CHK_FPW 23              // LDS record stride in doubles: ODD, so that the same field of different poses' records falls into
                                 // different bank pairs (a stride of 24 doubles = 48 dwords puts every 4th record on the same banks:
@@ -97,7 +104,8 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
     }
 
     const int64_t tiles = (n + 63) / 64;
-    for (int64_t tile = (int64_t)blockIdx.x * CHK_WAVES + wave; tile < tiles; tile += (int64_t)gridDim.x * CHK_WAVES) {
+    const int nwaves = (int)(blockDim.x >> 6);
+    for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < tiles; tile += (int64_t)gridDim.x * nwaves) {
         const int64_t i = tile * 64 + lane;
         const bool valid = i < n;
         int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
@@ -145,38 +153,75 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
             wave_sync();
         };
 
-        for (int c = 0; c < maxcol; c++) {
-            uint64_t bits0 = 0, bits1 = 0;
-            const int ix = ixlo + c;
-            if (c < ncol && !sHit[lane]) {
-                const uint64_t* col = sBits + (size_t)ix * m.wpc;
-                bits0 = col[w0];
-                // mask rows below iylo and above iyhi
-                bits0 &= ~0ull << (iylo & 63);
-                if (w1 == w0) bits0 &= ~0ull >> (63 - (iyhi & 63));
-                else { bits1 = col[w1] & (~0ull >> (63 - (iyhi & 63))); }
+        // Broad phase, CHK_COLS map columns per step: the lane fetches the bitmap words of its next columns together (their
+        // LDS latencies overlap), ONE wave prefix sum places all their candidates in the queue -- instead of one prefix sum,
+        // one queue update and one drain test per column (54 of them per tile).
+        for (int c0 = 0; c0 < maxcol; c0 += CHK_COLS) {
+            uint64_t b0[CHK_COLS], b1[CHK_COLS];
+            int cnt = 0;
+            const bool live = !sHit[lane];
+#pragma unroll
+            for (int k = 0; k < CHK_COLS; k++) {
+                uint64_t bits0 = 0, bits1 = 0;
+                const int c = c0 + k;
+                if (c < ncol && live) {
+                    const uint64_t* col = sBits + (size_t)(ixlo + c) * m.wpc;
+                    bits0 = col[w0];
+                    // mask rows below iylo and above iyhi
+                    bits0 &= ~0ull << (iylo & 63);
+                    if (w1 == w0) bits0 &= ~0ull >> (63 - (iyhi & 63));
+                    else { bits1 = col[w1] & (~0ull >> (63 - (iyhi & 63))); }
+                }
+                b0[k] = bits0; b1[k] = bits1;
+                cnt += __popcll(bits0) + __popcll(bits1);
             }
-            const int cnt = __popcll(bits0) + __popcll(bits1);
             int total;
             const int pre = wave_prefix_excl(cnt, lane, total);
             if (total == 0) continue;
-            if (qtail + total > CHK_QCAP) drain();            // (wave-uniform) never write past the queue, whatever the AABB height
-            int off = qtail + pre;
-            const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)ix << 13);
-            while (bits0) { const int bpos = __ffsll((unsigned long long)bits0) - 1; bits0 &= bits0 - 1; sQ[off++] = tag | (uint32_t)((w0 << 6) + bpos); }
-            while (bits1) { const int bpos = __ffsll((unsigned long long)bits1) - 1; bits1 &= bits1 - 1; sQ[off++] = tag | (uint32_t)((w1 << 6) + bpos); }
-            qtail += total;
-            if (qtail > CHK_QDRAIN) drain();
+            if (total <= CHK_QCAP) {
+                if (qtail + total > CHK_QCAP) drain();            // (wave-uniform) never write past the queue
+                int off = qtail + pre;
+#pragma unroll
+                for (int k = 0; k < CHK_COLS; k++) {
+                    const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)(ixlo + c0 + k) << 13);
+                    uint64_t bits0 = b0[k], bits1 = b1[k];
+                    while (bits0) { const int bpos = __ffsll((unsigned long long)bits0) - 1; bits0 &= bits0 - 1; sQ[off++] = tag | (uint32_t)((w0 << 6) + bpos); }
+                    while (bits1) { const int bpos = __ffsll((unsigned long long)bits1) - 1; bits1 &= bits1 - 1; sQ[off++] = tag | (uint32_t)((w1 << 6) + bpos); }
+                }
+                qtail += total;
+                if (qtail > CHK_QDRAIN) drain();
+            } else {
+                // more candidates in these columns than the queue holds (dense clutter): one column at a time, and within a
+                // column one group of CHK_QCAP / 64 lanes at a time (a lane's column holds at most 64 rows under the host's guard)
+                constexpr int GL = CHK_QCAP / 64 >= 64 ? 64 : CHK_QCAP / 64;
+#pragma unroll
+                for (int k = 0; k < CHK_COLS; k++) {
+                    for (int g0 = 0; g0 < 64; g0 += GL) {
+                        const bool mine = lane >= g0 && lane < g0 + GL;
+                        uint64_t bits0 = mine ? b0[k] : 0ull, bits1 = mine ? b1[k] : 0ull;
+                        int totk;
+                        const int prek = wave_prefix_excl(__popcll(bits0) + __popcll(bits1), lane, totk);
+                        if (totk == 0) continue;
+                        if (qtail + totk > CHK_QCAP) drain();
+                        int off = qtail + prek;
+                        const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)(ixlo + c0 + k) << 13);
+                        while (bits0) { const int bpos = __ffsll((unsigned long long)bits0) - 1; bits0 &= bits0 - 1; sQ[off++] = tag | (uint32_t)((w0 << 6) + bpos); }
+                        while (bits1) { const int bpos = __ffsll((unsigned long long)bits1) - 1; bits1 &= bits1 - 1; sQ[off++] = tag | (uint32_t)((w1 << 6) + bpos); }
+                        qtail += totk;
+                        if (qtail > CHK_QDRAIN) drain();
+                    }
+                }
+            }
         }
         drain();
         if (valid) out[i] = sHit[lane];
     }
 }
 
-static inline size_t check_distance_lds_bytes(const DevMap& m, bool stage)
+static inline size_t check_distance_lds_bytes(const DevMap& m, bool stage, int waves)
 {
     const size_t perWave = 64 * CHK_FPW + CHK_QCAP / 2 + 8;
-    return ((stage ? (size_t)m.nx * m.wpc + m.nx + m.ny : 0) + CHK_WAVES * perWave) * 8;
+    return ((stage ? (size_t)m.nx * m.wpc + m.nx + m.ny : 0) + (size_t)waves * perWave) * 8;
 }
 
 // ---- two-circle checker (collision_check.py:88-137): lane per pose, bitmap walk ---------------
@@ -298,17 +343,19 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
 // 64 lanes are compacted into a per-wave LDS queue, so the per-point work -- first matching edge area, point-line
 // distance, two divisions -- runs on full waves however unevenly the points are spread; the four running minima of a
 // way-point are LDS atomicMin on the bit patterns (all candidates are >= 0, NaN never wins: same as the "<" scan).
-#define COR_QCAP 4096
+#define COR_QCAP 2048            // queue entries per wave
+#define COR_WAVES 6               // waves per workgroup, at most (the host launches as many as fit the LDS)
+#define COR_COLS 4                // map columns per broad-phase step (up to 3 bitmap words each: the AABB is grown by expand_dis)
 struct CorPose { double ac, as, expand; int32_t cs, pad; unsigned long long mn[4]; };   // |cos|, |sin|, heading case, minima {x_max, y_max, x_min, y_min}
 
-static inline size_t corridor_lds_bytes(const DevMap& m, bool stage)
+static inline size_t corridor_lds_bytes(const DevMap& m, bool stage, int waves)
 {
     const size_t perWave = 64 * CHK_FPW * 8 + 64 * sizeof(CorPose) + COR_QCAP * 4;
-    return (stage ? ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8 : 0) + CHK_WAVES * perWave;
+    return (stage ? ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8 : 0) + (size_t)waves * perWave;
 }
 
 template <bool STAGE>
-__global__ __launch_bounds__(64 * CHK_WAVES) void corridor_compact_kernel(DevMap m, avp_params p, double expand,
+__global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap m, avp_params p, double expand,
                                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                                           const double* __restrict__ th, int64_t n, double* __restrict__ out)
 {
@@ -334,7 +381,8 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void corridor_compact_kernel(DevMap
     }
     const unsigned long long ebits = (unsigned long long)__double_as_longlong(expand);
     const int64_t tiles = (n + 63) / 64;
-    for (int64_t tile = (int64_t)blockIdx.x * CHK_WAVES + wave; tile < tiles; tile += (int64_t)gridDim.x * CHK_WAVES) {
+    const int nwaves = (int)(blockDim.x >> 6);
+    for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < tiles; tile += (int64_t)gridDim.x * nwaves) {
         const int64_t i = tile * 64 + lane;
         const bool valid = i < n;
         const double px = valid ? x[i] : 0.0, py = valid ? y[i] : 0.0, theta = valid ? th[i] : 0.0;
@@ -419,26 +467,65 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void corridor_compact_kernel(DevMap
             wave_sync();
         };
 
-        for (int c = 0; c < maxcol; c++) {
-            const int ix = ixlo + c;
-            for (int wi = 0; wi < maxword; wi++) {
-                uint64_t bits = 0;
-                const int w = w0 + wi;
-                if (c < ncol && wi < nword) {
-                    bits = sBits[(size_t)ix * m.wpc + w];
-                    if (w == w0) bits &= ~0ull << (iylo & 63);
-                    if (w == w1) bits &= ~0ull >> (63 - (iyhi & 63));
+        // Broad phase, COR_COLS columns (x up to 3 bitmap words) per step, as in check_distance_kernel: words fetched
+        // together, one wave prefix sum per step; a step that would not fit the queue is redone (column, word) by (column,
+        // word) in groups of COR_QCAP / 64 lanes.
+        const bool three = maxword > 2;                      // (wave-uniform) some lane's grown AABB spans three words
+        for (int c0 = 0; c0 < maxcol; c0 += COR_COLS) {
+            uint64_t bw[COR_COLS][3];
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < COR_COLS; k++) {
+#pragma unroll
+                for (int wi = 0; wi < 3; wi++) {
+                    uint64_t bits = 0;
+                    const int c = c0 + k, w = w0 + wi;
+                    if (c < ncol && wi < nword && (wi < 2 || three)) {
+                        bits = sBits[(size_t)(ixlo + c) * m.wpc + w];
+                        if (w == w0) bits &= ~0ull << (iylo & 63);
+                        if (w == w1) bits &= ~0ull >> (63 - (iyhi & 63));
+                    }
+                    bw[k][wi] = bits;
+                    cnt += __popcll(bits);
                 }
-                const int cnt = __popcll(bits);
-                int total;
-                const int pre = wave_prefix_excl(cnt, lane, total);
-                if (total == 0) continue;
-                if (qtail + total > COR_QCAP) drain();            // one (column, word) step appends <= 64 x 64 = COR_QCAP entries
+            }
+            int total;
+            const int pre = wave_prefix_excl(cnt, lane, total);
+            if (total == 0) continue;
+            if (total <= COR_QCAP) {
+                if (qtail + total > COR_QCAP) drain();
                 int off = qtail + pre;
-                const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)ix << 13);
-                while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; sQ[off++] = tag | (uint32_t)((w << 6) + bpos); }
+#pragma unroll
+                for (int k = 0; k < COR_COLS; k++) {
+                    const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)(ixlo + c0 + k) << 13);
+#pragma unroll
+                    for (int wi = 0; wi < 3; wi++) {
+                        uint64_t bits = bw[k][wi];
+                        while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; sQ[off++] = tag | (uint32_t)(((w0 + wi) << 6) + bpos); }
+                    }
+                }
                 qtail += total;
-                if (qtail > COR_QCAP - 1024) drain();
+                if (qtail > COR_QCAP / 2) drain();
+            } else {
+                constexpr int GL = COR_QCAP / 64;
+#pragma unroll
+                for (int k = 0; k < COR_COLS; k++) {
+#pragma unroll
+                    for (int wi = 0; wi < 3; wi++) {
+                        for (int g0 = 0; g0 < 64; g0 += GL) {
+                            uint64_t bits = (lane >= g0 && lane < g0 + GL) ? bw[k][wi] : 0ull;
+                            int totk;
+                            const int prek = wave_prefix_excl(__popcll(bits), lane, totk);
+                            if (totk == 0) continue;
+                            if (qtail + totk > COR_QCAP) drain();
+                            int off = qtail + prek;
+                            const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)(ixlo + c0 + k) << 13);
+                            while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; sQ[off++] = tag | (uint32_t)(((w0 + wi) << 6) + bpos); }
+                            qtail += totk;
+                            if (qtail > COR_QCAP / 2) drain();
+                        }
+                    }
+                }
             }
         }
         drain();

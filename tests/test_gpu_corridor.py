@@ -36,7 +36,7 @@ def test_corridor_random_vs_oracle(vehicle, cfg):
         poses = np.stack([rng.uniform(b[0] + 1, b[1] - 1, n), rng.uniform(b[2] + 1, b[3] - 1, n), rng.uniform(-np.pi, np.pi, n)], 1)
         poses[:500, 2] = rng.choice([0.0, np.pi / 2, -np.pi / 2, np.pi, -np.pi], 500)
         poses[500:520, 2] = 4.0            # outside [-pi, pi]: no heading case applies, bounds stay at expand_dis
-        for e in (0.8, 0.3, 2.5):           # 2.5 m: the grown AABB spans three 64-row bitmap words
+        for e in (0.8, 0.3, 2.5, 5.0):      # 2.5 m: the grown AABB spans three 64-row bitmap words; 5 m: more than the production kernel walks (falls back)
             want = o.corridor_batch(poses, e)
             assert np.array_equal(dm.corridor_batch(poses, e, variant=0), want, equal_nan=True)     # production: wave-compacted
             assert np.array_equal(dm.corridor_batch(poses, e, variant=1), want, equal_nan=True)     # lane per way-point
