@@ -19,7 +19,6 @@
 #include "../../include/avp_libm.h"
 
 enum { RS_S = 0, RS_L = 1, RS_R = 2 };
-#define RS_KEEP_MAX 24
 
 // ---- scalar maths as CALLED leaf functions (PL_LIBM_CALLS) ----------------------------------------------------
 // Fully inlined, the double-double sin/cos, atan2, asin/acos, tan, fmod and hypot bodies make up 60 % of the planner
@@ -60,44 +59,6 @@ struct RsPath {
     double l[AVP_RS_MAXSEG];   // normalised (unit turning radius) inside rs_generate; metres after rs_optimal
     double L;
 };
-
-struct RsKeep {
-    int n;
-    uint32_t code[RS_KEEP_MAX];
-    double l[RS_KEEP_MAX][AVP_RS_MAXSEG];
-    int best;
-    double bestL;          // L / maxc of the current optimum
-    double bestLn;         // its normalised L
-    int err;               // 1 = assertion L >= 0.01 failed; 2 = RS_KEEP_MAX exceeded
-    double maxc;
-};
-
-AVP_D uint32_t rs_code(int n, int a, int b, int c, int d, int e)
-{
-    return (uint32_t)n | (a << 3) | (b << 5) | (c << 7) | (d << 9) | (e << 11);
-}
-
-// rs_curve.py:137-156 + the running arg-min of :103-108
-AVP_D void rs_set_path(RsKeep& k, uint32_t code, int n, double l0, double l1, double l2, double l3, double l4)
-{
-    const double len[5] = { l0, l1, l2, l3, l4 };
-    for (int e = 0; e < k.n; e++) {
-        if (k.code[e] != code) continue;
-        double sum = 0;
-        for (int i = 0; i < n; i++) sum = sum + (k.l[e][i] - len[i]);
-        if (sum <= 0.01) return;
-    }
-    double L = 0;
-    for (int i = 0; i < n; i++) L = L + fabs(len[i]);
-    if (L >= 1000.0) return;
-    if (!(L >= 0.01)) { k.err = 1; return; }
-    if (k.n >= RS_KEEP_MAX) { k.err = 2; return; }
-    const int idx = k.n++;
-    k.code[idx] = code;
-    for (int i = 0; i < 5; i++) k.l[idx][i] = i < n ? len[i] : 0.0;
-    const double Lm = L / k.maxc;
-    if (idx == 0 || Lm <= k.bestL) { k.bestL = Lm; k.best = idx; k.bestLn = L; }
-}
 
 AVP_D void rs_polar(double x, double y, double& r, double& th) { r = avp_hypot(x, y); th = avp_atan2(y, x); }
 
@@ -367,49 +328,75 @@ __device__ __forceinline__ bool rs_word(int w, const RsFrame& f, double l[5])
     return true;
 }
 
-AVP_D void rs_keep_init(RsKeep& k, double maxc) { k.n = 0; k.err = 0; k.best = -1; k.bestL = 0; k.bestLn = 0; k.maxc = maxc; }
-AVP_D void rs_keep_add(RsKeep& k, int w, const double l[5])
+// One word as a CALLED leaf function (value in, value out: no stack): rs_optimal evaluates the words in four unrolled
+// call sites of a loop over the type groups, and inlining the nine solvers four times would only bloat the kernel.
+struct RsWordOut { double l0, l1, l2, l3, l4; int ok; };
+__device__ __noinline__ RsWordOut rs_word_fn(int w, RsFrame f)
 {
-    const RsWord W = RS_WORDS[w];
-    rs_set_path(k, rs_code(W.n, W.a, W.b, W.c, W.d, W.e), W.n, l[0], l[1], l[2], l[3], l[4]);
+    double l[5];
+    RsWordOut o;
+    o.ok = rs_word(w, f, l) ? 1 : 0;
+    o.l0 = l[0]; o.l1 = l[1]; o.l2 = l[2]; o.l3 = l[3]; o.l4 = l[4];
+    return o;
 }
 
-// rs_curve.py:627-644, serial form: fills `k` with the kept candidates and the optimum.
-AVP_D void rs_generate(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t, double maxc, RsKeep& k)
-{
-    const RsFrame f = rs_frame(q0x, q0y, q0t, q1x, q1y, q1t, maxc);
-    rs_keep_init(k, maxc);
-    for (int w = 0; w < 46; w++) {
-        double l[5];
-        if (!rs_word(w, f, l)) continue;
-        rs_keep_add(k, w, l);
-        if (k.err) return;
-    }
-}
-
-// winner of a filled RsKeep -> RsPath (normalised lengths); same status codes as rs_optimal
-AVP_D int rs_keep_result(const RsKeep& k, RsPath& out)
-{
-    out.n = 0; out.L = 0;
-    if (k.err == 1) return 2;
-    if (k.err == 2) return 4;
-    if (k.n == 0) return 1;
-    const uint32_t code = k.code[k.best];
-    out.n = code & 7;
-    for (int i = 0; i < AVP_RS_MAXSEG; i++) {
-        out.t[i] = i < out.n ? (int8_t)((code >> (3 + 2 * i)) & 3) : (int8_t)-1;
-        out.l[i] = k.l[k.best][i];
-    }
-    out.L = k.bestLn;
-    return 0;
-}
-
-// status: 0 ok, 1 no candidate (IndexError in the reference), 2 L >= 0.01 assertion, 4 keep overflow
+// calc_optimal_path (rs_curve.py:99-134 with generate_path :627-644 and set_path :137-156) for one query in one thread,
+// everything in registers: set_path only ever compares a candidate with kept candidates of the SAME type sequence, so the
+// 46 words are visited type group by type group (RS_GROUPS, word order inside a group = source order), the <= 3 kept
+// predecessors of a group live in registers, and the optimum is a running (length, word) pair -- the later word wins a
+// tie, which is what "<=" over the kept list in source order does (:103-108). No candidate list, no stack object.
+// Returns 0 ok (normalised lengths in `out`), 1 no candidate, 2 the reference's assertion L >= 0.01 fails.
 AVP_D int rs_optimal(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t, double maxc, RsPath& out)
 {
-    RsKeep k;
-    rs_generate(q0x, q0y, q0t, q1x, q1y, q1t, maxc, k);
-    return rs_keep_result(k, out);
+    const RsFrame f = rs_frame(q0x, q0y, q0t, q1x, q1y, q1t, maxc);
+    double bestLm = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0, b4 = 0.0;
+    int bestW = -1;
+    bool err = false;
+    for (int g = 0; g < 20; g++) {
+        unsigned accmask = 0;
+        double kept[3][5];
+        bool live = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int wd = RS_GROUPS[g][j];
+            if (wd < 0) live = false;
+            RsWordOut o;
+            o.l0 = o.l1 = o.l2 = o.l3 = o.l4 = 0.0; o.ok = 0;
+            if (live) o = rs_word_fn(wd, f);
+            const double l[5] = { o.l0, o.l1, o.l2, o.l3, o.l4 };
+            if (j < 3) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) kept[j][i] = l[i];
+            }
+            bool dup = false;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                if (e >= j) continue;
+                double sum = 0;
+#pragma unroll
+                for (int i = 0; i < 5; i++) sum = sum + (kept[e][i] - l[i]);          // the unused tail of both is 0.0
+                if ((accmask & (1u << e)) && sum <= 0.01) dup = true;
+            }
+            double L = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) L = L + fabs(l[i]);
+            if (!o.ok || dup || L >= 1000.0) continue;
+            if (!(L >= 0.01)) { err = true; continue; }
+            accmask |= 1u << j;
+            const double Lm = L / maxc;
+            if (bestW < 0 || Lm < bestLm || (Lm == bestLm && wd > bestW)) { bestLm = Lm; bestW = wd; b0 = l[0]; b1 = l[1]; b2 = l[2]; b3 = l[3]; b4 = l[4]; }
+        }
+    }
+    out.n = 0; out.L = 0;
+    if (err) return 2;
+    if (bestW < 0) return 1;
+    const RsWord W = RS_WORDS[bestW];
+    out.n = W.n;
+    out.t[0] = 0 < W.n ? W.a : (int8_t)-1; out.t[1] = 1 < W.n ? W.b : (int8_t)-1; out.t[2] = 2 < W.n ? W.c : (int8_t)-1;
+    out.t[3] = 3 < W.n ? W.d : (int8_t)-1; out.t[4] = 4 < W.n ? W.e : (int8_t)-1;
+    out.l[0] = b0; out.l[1] = b1; out.l[2] = b2; out.l[3] = b3; out.l[4] = b4;
+    out.L = ((((0.0 + fabs(b0)) + fabs(b1)) + fabs(b2)) + fabs(b3)) + fabs(b4);
+    return 0;
 }
 
 // rs_curve.py:597-624

@@ -121,8 +121,7 @@ int32_t avp_corridor_batch_v(avp_map* map, double expand_dis, const double* x, c
  * Replaces: rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-134), one call per (start, goal)
  * pair in the reference. All pointers device. q0, q1: n x 3 (x, y, yaw) row-major; maxc = 1 /
  * min turning radius. Outputs per query i: status[i] (0 ok, 1 no candidate word, 2 the reference's
- * "L >= 0.01" assertion fails, 3 more than maxpts samples (npts[i] = needed), 4 internal candidate
- * capacity), L[i] total length [m], types[i*5+k] in {0 S, 1 L, 2 R, -1 unused}, lens[i*5+k] signed
+ * "L >= 0.01" assertion fails, 3 more than maxpts samples (npts[i] = needed)), L[i] total length [m], types[i*5+k] in {0 S, 1 L, 2 R, -1 unused}, lens[i*5+k] signed
  * segment lengths [m], npts[i], xyyaw[(i*maxpts+j)*3 + {0,1,2}] world-frame samples every 0.5 m
  * (yaw wrapped by pi_2_pi), dir[i*maxpts+j] in {+1,-1}. maxpts = 0 (xyyaw/dir NULL) skips sampling.
  * map may be NULL (the reference's function is module-level and needs no map): the launch then goes to the
