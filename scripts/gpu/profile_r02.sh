@@ -4,7 +4,7 @@
 set -x
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/r02
-mkdir -p $O; export TMPDIR=/tmp
+rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 timeout -k 10 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log
 timeout -k 10 900 python bench.py --steps 5 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err; head -c 600 $O/bench_n1.json; tail -3 $O/bench_n1.err
 AVP_BENCH_FORCE_DIST=1 timeout -k 10 600 python bench.py --steps 3 --warmup 1 > $O/bench_force_dist.json 2> $O/bench_force_dist.err; head -c 400 $O/bench_force_dist.json
