@@ -49,7 +49,7 @@ enum { PH_INIT = 0, PH_POP, PH_RES_CLASSIFY, PH_RES_WRITE, PH_SHOT_CHECK, PH_CHI
        PH_X0 = PH_WAVE0 + 5 * 8,   // 8 fine-grained probes (see the PH_X uses)
        PH_COUNT = PH_X0 + 8 };
 #define PH_X(k, t0) do { if constexpr (PROFILE) s.phase[PH_X0 + (k)] += clock64() - (t0); } while (0)
-#define PH_MARK(k) do { if constexpr (PROFILE) { if ((threadIdx.x & 63) == 0) s.phase[PH_WAVE0 + 5 * (threadIdx.x >> 6) + (k)] += clock64() - t_pop0; } } while (0)
+#define PH_MARK(k) do { if constexpr (PROFILE) { if (ph_on && (threadIdx.x & 63) == 0) s.phase[PH_WAVE0 + 5 * (threadIdx.x >> 6) + (k)] += clock64() - t_pop0; } } while (0)
 // The timers are compiled into the PROFILE instantiation only (avp_plan_batch_profile): s_memtime instrumentation costs
 // ~10 % of the wave cycles, so the production kernel carries none and reports phase_cycles = 0.
 #define PH_NOW() (PROFILE ? clock64() : 0ll)
@@ -88,6 +88,14 @@ struct avp_plan_result_dev {          // mirrors avp_plan_result in include/avp.
 };
 
 struct PlHeapEnt { double f; uint32_t node; uint32_t pad; };
+// The first S::HEAP_LDS entries of the open list's binary heap live in LDS (members hl_f / hl_n of the state struct;
+// 0 in the wave form), the rest in the slot's workspace. Same array, same order, two homes.
+#ifndef PL_HEAP_LDS
+#define PL_HEAP_LDS 0                  // (measured: 1024 or 2048 entries in LDS make config[1] 3-5 % SLOWER than the L1/L2-resident array)
+#endif
+#ifndef PL_HEAP_POS
+#define PL_HEAP_POS 1
+#endif
 
 struct PlanWs {                       // per-slot workspace carve (device pointers)
     uint32_t* dist;                   // [idCap]
@@ -143,6 +151,43 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
     w.rsdir = (int8_t*)(base + o);
     return w;
 }
+
+// ---- expansion lookahead (plan_kernel<.., LOOK = true>) -------------------------------------------------------------
+// Everything the expansion of a node costs before the sequential resolution -- the children's poses, their sub-step
+// collision checks, the 11 Reeds-Shepp solves, the sampled shot and its collision checks -- is a pure function of
+// (node pose, goal, map, params). Workgroups that have no problem of their own (the batch is smaller than the chip, or
+// their problems are finished) serve as HELPERS: the owners post the nodes at the top of their open lists to a job
+// ring, a helper computes the expansion record with the very same device code, and the owner, when it pops that node
+// later, reads the record instead of recomputing (a record is used only if it is keyed with the node's exact pose
+// bits; whether one exists changes the time, never a result).
+#define PL_REC_WORDS 88               // u64 words of one record: 5 x 16 per-child words + 8 header words
+#define PL_JOB_WORDS 8
+#define PL_JCAP 65536                 // entries of the job ring
+#ifndef PL_LOOK_TOP
+#define PL_LOOK_TOP 16                // heap slots an owner posts per pop
+#endif
+#define PL_LOOK_HRS (pl_al((size_t)PL_RS_CAP * 3 * 8) + pl_al((size_t)PL_RS_CAP))   // sample scratch of a helper-only workgroup
+struct PlLook {
+    unsigned long long* ctrl;         // [0] ring tail, [16] ring head, [32] problems finished, [48] helpers alive (one 128-B line each)
+    unsigned long long* jobs;         // [PL_JCAP][PL_JOB_WORDS]: pid << 32 | node, pose, goal, sequence number
+    uint32_t* state;                  // [n][maxNodes]: 0 = not posted, 1 = posted, 2 = record ready
+    unsigned long long* recs;         // [n][maxNodes][PL_REC_WORDS]
+    char* hrs;                        // [helper-only workgroups][PL_LOOK_HRS]
+    int32_t on, main_blocks;          // workgroups [0, main_blocks) own a workspace slot and take problems
+};
+static inline __host__ __device__ size_t pl_look_bytes(int64_t n, int32_t maxNodes, int32_t helper_blocks)
+{
+    return 512 + (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_al((size_t)n * maxNodes * 4) + (size_t)n * maxNodes * PL_REC_WORDS * 8 +
+           (size_t)helper_blocks * PL_LOOK_HRS;
+}
+// agent-scope relaxed accesses (sc1): payload stores, s_waitcnt vmcnt(0), flag store on the producer side; flag load,
+// then payload loads on the consumer side
+__device__ __forceinline__ unsigned long long pl_ld64(const unsigned long long* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pl_st64(unsigned long long* q, unsigned long long v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t pl_ld32(const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pl_st32(uint32_t* q, uint32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long pl_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ double pl_unbits(unsigned long long v) { return __longlong_as_double((long long)v); }
 
 // ---- lane-per-pose collision test through the column bitmaps (reads L1/L2-resident tables) -----
 __device__ __forceinline__ bool pl_check_pose(const DevMap& m, const avp_params& p, double x, double y, double th)
@@ -296,9 +341,18 @@ struct PlShared {
     int32_t chk_qover;
     PlWaveChk wchk[PL_THREADS / 64];
     static constexpr int RS_CAP = PL_RS_CAP;
+    static constexpr bool HEAP_POS = PL_HEAP_POS != 0;
+    static constexpr int HEAP_LDS = PL_HEAP_LDS;
+    double hl_f[PL_HEAP_LDS > 0 ? PL_HEAP_LDS : 1];      // the first HEAP_LDS entries of the open list's heap: keys,
+    uint32_t hl_n[PL_HEAP_LDS > 0 ? PL_HEAP_LDS : 1];    // ... nodes
     __device__ __forceinline__ PlWaveChk& wave_chk() { return wchk[threadIdx.x >> 6]; }
     uint32_t chk_hit[PL_MAXCHILD * 4];   // hit flag per sub-step pose of the current pop
     int32_t next_cur, have_next;      // node popped ahead by wave 0 at the end of its resolution (see pl_resolve_fast_wave)
+    // expansion lookahead
+    unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
+    int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
+    unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
+    int32_t use_rec, job_skip, helper_reg, n_hits;
 };
 
 static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
@@ -347,13 +401,48 @@ AVP_D void pl_hash_put_atomic(const PlanWs& w, int64_t hashCap, int32_t pos, dou
 // The key is stored next to the position (one load per comparison); an in-place improvement of an
 // open node updates both copies and, like the reference (:224-230), does NOT restore the heap order.
 template <class S>
-AVP_D PlHeapEnt pl_heap_get(const PlanWs& w, const S& s, int32_t pos) { return w.heap[pos]; }
+AVP_D PlHeapEnt pl_heap_get(const PlanWs& w, const S& s, int32_t pos)
+{
+    if constexpr (S::HEAP_LDS > 0) if (pos < S::HEAP_LDS) { PlHeapEnt e; e.f = s.hl_f[pos]; e.node = s.hl_n[pos]; e.pad = 0; return e; }
+    return w.heap[pos];
+}
+// S::HEAP_POS: every node keeps the slot of its heap entry (a global store per moved entry); without it an open node's
+// entry is found by a search when its key is lowered in place (an equal pose reached again at a lower cost: measured
+// 0.4 times per pop on the bench workload -- too often for a search, hence 1).
 template <class S>
-AVP_D void pl_heap_set(const PlanWs& w, S& s, int32_t pos, PlHeapEnt e) { w.heap[pos] = e; w.nodes[e.node].heap_pos = pos; }
+AVP_D void pl_heap_set(const PlanWs& w, S& s, int32_t pos, PlHeapEnt e)
+{
+    bool lds = false;
+    if constexpr (S::HEAP_LDS > 0) if (pos < S::HEAP_LDS) { s.hl_f[pos] = e.f; s.hl_n[pos] = e.node; lds = true; }
+    if (!lds) w.heap[pos] = e;
+    if constexpr (S::HEAP_POS) w.nodes[e.node].heap_pos = pos;
+}
 template <class S>
-AVP_D void pl_heap_set_key(const PlanWs& w, S& s, int32_t pos, double f) { w.heap[pos].f = f; }
+AVP_D void pl_heap_set_key(const PlanWs& w, S& s, int32_t pos, double f)
+{
+    if constexpr (S::HEAP_LDS > 0) if (pos < S::HEAP_LDS) { s.hl_f[pos] = f; return; }
+    w.heap[pos].f = f;
+}
+// slot of `node`'s entry among the first nheap: by one thread / by a whole wave (every lane gets the answer)
+template <class S>
+AVP_D int32_t pl_heap_find(const PlanWs& w, const S& s, int32_t nheap, uint32_t node)
+{
+    for (int32_t i = 0; i < nheap; i++) if (pl_heap_get(w, s, i).node == node) return i;
+    return -1;
+}
+template <class S>
+AVP_D int32_t pl_heap_find_wave(const PlanWs& w, const S& s, int32_t nheap, uint32_t node)
+{
+    const int lane = threadIdx.x & 63;
+    for (int32_t base = 0; base < nheap; base += 64) {
+        const bool hit = base + lane < nheap && pl_heap_get(w, s, base + lane).node == node;
+        const unsigned long long mk = __ballot(hit);
+        if (mk) return base + __ffsll((unsigned long long)mk) - 1;
+    }
+    return -1;
+}
 // (the item being moved is passed in registers: re-reading a slot this thread has just written would put
-// two global round trips on the serial path of every push / pop)
+// two round trips on the serial path of every push / pop)
 template <class S>
 AVP_D void pl_siftdown(const PlanWs& w, S& s, int32_t startpos, int32_t pos, const PlHeapEnt newitem)
 {
@@ -395,7 +484,8 @@ AVP_D void pl_heap_push(const PlanWs& w, S& s, uint32_t node, double f)
 // not change while it climbs: lane i fetches ancestor i of the slot (one round trip for the whole root path instead of
 // one per level), a ballot finds the first ancestor the item does not beat, the ancestors below it move down one step
 // each (in parallel) and the item lands in the freed slot -- the same array the serial loop produces.
-AVP_D void pl_heap_push_wave(const PlanWs& w, int32_t nheap, uint32_t node, double f)
+template <class S>
+AVP_D void pl_heap_push_wave(const PlanWs& w, S& s, int32_t nheap, uint32_t node, double f)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t slot1 = (uint32_t)nheap + 1u;                 // 1-based index of the new slot
@@ -405,19 +495,20 @@ AVP_D void pl_heap_push_wave(const PlanWs& w, int32_t nheap, uint32_t node, doub
     const int32_t par = (int32_t)(slot1 >> (lane < 30 ? lane + 1 : 31)) - 1;       // path[i+1]
     PlHeapEnt anc; anc.f = 0.0; anc.node = 0; anc.pad = 0;
     const bool act = lane < depth;
-    if (act) anc = w.heap[par];
+    if (act) anc = pl_heap_get(w, s, par);
     const unsigned long long stop = __ballot(act && !(f < anc.f));
     const int j = stop ? __ffsll((unsigned long long)stop) - 1 : depth;   // the item ends at path[j]
-    if (lane < j) { w.heap[mine] = anc; w.nodes[anc.node].heap_pos = mine; }
-    if (lane == j) { PlHeapEnt e; e.f = f; e.node = node; e.pad = 0; w.heap[mine] = e; w.nodes[node].heap_pos = mine; }
+    if (lane < j) pl_heap_set(w, s, mine, anc);
+    if (lane == j) { PlHeapEnt e; e.f = f; e.node = node; e.pad = 0; pl_heap_set(w, s, mine, e); }
 }
 template <class S>
 AVP_D uint32_t pl_heap_pop(const PlanWs& w, S& s)
 {
-    const PlHeapEnt lastelt = pl_heap_get(w, s, --s.nheap);
-    if (s.nheap) {
+    const int32_t nh = --s.nheap;
+    const PlHeapEnt lastelt = pl_heap_get(w, s, nh);
+    if (nh) {
         const PlHeapEnt ret = pl_heap_get(w, s, 0);
-        pl_siftup(w, s, 0, s.nheap, lastelt);
+        pl_siftup(w, s, 0, nh, lastelt);
         return ret.node;
     }
     return lastelt.node;
@@ -1101,20 +1192,34 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         const int icls = __shfl(cls, i, 64), ipos = __shfl(pos, i, 64), ifound = __shfl(found, i, 64);
         const double if_ = __shfl(cf, i, 64), ig = __shfl(cg, i, 64), ih = __shfl(ch_, i, 64);
         if (icls == CL_NEW_OPEN) {
-            pl_heap_push_wave(w, nheap, (uint32_t)ipos, if_);
+            pl_heap_push_wave(w, s, nheap, (uint32_t)ipos, if_);
             nheap++;
-        } else if (lane == 0) {
-            PlNode& ch = w.nodes[ifound];
-            ch.f = if_; ch.g = ig; ch.h = ih;
-            ch.parent_index = cn.index; ch.parent_pos = cur;
-            ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
-            pl_heap_set_key(w, s, ch.heap_pos, if_);      // current slot: earlier pushes of this pop may have moved it
+            // The next push reads entries this one has written (other lanes' stores). While the whole root path is in
+            // the LDS part of the heap the wave's LDS operations are ordered as issued; entries in the workspace need
+            // the stores drained (a global round trip).
+            if (nheap > S::HEAP_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); wave_sync(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+            else wave_sync();
+        } else {
+            // an improvement reads the heap_pos field earlier pushes of this pop may have written (other lanes' global stores)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            wave_sync();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            int32_t hp = 0;
+            if constexpr (!S::HEAP_POS) hp = pl_heap_find_wave(w, s, nheap, (uint32_t)ifound);
+            if (lane == 0) {
+                PlNode& ch = w.nodes[ifound];
+                ch.f = if_; ch.g = ig; ch.h = ih;
+                ch.parent_index = cn.index; ch.parent_pos = cur;
+                ch.forward = (int8_t)(i < p.n_steer ? 1 : 0); ch.steer_i = (int8_t)(i % p.n_steer);
+                if constexpr (S::HEAP_POS) hp = ch.heap_pos;   // current slot: earlier pushes of this pop may have moved it
+                pl_heap_set_key(w, s, hp, if_);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            wave_sync();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        // the next push / improvement reads entries and heap_pos fields this one has written (other lanes' stores)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wave_sync();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    if (nheap > S::HEAP_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (the pop below reads entries in the workspace)
     if (lane == 0) s.nheap = nheap;
     wave_sync();
     const long long t_r3 = PH_NOW();
@@ -1199,22 +1304,119 @@ AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const dou
             else { for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = 0; }
 }
 
-template <bool STAGE, bool PROFILE>
+// Owner side of the lookahead (one wave): the expansion record of `node`, if a helper has finished it, is copied to
+// s.recb[buf]; returns whether it is there and is keyed with the node's exact pose bits, this problem and this goal.
+// Consumer order: ready flag, then payload.
+template <class S>
+__device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int buf)
+{
+    int ok = 0;
+    if (node >= 0) {
+        const size_t ri = (size_t)pid * maxNodes + node;
+        uint32_t st = 0;
+        if (lane == 0) st = pl_ld32(look.state + ri);
+        st = __shfl(st, 0, 64);
+        if (st == 2u) {
+            const unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
+            unsigned long long* rec = s.recb[buf];
+            rec[lane] = pl_ld64(rp + lane);
+            if (lane + 64 < PL_REC_WORDS) rec[lane + 64] = pl_ld64(rp + lane + 64);
+            wave_sync();
+            const PlNode& nn = w.nodes[node];
+            const unsigned long long fl = rec[84];
+            const bool r_in = fl & 1ull, r_err = (fl >> 8) & 0xffull, r_hit = (fl >> 1) & 1ull;
+            // (a record whose shot failed to solve or came out collision free is not used: that pop takes the long way)
+            ok = rec[80] == pl_bits(nn.x) && rec[81] == pl_bits(nn.y) && rec[82] == pl_bits(nn.th) &&
+                 rec[83] == (unsigned long long)pid && rec[86] == pl_bits(s.goal[0]) && rec[87] == pl_bits(s.goal[1]) &&
+                 !(r_in && (r_err || !r_hit));
+        }
+    }
+    return ok;
+}
+// The record of the node the next pop expands (wave 0, once that node is known): the prefetched one if it is that node's,
+// else loaded now. Not for the only open node: the search may end with that pop and hand back its (colliding) shot,
+// which a record does not hold.
+template <class S>
+__device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane)
+{
+    int ok = 0;
+    if (s.status == 0 && s.nheap >= 1 && node >= 0) {
+        if (node == s.pre_node && s.pre_ok) ok = 1;
+        else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1);
+    }
+    wave_sync();
+    if (lane == 0) { s.use_rec = ok; s.n_hits += ok; if (ok) s.rec_cur ^= 1; s.pre_node = -1; s.pre_ok = 0; }
+    wave_sync();
+}
+// Ahead of that: while the pop is busy elsewhere, an otherwise idle wave copies the record of the node on top of the open
+// list -- the next pop's node unless a child of this one beats it.
+template <class S>
+__device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane)
+{
+    int32_t node = -1;
+    if (s.nheap >= 2) node = (int32_t)pl_heap_get(w, s, 0).node;      // (with one open node left the record would not be used)
+    const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1);
+    if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
+}
+
+// Owner side of the lookahead: one wave posts the nodes in the first PL_LOOK_TOP heap slots that have no job yet.
+// pl_look_candidates reads the heap (while nobody changes it); pl_look_post may run later: node poses never change.
+template <class S>
+__device__ __forceinline__ uint32_t pl_look_candidate(const PlanWs& w, S& s, int lane)
+{
+    uint32_t node = 0xffffffffu;
+    if (lane < PL_LOOK_TOP && lane < s.nheap) { node = pl_heap_get(w, s, lane).node; if (node >= (uint32_t)s.nnodes) node = 0xffffffffu; }
+    return node;
+}
+template <class S>
+__device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane, uint32_t node)
+{
+    unsigned long long c = 0;
+    if (lane < 3) c = pl_ld64(look.ctrl + (lane == 0 ? 48 : lane == 1 ? 0 : 16));
+    bool want = false;
+    if (node != 0xffffffffu) want = pl_ld32(look.state + (size_t)pid * maxNodes + node) == 0u;
+    const unsigned long long helpers = __shfl(c, 0, 64), tail = __shfl(c, 1, 64), head = __shfl(c, 2, 64);
+    if (helpers == 0 || (tail > head && tail - head > (unsigned long long)(PL_JCAP - 4096))) return;    // nobody to serve / ring full
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    unsigned long long t0 = 0;
+    if (lane == 0) t0 = atomicAdd(look.ctrl + 0, (unsigned long long)__popcll(mask));
+    t0 = __shfl(t0, 0, 64);
+    if (want) {
+        const unsigned long long t = t0 + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        unsigned long long* e = look.jobs + (size_t)(t & (PL_JCAP - 1)) * PL_JOB_WORDS;
+        const PlNode& nd = w.nodes[node];
+        pl_st32(look.state + (size_t)pid * maxNodes + node, 1u);
+        pl_st64(e + 0, ((unsigned long long)pid << 32) | node);
+        pl_st64(e + 1, pl_bits(nd.x)); pl_st64(e + 2, pl_bits(nd.y)); pl_st64(e + 3, pl_bits(nd.th));
+        pl_st64(e + 4, pl_bits(s.goal[0])); pl_st64(e + 5, pl_bits(s.goal[1])); pl_st64(e + 6, pl_bits(s.goal[2]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pl_st64(e + 7, t + 1ull);
+    }
+}
+
+template <bool STAGE, bool PROFILE, bool LOOK = false>
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                           const double* __restrict__ goals, int64_t n, int32_t maxNodes,
                                                           char* __restrict__ workspace, unsigned int* __restrict__ counter,
                                                           avp_plan_result_dev* __restrict__ results,
                                                           double* __restrict__ paths, int32_t max_path,
-                                                          double* __restrict__ trace, int32_t max_trace, int32_t retry_only)
+                                                          double* __restrict__ trace, int32_t max_trace, int32_t retry_only, PlLook look)
 {
     avp_lds_tables_fill<true>();
     rs_lds_tables_fill();
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
     PlShared& s = *reinterpret_cast<PlShared*>(pl_smem);
     const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
-    const PlanWs w = plan_carve(workspace + (size_t)blockIdx.x * dims.bytes, dims);
+    // with LOOK the workgroups past look.main_blocks own no workspace slot: they only ever serve as helpers
+    const bool own_ws = !LOOK || (int32_t)blockIdx.x < look.main_blocks;
+    PlanWs w = plan_carve(workspace + (size_t)(own_ws ? blockIdx.x : 0) * dims.bytes, dims);
+    if constexpr (LOOK) if (!own_ws) {
+        w.rsbuf = (double*)(look.hrs + (size_t)((int32_t)blockIdx.x - look.main_blocks) * PL_LOOK_HRS);
+        w.rsdir = (int8_t*)(look.hrs + (size_t)((int32_t)blockIdx.x - look.main_blocks) * PL_LOOK_HRS + pl_al((size_t)PL_RS_CAP * 3 * 8));
+    }
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll
@@ -1245,12 +1447,22 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) s.pid = (int32_t)atomicAdd(counter, 1u);
+        if (tid == 0) s.pid = own_ws ? (int32_t)atomicAdd(counter, 1u) : 0x7fffffff;
         __syncthreads();
         const int64_t pid = s.pid;
-        if (pid >= n) break;
+        // no problem left: done -- or, with LOOK, serve the owners of the unfinished problems until all are finished
+        const bool helper = LOOK && pid >= n;
+        if (pid >= n && !helper) break;
         // second launch behind plan_wave_kernel: only the problems it handed back (status 100 = AVP_PLAN_RETRY)
-        if (retry_only && results[pid].status != 100) continue;
+        if (!helper && retry_only && results[pid].status != 100) continue;
+        if (helper) {
+            if (tid == 0) {
+                s.status = 0; s.done = 0; s.cur = -1; s.closed_nonempty = 0; s.nnodes = 0; s.nheap = 0; s.have_next = 0; s.use_rec = 0;
+                s.n_checks = 0; s.n_rs = 0; s.rs.n = 0;
+                if (!s.helper_reg) { s.helper_reg = 1; atomicAdd(look.ctrl + 48, 1ull); }
+            }
+            __syncthreads();
+        } else {
         const double sx = starts[3 * pid], sy = starts[3 * pid + 1], sth = starts[3 * pid + 2];
         const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
 
@@ -1286,12 +1498,16 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         }
 
         PH_ACC(PH_INIT, t_init0);
+        }
+        const int wave = tid >> 6, lane = tid & 63;
+        const int nwave = PL_THREADS / 64;
         int64_t n_pops = 0;
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
         while (s.status == 0 && !s.done) {
             __syncthreads();
             { const long long t_pop = PH_NOW();
-            if (tid == 0) {
+            const int ahead = s.have_next;
+            if (tid == 0 && !helper) {
                 if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }     // popped ahead by wave 0 (n_pops < max_pops held there)
                 else if (s.nheap == 0) { s.status = 1; }
                 else if (n_pops >= max_pops) { s.status = 4; }
@@ -1301,11 +1517,53 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     w.nodes[c].state = 3;
                 }
             }
+            if constexpr (LOOK) {
+                if (helper) {
+                    // next job of the ring (tickets are served in order; a ticket past the tail waits for its job)
+                    if (tid == 0) {
+                        const unsigned long long ticket = atomicAdd(look.ctrl + 16, 1ull);
+                        const unsigned long long* e = look.jobs + (size_t)(ticket & (PL_JCAP - 1)) * PL_JOB_WORDS;
+                        int got = 0;
+                        for (int spin = 0; spin < (1 << 23); spin++) {
+                            const unsigned long long seq = pl_ld64(e + 7);
+                            if (seq == ticket + 1ull) { got = 1; break; }
+                            if (seq > ticket + 1ull) { got = 2; break; }
+                            if (pl_ld64(look.ctrl + 32) >= (unsigned long long)n) break;
+                            __builtin_amdgcn_s_sleep(64);
+                        }
+                        s.job_skip = 0;
+                        if (got == 1) {
+                            for (int k = 0; k < 7; k++) s.job[k] = pl_ld64(e + k);
+                            if (pl_ld64(e + 7) != ticket + 1ull) s.job_skip = 1;
+                            s.goal[0] = pl_unbits(s.job[4]); s.goal[1] = pl_unbits(s.job[5]); s.goal[2] = pl_unbits(s.job[6]);
+                        } else if (got == 2) s.job_skip = 1;
+                        else s.done = 1;
+                    }
+                } else if (look.on && wave == 0 && !ahead) {
+                    // (a node popped ahead had its record fetched right behind the resolution that popped it)
+                    wave_sync();
+                    pl_look_fetch(look, w, s, pid, maxNodes, s.cur, lane);
+                }
+            }
             PH_ACC(PH_POP, t_pop); }
             __syncthreads();
             if (s.status != 0) break;
-            const PlNode cn = w.nodes[s.cur];
-            if (trace && tid == 0 && n_pops < max_trace) {
+            if constexpr (LOOK) if (helper) { if (s.done) break; if (s.job_skip) continue; }
+            PlNode cn;
+            if (!helper) cn = w.nodes[s.cur];
+            else {
+                cn.x = pl_unbits(s.job[1]); cn.y = pl_unbits(s.job[2]); cn.th = pl_unbits(s.job[3]);
+                cn.g = 0; cn.h = 0; cn.f = 0; cn.index = 0; cn.parent_index = -1; cn.parent_pos = -1; cn.forward = 1; cn.steer_i = -1; cn.state = 3; cn.heap_pos = -1;
+            }
+            const bool use_rec = LOOK && !helper && s.use_rec;
+            const bool ph_on = !LOOK || use_rec;      // (instrumented lookahead run: the per-wave timeline covers the record pops only)
+            if (PROFILE && LOOK && tid == 0 && use_rec) s.phase[PH_X0 + 7] += 1;
+            uint32_t look_node = 0xffffffffu;
+            if constexpr (LOOK) if (!helper && look.on && wave == nwave - 1) {
+                look_node = pl_look_candidate(w, s, lane);
+                if (!use_rec) pl_look_post(look, w, s, pid, maxNodes, lane, look_node);      // (hidden behind the sub-step checks)
+            }
+            if (trace && tid == 0 && !helper && n_pops < max_trace) {
                 double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
                 t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(m, cn.x, cn.y);
                 t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
@@ -1320,6 +1578,35 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
             const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
             const bool in_radius = distance < p.flag_radius;
+            bool can_fast = false;
+            long long t_f = 0;
+            if (use_rec) {
+                // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
+                const unsigned long long* rec = s.recb[s.rec_cur];
+                if constexpr (LOOK) if (wave == 1) pl_look_prefetch(look, w, s, pid, maxNodes, lane);
+                if (tid == 0) {
+                    const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
+                    s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
+                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2;
+                    if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
+                }
+                if (tid < nchild) {
+                    PlChild& c = s.child[tid];
+                    c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
+                    c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
+                    c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
+                    c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
+                    c.id = avp_pos_to_index(m, c.x, c.y);
+                    c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
+                    c.rs_err = (int8_t)(rec[64 + tid] >> 32);
+                    c.L = pl_unbits(rec[48 + tid]);
+                }
+                PH_MARK(0);
+                __syncthreads();
+                can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
+                t_f = PH_NOW();
+                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) pl_look_post(look, w, s, pid, maxNodes, lane, look_node);
+            } else {
             if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 0; }
             if (tid < nchild) {
                 PlChild& c = s.child[tid];
@@ -1333,7 +1620,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 c.x = cn.x + travel * cth;
                 c.y = cn.y + travel * sth;
                 c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
-                c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
+                c.found = helper ? -1 : pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);     // (a helper has no node table)
                 c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
                 c.id = avp_pos_to_index(m, c.x, c.y);
                 c.first_coll = 0x7fffffff;
@@ -1343,10 +1630,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             } else if (one_pass && tid == PL_THREADS - 2) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1);
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
+            if constexpr (LOOK) if (!helper && look.on && wave == 0) pl_look_prefetch(look, w, s, pid, maxNodes, lane);   // (wave 0 idles until the sub-step checks are done)
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
-            const int wave = tid >> 6, lane = tid & 63;
-            const int nwave = PL_THREADS / 64;
             const int nsubs = nchild * p.n_sub;
             {
                 const int nw = min(nwave - 2, PL_SUB_WAVES);
@@ -1374,7 +1660,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (PROFILE && tid == 0) s.phase[PH_CHILD] += t_e - t_d;
 
             // read here, a full barrier before the speculative resolution on wave 0 starts to move s.nnodes
-            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
+            can_fast = !helper && s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
 
             // ---- Reeds-Shepp words: query 0 = the shot from the popped node (:326-332), 1.. = children (:286-294)
             {
@@ -1444,8 +1730,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             const long long t_f0 = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
-            if (in_radius && s.rs_status) { if (tid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? 5 : 3; __syncthreads(); break; }
+            if (!helper && in_radius && s.rs_status) { if (tid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? 5 : 3; __syncthreads(); break; }
             const long long t_g = t_f0;
+            const bool do_shot = in_radius && !s.rs_status;       // (a helper reports a failed solve in its record instead)
             // The outcome of the shot is not an input of the child resolution, so when the resolution can take its
             // fast path, wave 0 runs it SPECULATIVELY while the other waves sample and check the shot; if the shot
             // then turns out collision free (the search ends at this pop, before expand_node), the counters are
@@ -1453,7 +1740,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             // The samples are produced by the wave that checks them (no hand-over through memory, no barrier), in
             // path order, and a wave stops as soon as a collision is known before its next chunk: the reference
             // stops at the first colliding sample (:335-345), typically among the first few.
-            if (in_radius) {
+            if (do_shot) {
                 const int total = s.smp_hi + 1;                 // entries past smp_hi are unset = popped by the trim
                 const int w0 = can_fast ? 1 : 0, nw = min(nwave - w0, PL_SHOT_WAVES);
                 if (wave == 0) {
@@ -1462,7 +1749,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         s.snap[0] = s.nnodes; s.snap[1] = s.n_checks; s.snap[2] = s.n_rs; s.snap[3] = s.nclosed; s.snap[4] = s.nheap;
                     }
                     wave_sync();
-                    if (can_fast) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
+                    if (can_fast) {
+                        pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
+                        if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane); }
+                    }
                 }
                 if (wave >= w0 && wave < w0 + nw) {
                     double cm, sm;
@@ -1513,7 +1803,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (tid == 0) {
                     // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
                     if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
-                    if (s.rs_first_coll == 0x7fffffff) {
+                    if (helper) { s.collision = s.rs_first_coll != 0x7fffffff; }
+                    else if (s.rs_first_coll == 0x7fffffff) {
                         // success: the reference returns before expand_node -- undo the speculative bookkeeping
                         s.nnodes = (int32_t)s.snap[0]; s.n_checks = s.snap[1]; s.n_rs = s.snap[2]; s.nclosed = (int32_t)s.snap[3]; s.nheap = (int32_t)s.snap[4];
                         s.n_checks += s.rs_npts;
@@ -1523,18 +1814,48 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             PH_MARK(3);
             pl_lds_barrier();
-            const long long t_f = PH_NOW();
+            t_f = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
+            if constexpr (LOOK) if (helper) {
+                // publish the record: payload, then the ready flag
+                if (wave == 0) {
+                    const size_t ri = (size_t)(s.job[0] >> 32) * maxNodes + (size_t)(s.job[0] & 0xffffffffull);
+                    unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
+                    if (lane < nchild) {
+                        const PlChild& c = s.child[lane];
+                        pl_st64(rp + lane, pl_bits(c.x)); pl_st64(rp + 16 + lane, pl_bits(c.y)); pl_st64(rp + 32 + lane, pl_bits(c.th));
+                        pl_st64(rp + 48 + lane, pl_bits(c.L));
+                        pl_st64(rp + 64 + lane, (unsigned long long)(uint32_t)c.first_coll | ((unsigned long long)(uint8_t)c.rs_err << 32));
+                    }
+                    if (lane == 63) {
+                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, s.job[0] >> 32);
+                        pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
+                        pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
+                        pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    wave_sync();
+                    if (lane == 0) { pl_st32(look.state + ri, 2u); atomicAdd(look.ctrl + 24, 1ull); }      // ([24]: records made)
+                }
+                continue;
+            }
             if (s.status != 0 || s.done) break;
+            }
 
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
             // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
-            const bool tried = in_radius && can_fast;               // the speculative attempt above
+            const bool tried = !use_rec && in_radius && can_fast;   // the speculative attempt above
             if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; if (!tried) s.fast = can_fast ? 1 : 0; }
             if (!can_fast && tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
             if (!tried && can_fast) {
-                if (wave == 0) pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
+                if (wave == 0) {
+                    pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
+                    if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane); }
+                } else if (LOOK && use_rec && wave == nwave - 1) {
+                    if constexpr (LOOK) pl_look_post(look, w, s, pid, maxNodes, lane, look_node);    // (beside the resolution on wave 0)
+                }
+                if (LOOK && use_rec) PH_MARK(3);
                 __syncthreads();
             }
             if (s.fast) {
@@ -1589,7 +1910,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             const double new_f = hval + new_g;
                             if (new_f < ch.f) {
                                 ch.f = new_f; ch.g = new_g; ch.h = hval;
-                                pl_heap_set_key(w, s, ch.heap_pos, new_f);
+                                pl_heap_set_key(w, s, PlShared::HEAP_POS ? ch.heap_pos : pl_heap_find(w, s, s.nheap, (uint32_t)c.found), new_f);
                                 ch.parent_index = cn.index; ch.parent_pos = s.cur;
                                 ch.forward = (int8_t)is_forward; ch.steer_i = (int8_t)si;
                             }
@@ -1627,8 +1948,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
         }
 
+        if constexpr (LOOK) if (helper) break;             // every problem is finished (or the ring ran dry for good)
+
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
-        if (tid == 0) pl_write_result<PROFILE>(p, w, s, s.k_travel_ddt, s.k_dth_ddt, results, paths, max_path, pid, n_pops, (int32_t)blockIdx.x, t_fin);
+        if (tid == 0) {
+            pl_write_result<PROFILE>(p, w, s, s.k_travel_ddt, s.k_dth_ddt, results, paths, max_path, pid, n_pops, (int32_t)blockIdx.x, t_fin);
+            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } }   // ([8]: records used, a diagnostic)
+        }
         __syncthreads();
     }
 }

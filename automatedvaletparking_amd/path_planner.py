@@ -75,9 +75,12 @@ class BatchPlanner:
     """Device-side batched planner bound to one DeviceMap. Owns the scratch workspace (torch tensor)."""
 
     def __init__(self, device_map: _native.DeviceMap, max_nodes: int = 65536, n_slots: Optional[int] = None,
-                 max_path: int = 512, mode: int = 0):
+                 max_path: int = 512, mode: int = 0, lookahead: Optional[bool] = None):
         """mode: 0 = the library's choice by batch size, 1 = one workgroup per problem, 2 = one wave per problem
-        (include/avp.h: avp_plan_batch_mode). n_slots: problem slots (default: what the chosen form can keep busy)."""
+        (include/avp.h: avp_plan_batch_mode). n_slots: problem slots (default: what the chosen form can keep busy).
+        lookahead: let the compute units without a problem of their own pre-compute node expansions for the running
+        searches (avp_plan_batch_look; results are identical either way). None = when the library wants it for the batch
+        and its record store fits LOOK_BYTES_MAX, True = whenever the library supports it, False = never."""
         self.dm = device_map
         self.max_nodes = int(max_nodes)
         L = _native.lib()
@@ -88,6 +91,22 @@ class BatchPlanner:
             raise RuntimeError("avp_plan_result layout mismatch")
         self._ws = None
         self._ws_slots = 0
+        self.lookahead = lookahead
+        self._look = None
+        self.last_lookahead = False
+
+    LOOK_BYTES_MAX = 24 << 30
+
+    def _look_workspace(self, n):
+        if self.lookahead is False:
+            return None
+        nbytes = int(_native.lib().avp_plan_look_bytes(self.dm.h, C.c_int64(n), C.c_int32(self.max_nodes)))
+        if nbytes <= 0 or (self.lookahead is None and nbytes > self.LOOK_BYTES_MAX):
+            return None
+        if self._look is None or self._look.numel() < nbytes:
+            self._look = None
+            self._look = self.dm.empty(nbytes, self.dm.torch.uint8)
+        return self._look
 
     def _workspace(self, slots):
         if self._ws is None or self._ws_slots < slots:
@@ -120,8 +139,13 @@ class BatchPlanner:
                 C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
                 C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
                 C.c_void_p(trace.data_ptr()) if trace is not None else None, C.c_int32(max_trace))
-        if profile:
+        look = self._look_workspace(n) if (mode == 1 and (not profile or self.lookahead)) else None
+        self.last_lookahead = look is not None
+        if profile and look is None:
             _native.chk(L.avp_plan_batch_profile(*args), "avp_plan_batch_profile")
+        elif look is not None:
+            _native.chk(L.avp_plan_batch_look(*args, C.c_int32(mode | (0x100 if profile else 0)), C.c_void_p(look.data_ptr()), C.c_int64(look.numel())),
+                        "avp_plan_batch_look")
         else:
             _native.chk(L.avp_plan_batch_mode(*args, C.c_int32(mode)), "avp_plan_batch_mode")
         return res, paths, trace

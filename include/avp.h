@@ -200,6 +200,25 @@ int32_t avp_plan_batch_mode(avp_map* map, const double* starts, const double* go
 int32_t avp_plan_pick_mode(avp_map* map, int64_t n, int32_t mode);
 int32_t avp_plan_slots(avp_map* map, int32_t mode);
 
+/*
+ * Expansion lookahead (mode 1 only). A batch no larger than the chip leaves compute units without a problem of their
+ * own as soon as the short searches finish -- BASELINE config[1] keeps 20 % of the CU time busy. With a lookahead
+ * workspace the idle workgroups serve the running searches: the owner of a search posts the nodes at the top of its
+ * open list, a helper computes everything the expansion of such a node needs before the sequential resolution
+ * (children poses, sub-step collision checks, the Reeds-Shepp length of every child, the sampled and checked analytic
+ * shot -- a pure function of node pose, goal, map and parameters, evaluated by the same device code), and the owner
+ * reads the record when it pops the node. Whether a record exists changes the time of a pop, never its result
+ * (tests/test_gpu_lookahead.py: bit-identical records, paths and traces with and without).
+ * avp_plan_look_bytes: bytes of the lookahead workspace for a batch of n (0 = the library would not use one: mode 2
+ * batch, more than 2 problems per CU, more than 16 children); avp_plan_batch_look = avp_plan_batch_mode + that workspace
+ * (look_ws NULL = no lookahead).
+ */
+int64_t avp_plan_look_bytes(avp_map* map, int64_t n, int32_t max_nodes);
+int32_t avp_plan_batch_look(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
+                            int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
+                            double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t mode,
+                            void* look_ws, int64_t look_bytes);
+
 /* The same call through the instrumented instantiation of the kernel: results[i].phase_cycles holds the shader
  * cycles thread 0 spent in each phase of problem i (avp_plan_batch leaves them 0: the s_memtime reads cost ~10 % of
  * the kernel's wave cycles, so the production kernel carries none). Diagnostics only; results are identical. */

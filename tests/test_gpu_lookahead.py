@@ -1,0 +1,68 @@
+"""Expansion lookahead (avp_plan_batch_look): workgroups without a problem of their own pre-compute node expansions for
+the running searches. A record only ever replaces the very computation it was made by, so every result -- record fields,
+counters, pop traces, way-points -- must be identical with and without it, and equal to the oracle's."""
+import numpy as np
+import pytest
+
+from conftest import case_map_from_gold
+from test_gpu_plan_wave import _same_results
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(m, dm, n, seed):
+    rng = np.random.default_rng(seed)
+    b = m.boundary
+    poses = np.stack([rng.uniform(b[0] + 6, b[1] - 6, 8 * n), rng.uniform(b[2] + 6, b[3] - 6, 8 * n), rng.uniform(-np.pi, np.pi, 8 * n)], 1)
+    free = poses[dm.check_batch(poses) == 0]
+    assert len(free) >= 2 * n
+    return free[0:2 * n:2], free[1:2 * n:2]
+
+
+@pytest.mark.parametrize("n", [1, 5, 40, 256, 300])
+def test_lookahead_changes_no_result(vehicle, cfg, n):
+    from automatedvaletparking_amd import _native, path_planner
+    m = case_map_from_gold(1)
+    cap = 400
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
+    st, go = _pairs(m, dm, n, 77 + n)
+    off = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1, lookahead=False)
+    on = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1, lookahead=True)
+    a = off.plan(st, go, max_trace=cap)
+    b = on.plan(st, go, max_trace=cap)
+    assert on.last_lookahead and not off.last_lookahead
+    _same_results(a, b)
+    _same_results(on.plan(st, go, max_trace=cap), a)        # a second call on the same (re-zeroed) lookahead workspace
+
+
+def test_lookahead_vs_oracle(vehicle, cfg):
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from automatedvaletparking_amd import _native, path_planner
+    from oracle import oracle
+    from test_gpu_plan import _assert_same_as_oracle
+    m = case_map_from_gold(5)
+    cap = 300
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
+    st, go = _pairs(m, dm, 48, 5)
+    on = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1, lookahead=True)
+    res = on.plan(st, go, max_trace=cap)
+    assert on.last_lookahead
+    o = oracle.Oracle(m, vehicle, cfg, max_pops=cap)
+    with oracle.device_arithmetic():
+        with ThreadPoolExecutor(min(48, os.cpu_count() or 1)) as ex:
+            ws = list(ex.map(lambda i: o.plan(st[i], go[i], max_trace=cap), range(48)))
+    for r, w in zip(res, ws):
+        _assert_same_as_oracle(r, w)
+
+
+def test_lookahead_not_used_for_large_batches(vehicle, cfg):
+    import ctypes as C
+    from automatedvaletparking_amd import _native
+    m = case_map_from_gold(1)
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=10)
+    L = _native.lib()
+    ncu = int(L.avp_plan_slots(dm.h, C.c_int32(1)))
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu), C.c_int32(4096))) > 0
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu + 1), C.c_int32(4096))) == 0
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(64 * ncu), C.c_int32(4096))) == 0
