@@ -166,6 +166,9 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 #ifndef PL_LOOK_TOP
 #define PL_LOOK_TOP 16                // heap slots an owner posts per pop
 #endif
+#ifndef PL_LOOK_SLEEP
+#define PL_LOOK_SLEEP 64                // s_sleep argument of a helper waiting for its job (x 64 cycles; 16 .. 127 measured alike)
+#endif
 #define PL_LOOK_HRS (pl_al((size_t)PL_RS_CAP * 3 * 8) + pl_al((size_t)PL_RS_CAP))   // sample scratch of a helper-only workgroup
 struct PlLook {
     unsigned long long* ctrl;         // [0] ring tail, [16] ring head, [32] problems finished, [48] helpers alive (one 128-B line each)
@@ -1401,7 +1404,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                                           char* __restrict__ workspace, unsigned int* __restrict__ counter,
                                                           avp_plan_result_dev* __restrict__ results,
                                                           double* __restrict__ paths, int32_t max_path,
-                                                          double* __restrict__ trace, int32_t max_trace, int32_t retry_only, PlLook look)
+                                                          double* __restrict__ trace, int32_t max_trace, int32_t retry_only, PlLook look,
+                                                          const int32_t* __restrict__ order)
 {
     avp_lds_tables_fill<true>();
     rs_lds_tables_fill();
@@ -1447,7 +1451,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) s.pid = own_ws ? (int32_t)atomicAdd(counter, 1u) : 0x7fffffff;
+        if (tid == 0) {
+            // problems are taken in the caller's order (order[ticket], e.g. the expected longest first) or by index
+            const uint32_t t = own_ws ? atomicAdd(counter, 1u) : 0xffffffffu;
+            s.pid = (int64_t)t < n ? (order ? order[t] : (int32_t)t) : 0x7fffffff;
+        }
         __syncthreads();
         const int64_t pid = s.pid;
         // no problem left: done -- or, with LOOK, serve the owners of the unfinished problems until all are finished
@@ -1529,7 +1537,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             if (seq == ticket + 1ull) { got = 1; break; }
                             if (seq > ticket + 1ull) { got = 2; break; }
                             if (pl_ld64(look.ctrl + 32) >= (unsigned long long)n) break;
-                            __builtin_amdgcn_s_sleep(64);
+                            __builtin_amdgcn_s_sleep(PL_LOOK_SLEEP);
                         }
                         s.job_skip = 0;
                         if (got == 1) {

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(PW_THREADS) void plan_wave_kernel(DevMap m, avp_par
                                                                char* __restrict__ workspace, unsigned int* __restrict__ counter,
                                                                avp_plan_result_dev* __restrict__ results,
                                                                double* __restrict__ paths, int32_t max_path,
-                                                               double* __restrict__ trace, int32_t max_trace)
+                                                               double* __restrict__ trace, int32_t max_trace,
+                                                               const int32_t* __restrict__ order)
 {
     constexpr bool PROFILE = false;
     avp_lds_tables_fill<true>();
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(PW_THREADS) void plan_wave_kernel(DevMap m, avp_par
 
     for (;;) {
         CoopWave::sync();
-        if (lane == 0) s.pid = (int32_t)atomicAdd(counter, 1u);
+        if (lane == 0) { const uint32_t t = atomicAdd(counter, 1u); s.pid = (int64_t)t < n ? (order ? order[t] : (int32_t)t) : 0x7fffffff; }
         CoopWave::sync();
         const int64_t pid = s.pid;
         if (pid >= n) break;

@@ -85,6 +85,9 @@ def plan_groups(groups):
     for g in groups:
         if not hasattr(g, "stream"):
             g.stream = torch.cuda.Stream()
+            # the expansion lookahead parks helper workgroups on every CU its launch leaves free: right for one launch
+            # that has the device to itself, wrong beside 19 other launches that want those CUs (measured: 133 vs 83 ms)
+            g.bp.lookahead = False
         g.stream.wait_stream(cur)
         with torch.cuda.stream(g.stream):
             outs.append(g.bp.plan_dev(g.st_t, g.go_t, want_paths=True))
@@ -362,6 +365,7 @@ def main():
             "scaling": "strong" if use_dist else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "problems": head["problems"], "pop_cap": cap, "obstacle_points": P,
                        "kernel_form": "one workgroup per problem" if groups[0].mode == 1 else "one wave per problem",
+                       "expansion_lookahead": bool(groups[0].bp.last_lookahead),
                        "parallelism": f"shard{world}" + (" (records + paths all-gathered in the timed step)" if use_dist else "")},
             "value_counts": "completed searches (status OK or NO_PATH); ITER_LIMIT problems are excluded",
             "all_problems_per_s": head["all_problems_per_s"], "expansions_per_s": head["expansions_per_s"],
@@ -370,6 +374,23 @@ def main():
             "roofline": rl,
         }
 
+        if world == 1 and not use_dist and not a.no_extras and not a.pmc_mode and groups[0].bp.last_lookahead:
+            # ---- the same step without the expansion lookahead (idle CUs stay idle): what the helpers buy -----------------
+            g0 = groups[0]
+            bp0 = path_planner.BatchPlanner(g0.dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=1, lookahead=False)
+            o0 = bp0.plan_dev(g0.st_t, g0.go_t, want_paths=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                o0 = bp0.plan_dev(g0.st_t, g0.go_t, want_paths=True)
+            torch.cuda.synchronize()
+            x0 = summarize([records(o0[0], g0.n)], [g0.slots], (time.perf_counter() - t0) / 3)
+            r_on, r_off = recs[0], records(o0[0], g0.n)
+            p_on, p_off = outs[0][1].cpu().numpy(), o0[1].cpu().numpy()
+            x0["identical_results"] = bool(all(np.array_equal(r_on[f], r_off[f]) for f in r_on.dtype.names if f not in ("slot", "phase_cycles"))
+                                           and all(np.array_equal(p_on[i, :r_on["n_final"][i]], p_off[i, :r_on["n_final"][i]]) for i in range(g0.n)))
+            out["without_lookahead"] = x0
+            del bp0
         if world == 1 and not use_dist and not a.no_extras:
             # ---- extras on the same GPU: the other BASELINE workloads ------------------------------------------------
             for name in ("batch4096", "c3", "c5"):

@@ -210,14 +210,22 @@ int32_t avp_plan_slots(avp_map* map, int32_t mode);
  * reads the record when it pops the node. Whether a record exists changes the time of a pop, never its result
  * (tests/test_gpu_lookahead.py: bit-identical records, paths and traces with and without).
  * avp_plan_look_bytes: bytes of the lookahead workspace for a batch of n (0 = the library would not use one: mode 2
- * batch, more than 2 problems per CU, more than 16 children); avp_plan_batch_look = avp_plan_batch_mode + that workspace
- * (look_ws NULL = no lookahead).
+ * batch, more than 16 children). The helpers occupy every CU their launch leaves free until its last problem is done:
+ * meant for a launch that has the device to itself, not for several concurrent launches on different streams.
+ *
+ * Problem order. The persistent workgroups (waves) take problems off a counter; when the batch is larger than the chip the
+ * longest searches should start first or the last ones run alone (4 096 random problems in index order keep 76 % of
+ * the slot time busy). order: device, n int32, a permutation of 0 .. n-1 -- problem order[k] is the k-th to start;
+ * results stay at their problem's index. NULL = index order. For a caller that can tell its long searches: on the bench's
+ * random pairs the start-goal distance does NOT (119 vs 116 ms, scripts/order_bench.py), so nothing is reordered by default.
+ *
+ * avp_plan_batch_ex = avp_plan_batch_mode + the lookahead workspace (look_ws NULL = none) + the order (NULL = none).
  */
 int64_t avp_plan_look_bytes(avp_map* map, int64_t n, int32_t max_nodes);
-int32_t avp_plan_batch_look(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
-                            int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
-                            double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t mode,
-                            void* look_ws, int64_t look_bytes);
+int32_t avp_plan_batch_ex(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
+                          int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
+                          double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t mode,
+                          void* look_ws, int64_t look_bytes, const int32_t* order);
 
 /* The same call through the instrumented instantiation of the kernel: results[i].phase_cycles holds the shader
  * cycles thread 0 spent in each phase of problem i (avp_plan_batch leaves them 0: the s_memtime reads cost ~10 % of

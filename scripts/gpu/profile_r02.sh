@@ -17,4 +17,5 @@ done
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_check --output-format csv -- python $R/scripts/bench_check.py --iters 10 > $O/bench_check.jsonl 2> $O/stats_check.err)
 python scripts/pmc_r02_summary.py $O/pmc > $O/pmc_summary.json; head -c 400 $O/pmc_summary.json
 python scripts/variant_bench.py --big 2048 > $O/phase_profile.json 2> $O/phase_profile.err
+timeout -k 10 300 python scripts/look_bench.py > $O/lookahead.json 2> $O/lookahead.err; head -c 300 $O/lookahead.json
 find $O -name "*kernel_stats.csv" | head; du -sh $O

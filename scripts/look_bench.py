@@ -1,5 +1,8 @@
-"""A/B of the expansion lookahead on the bench's config[1] workload: identical results, time with and without.
+"""A/B of the expansion lookahead (avp_plan_batch_ex) on the bench's config[1] workload: identical results, time with and
+without, the helpers' job counters, and the per-wave timeline of the pops that were served from a record (instrumented
+instantiation). Prints one JSON object (committed as profiles/r02_lookahead.json).
 usage: python scripts/look_bench.py [n_problems] [cap]"""
+import json
 import os
 import sys
 import time
@@ -14,84 +17,59 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     import torch
     import bench
-    from automatedvaletparking_amd import _native, path_planner
+    from automatedvaletparking_amd import _native, path_planner, config, costmap
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     cap = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-    from automatedvaletparking_amd import config, costmap
     cfg, veh = config.default_config(), costmap.Vehicle()
     m = costmap.Map(file=os.path.join(bench.CASES, "Case1.csv"), discrete_size=cfg["map_discrete_size"])
-    dm0 = _native.DeviceMap(m, veh, cfg, device=0, max_pops=cap)
-    st, go = bench.sample_pairs(m, dm0, n, np.random.default_rng(20260927))
-    g = bench.Group(m, veh, cfg, st, go, 0, cap, mode=1)
-    dm = g.bp.dm
-    out = {}
-    for name, look in (("off", False), ("on", True), ("off2", False), ("on2", True)):
-        bp = path_planner.BatchPlanner(dm, max_nodes=g.bp.max_nodes, mode=1, lookahead=look)
-        bp.plan_dev(g.st_t, g.go_t, want_paths=True)
+    dm = _native.DeviceMap(m, veh, cfg, device=0, max_pops=cap)
+    st, go = bench.sample_pairs(m, dm, n, np.random.default_rng(20260927))
+    stt, got = dm.dev_tensor(st), dm.dev_tensor(go)
+    out = {"workload": "Case1 map, %d random start/goal pairs, pop cap %d (bench.py's config[1] problem set)" % (n, cap),
+           "source_hash": bench.source_hash()}
+    keep = {}
+    for name, look in (("without_lookahead", False), ("with_lookahead", True)):
+        bp = path_planner.BatchPlanner(dm, max_nodes=bench.MAX_NODES, max_path=bench.MAX_PATH, mode=1, lookahead=look)
+        bp.plan_dev(stt, got, want_paths=True)
         torch.cuda.synchronize()
         ts = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
-            res, paths, _ = bp.plan_dev(g.st_t, g.go_t, want_paths=True)
+            res, paths, _ = bp.plan_dev(stt, got, want_paths=True)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
         rec = res.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)
-        out[name] = (rec, paths.cpu().numpy(), min(ts))
+        keep[name] = (rec, paths.cpu().numpy())
+        e = {"ms_per_batch": [round(t, 3) for t in ts], "ms_best": min(ts), "pops": int(rec["n_pops"].sum()), "lookahead_used": bool(bp.last_lookahead)}
         if bp._look is not None:
             c = bp._look[:512].cpu().numpy().view(np.uint64)
-            print("   jobs posted %d, records made %d, records used %d, helpers %d" % (c[0], c[24], c[8], c[48]))
-        print(name, "lookahead used:", bp.last_lookahead, "ms:", [round(t, 2) for t in ts], "pops:", int(rec["n_pops"].sum()), flush=True)
-    a, b = out["off"], out["on"]
-    same = True
-    for f in a[0].dtype.names:
-        if f in ("slot", "phase_cycles"):
-            continue
-        if not np.array_equal(a[0][f], b[0][f]):
-            same = False
-            print("FIELD DIFFERS:", f, int((a[0][f] != b[0][f]).sum() if a[0][f].ndim == 1 else -1))
-    for i in range(len(a[0])):
-        nf = int(a[0]["n_final"][i])
-        if not np.array_equal(a[1][i, :nf], b[1][i, :nf]):
-            same = False
-            print("PATH DIFFERS:", i)
-            break
-    print("identical:", same, " speedup: %.3f" % (a[2] / b[2]))
+            e.update(jobs_posted=int(c[0]), records_made=int(c[24]), records_used=int(c[8]), helper_workgroups=int(c[48]),
+                     record_pop_frac=float(c[8]) / max(int(rec["n_pops"].sum()), 1), lookahead_workspace_bytes=int(bp._look.numel()))
+        out[name] = e
+    a, b = keep["without_lookahead"], keep["with_lookahead"]
+    same = all(np.array_equal(a[0][f], b[0][f]) for f in a[0].dtype.names if f not in ("slot", "phase_cycles"))
+    same = same and all(np.array_equal(a[1][i, :a[0]["n_final"][i]], b[1][i, :a[0]["n_final"][i]]) for i in range(len(a[0])))
+    out["identical_results"] = bool(same)
+    out["speedup"] = out["without_lookahead"]["ms_best"] / out["with_lookahead"]["ms_best"]
 
-
-
-
-def profile_record_pops():
-    """per-wave timeline of the pops served from a record (instrumented instantiation with the lookahead on)"""
-    import torch
-    import bench
-    from automatedvaletparking_amd import _native, path_planner, config, costmap
-    cfg, veh = config.default_config(), costmap.Vehicle()
-    m = costmap.Map(file=os.path.join(bench.CASES, "Case1.csv"), discrete_size=cfg["map_discrete_size"])
-    dm = _native.DeviceMap(m, veh, cfg, device=0, max_pops=1000)
-    st, go = bench.sample_pairs(m, dm, 256, np.random.default_rng(20260927))
-    bp = path_planner.BatchPlanner(dm, max_nodes=bench.MAX_NODES, mode=1, lookahead=True)
-    stt, got = dm.dev_tensor(st), dm.dev_tensor(go)
+    # the pops served from a record, per wave (instrumented instantiation, lookahead on)
+    bp = path_planner.BatchPlanner(dm, max_nodes=bench.MAX_NODES, max_path=bench.MAX_PATH, mode=1, lookahead=True)
     bp.plan_dev(stt, got, True, profile=True)
     res, _, _ = bp.plan_dev(stt, got, True, profile=True)
     torch.cuda.synchronize()
     rec = res.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)
     ph = rec["phase_cycles"].astype(np.float64)
-    long_ = rec["n_pops"] >= 900
-    hits = ph[long_, 63].sum()
-    c = bp._look[:512].cpu().numpy().view(np.uint64)
-    print("   jobs posted %d, records made %d, records used %d, helpers %d" % (c[0], c[24], c[8], c[48]))
-    pops = rec["n_pops"][long_].sum()
-    print("long problems: %d, pops %d, record pops %d (%.1f %%)" % (long_.sum(), pops, hits, 100 * hits / pops))
-    print("record pops, cycles per pop at barrier k, per wave (0 = children ready, 3 = resolution done, 4 = end):")
-    for wv in range(8):
-        print("  wave %d:" % wv, " ".join("%8.0f" % (ph[long_, 16 + 5 * wv + k].sum() / max(hits, 1)) for k in (0, 3, 4)))
-    print("PH_POP per pop %.0f; resolve classify/write/push per pop %.0f %.0f %.0f" % (
-        ph[long_, 1].sum() / pops, ph[long_, 2].sum() / pops, ph[long_, 3].sum() / pops, ph[long_, 10].sum() / pops))
+    long_ = rec["n_pops"] >= int(0.9 * cap)
+    hits, pops = ph[long_, 63].sum(), float(rec["n_pops"][long_].sum())
+    out["record_pops_of_capped_problems"] = {
+        "problems": int(long_.sum()), "pops": int(pops), "record_pops": int(hits), "record_pop_frac": hits / max(pops, 1),
+        "cycles_since_pop_start_per_wave": {"children_ready": [ph[long_, 16 + 5 * w + 0].sum() / max(hits, 1) for w in range(8)],
+                                            "resolution_done": [ph[long_, 16 + 5 * w + 3].sum() / max(hits, 1) for w in range(8)],
+                                            "end_of_pop": [ph[long_, 16 + 5 * w + 4].sum() / max(hits, 1) for w in range(8)]},
+        "resolution_classify_write_push_cycles_per_pop": [ph[long_, k].sum() / pops for k in (2, 3, 10)],
+        "note": "instrumented kernel (s_memtime reads cost ~10 %); the timeline covers record pops only, wave 0 resolves the children"}
+    print(json.dumps(out))
 
-
-if len(sys.argv) > 1 and sys.argv[1] == "profile":
-    profile_record_pops()
-    sys.exit(0)
 
 if __name__ == "__main__":
     main()

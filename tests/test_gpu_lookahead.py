@@ -1,4 +1,4 @@
-"""Expansion lookahead (avp_plan_batch_look): workgroups without a problem of their own pre-compute node expansions for
+"""Expansion lookahead (avp_plan_batch_ex): workgroups without a problem of their own pre-compute node expansions for
 the running searches. A record only ever replaces the very computation it was made by, so every result -- record fields,
 counters, pop traces, way-points -- must be identical with and without it, and equal to the oracle's."""
 import numpy as np
@@ -19,7 +19,7 @@ def _pairs(m, dm, n, seed):
     return free[0:2 * n:2], free[1:2 * n:2]
 
 
-@pytest.mark.parametrize("n", [1, 5, 40, 256, 300])
+@pytest.mark.parametrize("n", [1, 5, 40, 256, 300, 1100])
 def test_lookahead_changes_no_result(vehicle, cfg, n):
     from automatedvaletparking_amd import _native, path_planner
     m = case_map_from_gold(1)
@@ -64,5 +64,18 @@ def test_lookahead_not_used_for_large_batches(vehicle, cfg):
     L = _native.lib()
     ncu = int(L.avp_plan_slots(dm.h, C.c_int32(1)))
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu), C.c_int32(4096))) > 0
-    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu + 1), C.c_int32(4096))) == 0
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(32 * ncu - 1), C.c_int32(4096))) > 0      # the tail of a large workgroup-form batch
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(32 * ncu), C.c_int32(4096))) == 0          # wave form: no helpers
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(64 * ncu), C.c_int32(4096))) == 0
+
+
+def test_problem_order_changes_no_result(vehicle, cfg):
+    """avp_plan_batch_ex `order`: the problems start in the caller's order, results stay at their index -- both kernel forms."""
+    from automatedvaletparking_amd import _native, path_planner
+    m = case_map_from_gold(1)
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=150)
+    st, go = _pairs(m, dm, 700, 3)
+    for mode in (1, 2):
+        a = path_planner.BatchPlanner(dm, max_nodes=4096, mode=mode, lookahead=False, n_slots=64).plan(st, go, max_trace=150)
+        b = path_planner.BatchPlanner(dm, max_nodes=4096, mode=mode, lookahead=False, n_slots=64, longest_first=True).plan(st, go, max_trace=150)
+        _same_results(a, b)
