@@ -170,19 +170,44 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 #define PL_LOOK_SLEEP 64                // s_sleep argument of a helper waiting for its job (x 64 cycles; 16 .. 127 measured alike)
 #endif
 #define PL_LOOK_HRS (pl_al((size_t)PL_RS_CAP * 3 * 8) + pl_al((size_t)PL_RS_CAP))   // sample scratch of a helper-only workgroup
+#define PL_LOOK_KIDS 3                // child records per node: same gear, steering index -1 / 0 / +1 from the node's own
+#ifndef PL_LOOK_KIDS_ON_HIT
+#define PL_LOOK_KIDS_ON_HIT 0         // post the likely children on record pops too (they then need PL_LOOK_WAIT to be of use)
+#endif
+#ifndef PL_LOOK_BACKLOG
+#define PL_LOOK_BACKLOG 16             // child jobs are posted only while at most this many jobs wait in a ring
+#endif
+#ifndef PL_LOOK_WAIT
+#define PL_LOOK_WAIT 10000            // cycles an owner waits for a record that is posted but not finished (0 / 10 k / 20 k: 21.4 / 20.7 / 20.7 ms)
+#endif
 struct PlLook {
-    unsigned long long* ctrl;         // [0] ring tail, [16] ring head, [32] problems finished, [48] helpers alive (one 128-B line each)
-    unsigned long long* jobs;         // [PL_JCAP][PL_JOB_WORDS]: pid << 32 | node, pose, goal, sequence number
-    uint32_t* state;                  // [n][maxNodes]: 0 = not posted, 1 = posted, 2 = record ready
-    unsigned long long* recs;         // [n][maxNodes][PL_REC_WORDS]
+    unsigned long long* ctrl;         // ring r (0: children halves, 1: shot halves): [64 r] tail, [64 r + 16] head; [32] problems finished,
+                                      // [48] helpers alive (one 128-B line each); [8], [24], [88], [72 ..] diagnostics
+    unsigned long long* jobs;         // [2][PL_JCAP][PL_JOB_WORDS]: node | pid << 32 | slot << 52, pose, goal, sequence number
+    uint32_t* state;                  // [n][maxNodes][1 + PL_LOOK_KIDS]: bit 0 posted, bit 1 children half ready, bit 2 shot half ready
+    unsigned long long* recs;         // [n][maxNodes][1 + PL_LOOK_KIDS][PL_REC_WORDS]
     char* hrs;                        // [helper-only workgroups][PL_LOOK_HRS]
     int32_t on, main_blocks;          // workgroups [0, main_blocks) own a workspace slot and take problems
 };
+// Every expansion is posted as TWO jobs that two helpers serve at the same time -- the children half (children poses,
+// sub-step checks, the children's Reeds-Shepp lengths) and the shot half (the node's own Reeds-Shepp path, sampled and
+// checked) -- so a record is there after ~35 k cycles instead of ~55 k; a helper serves one kind only (even / odd
+// workgroups), which keeps its RS word schedule fixed. Record slot 0 of a node is the node's own expansion (posted by the
+// owner when the node reaches the top of its open list). Slots 1 .. PL_LOOK_KIDS belong to CHILDREN the node does not
+// have yet: a quarter of all pops expand a child of the node popped just before (searches dive), 99.9 % of those
+// children keep the parent's gear and 77 % steer within one step of it (CPU oracle, bench workload). When a pop takes
+// the long way the owner posts those three children right at its start, keyed (node, steering step); the fresh child is
+// looked up through its parent when it is popped ahead ~65 k cycles later.
+static inline __host__ __device__ size_t pl_look_state_bytes(int64_t n, int32_t maxNodes) { return pl_al((size_t)n * maxNodes * (1 + PL_LOOK_KIDS) * 4); }
 static inline __host__ __device__ size_t pl_look_bytes(int64_t n, int32_t maxNodes, int32_t helper_blocks)
 {
-    return 512 + (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_al((size_t)n * maxNodes * 4) + (size_t)n * maxNodes * PL_REC_WORDS * 8 +
-           (size_t)helper_blocks * PL_LOOK_HRS;
+    return 1024 + 2 * (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_look_state_bytes(n, maxNodes) +
+           (size_t)n * maxNodes * (1 + PL_LOOK_KIDS) * PL_REC_WORDS * 8 + (size_t)helper_blocks * PL_LOOK_HRS;
 }
+__device__ __forceinline__ size_t pl_look_idx(int64_t pid, int32_t maxNodes, int64_t node, int slot) { return ((size_t)pid * maxNodes + (size_t)node) * (1 + PL_LOOK_KIDS) + slot; }
+#define PL_JOB_NODE(w0) ((uint32_t)((w0) & 0xffffffffull))
+#define PL_JOB_PID(w0) ((int64_t)(((w0) >> 32) & 0xfffffull))
+#define PL_JOB_SLOT(w0) ((int)(((w0) >> 52) & 3ull))
 // agent-scope relaxed accesses (sc1): payload stores, s_waitcnt vmcnt(0), flag store on the producer side; flag load,
 // then payload loads on the consumer side
 __device__ __forceinline__ unsigned long long pl_ld64(const unsigned long long* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -355,7 +380,7 @@ struct PlShared {
     unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
-    int32_t use_rec, job_skip, helper_reg, n_hits;
+    int32_t use_rec, job_skip, helper_reg, n_hits, n_sec[4];
 };
 
 static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
@@ -1307,19 +1332,39 @@ AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const dou
             else { for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = 0; }
 }
 
-// Owner side of the lookahead (one wave): the expansion record of `node`, if a helper has finished it, is copied to
+// Owner side of the lookahead (one wave): the expansion record of `node`, if both halves are finished, is copied to
 // s.recb[buf]; returns whether it is there and is keyed with the node's exact pose bits, this problem and this goal.
-// Consumer order: ready flag, then payload.
+// A node without a record of its own is looked up among its parent's child records. Consumer order: flags, then payload.
 template <class S>
-__device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int buf)
+__device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int buf, bool wait)
 {
     int ok = 0;
     if (node >= 0) {
-        const size_t ri = (size_t)pid * maxNodes + node;
+        size_t ri = pl_look_idx(pid, maxNodes, node, 0);
         uint32_t st = 0;
-        if (lane == 0) st = pl_ld32(look.state + ri);
+        if (lane == 0) {
+            st = pl_ld32(look.state + ri);
+            if ((st & 6u) != 6u && !(st & 1u)) {
+                const PlNode& nn = w.nodes[node];
+                if (nn.parent_pos >= 0) {
+                    const PlNode& pp = w.nodes[nn.parent_pos];
+                    const int d = (int)nn.steer_i - (int)pp.steer_i;
+                    if (pp.steer_i >= 0 && nn.forward == pp.forward && d >= -1 && d <= 1) {
+                        ri = pl_look_idx(pid, maxNodes, nn.parent_pos, 2 + d);
+                        st = pl_ld32(look.state + ri);
+                        s.n_sec[(st & 6u) == 6u ? 2 : (st & 1u)] += 1;
+                    }
+                }
+            }
+            if (PL_LOOK_WAIT > 0 && wait && (st & 1u) && (st & 6u) != 6u) {
+                const long long t0 = clock64();
+                while ((st & 6u) != 6u && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = pl_ld32(look.state + ri); }
+                s.n_sec[3] += 1;
+            }
+        }
         st = __shfl(st, 0, 64);
-        if (st == 2u) {
+        ri = (size_t)__shfl((unsigned long long)ri, 0, 64);
+        if ((st & 6u) == 6u) {
             const unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
             unsigned long long* rec = s.recb[buf];
             rec[lane] = pl_ld64(rp + lane);
@@ -1345,7 +1390,7 @@ __device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& 
     int ok = 0;
     if (s.status == 0 && s.nheap >= 1 && node >= 0) {
         if (node == s.pre_node && s.pre_ok) ok = 1;
-        else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1);
+        else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true);
     }
     wave_sync();
     if (lane == 0) { s.use_rec = ok; s.n_hits += ok; if (ok) s.rec_cur ^= 1; s.pre_node = -1; s.pre_ok = 0; }
@@ -1358,12 +1403,38 @@ __device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanW
 {
     int32_t node = -1;
     if (s.nheap >= 2) node = (int32_t)pl_heap_get(w, s, 0).node;      // (with one open node left the record would not be used)
-    const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1);
+    const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, false);
     if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
 }
 
-// Owner side of the lookahead: one wave posts the nodes in the first PL_LOOK_TOP heap slots that have no job yet.
-// pl_look_candidates reads the heap (while nobody changes it); pl_look_post may run later: node poses never change.
+// One wave posts the jobs of its lanes that `want` one to BOTH rings (children half, shot half): one ticket range per ring.
+__device__ __forceinline__ void pl_ring_post2(const PlLook& look, int lane, bool want, unsigned long long w0, double x, double y, double th, const double* goal)
+{
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    unsigned long long t = 0;
+    if (lane < 2) t = atomicAdd(look.ctrl + 64 * lane, (unsigned long long)__popcll(mask));
+    const unsigned long long t0 = __shfl(t, 0, 64), t1 = __shfl(t, 1, 64);
+    if (want) {
+        const unsigned long long k = (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        unsigned long long* e0 = look.jobs + ((size_t)((t0 + k) & (PL_JCAP - 1))) * PL_JOB_WORDS;
+        unsigned long long* e1 = look.jobs + ((size_t)PL_JCAP + (size_t)((t1 + k) & (PL_JCAP - 1))) * PL_JOB_WORDS;
+        const unsigned long long bx = pl_bits(x), by = pl_bits(y), bt = pl_bits(th), g0 = pl_bits(goal[0]), g1 = pl_bits(goal[1]), g2 = pl_bits(goal[2]);
+        pl_st64(e0 + 0, w0); pl_st64(e0 + 1, bx); pl_st64(e0 + 2, by); pl_st64(e0 + 3, bt); pl_st64(e0 + 4, g0); pl_st64(e0 + 5, g1); pl_st64(e0 + 6, g2);
+        pl_st64(e1 + 0, w0); pl_st64(e1 + 1, bx); pl_st64(e1 + 2, by); pl_st64(e1 + 3, bt); pl_st64(e1 + 4, g0); pl_st64(e1 + 5, g1); pl_st64(e1 + 6, g2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pl_st64(e0 + 7, t0 + k + 1ull);
+        pl_st64(e1 + 7, t1 + k + 1ull);
+    }
+}
+// Owner side of the lookahead: one wave posts, in ONE round (one look at the ring counters, one ticket range per ring,
+// one drain of the payload stores),
+//  * lanes 0 .. PL_LOOK_TOP-1: the nodes in the first heap slots that have no job yet (pl_look_candidate reads the heap
+//    while nobody changes it; the posting may run later: node poses never change);
+//  * lanes 32 .. 34, at the start of a pop that takes the long way (kids): the three children it is most likely to be
+//    followed by -- only while the helpers keep up (at most PL_LOOK_BACKLOG jobs waiting in a ring): a child job that
+//    queues comes too late anyway, and late records mean more long pops, which post more children; without the gate the
+//    system locks into that state (measured: 18 % record pops instead of 75 %).
 template <class S>
 __device__ __forceinline__ uint32_t pl_look_candidate(const PlanWs& w, S& s, int lane)
 {
@@ -1372,30 +1443,44 @@ __device__ __forceinline__ uint32_t pl_look_candidate(const PlanWs& w, S& s, int
     return node;
 }
 template <class S>
-__device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane, uint32_t node)
+__device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w, S& s, const avp_params& p, const PlNode& cn, int64_t pid,
+                                             int32_t maxNodes, int lane, uint32_t node, bool kids)
 {
+    static_assert(PL_LOOK_TOP <= 32, "lanes 32 .. 34 post the children");
+    // ring counters (head counts the tickets drawn: it runs ahead of the tail while helpers wait for work)
     unsigned long long c = 0;
-    if (lane < 3) c = pl_ld64(look.ctrl + (lane == 0 ? 48 : lane == 1 ? 0 : 16));
+    if (lane < 5) c = pl_ld64(look.ctrl + (lane == 0 ? 48 : lane == 1 ? 0 : lane == 2 ? 16 : lane == 3 ? 64 : 80));
+    // candidates: does the slot have a job already?
+    const int d = lane - 33, sc = (int)cn.steer_i + d;
+    const bool kid = kids && lane >= 32 && lane < 32 + PL_LOOK_KIDS && cn.steer_i >= 0 && sc >= 0 && sc < p.n_steer;
+    const bool cand = lane < 32 && node != 0xffffffffu;
+    const size_t si = kid ? pl_look_idx(pid, maxNodes, s.cur, 2 + d) : pl_look_idx(pid, maxNodes, cand ? node : 0, 0);
     bool want = false;
-    if (node != 0xffffffffu) want = pl_ld32(look.state + (size_t)pid * maxNodes + node) == 0u;
-    const unsigned long long helpers = __shfl(c, 0, 64), tail = __shfl(c, 1, 64), head = __shfl(c, 2, 64);
-    if (helpers == 0 || (tail > head && tail - head > (unsigned long long)(PL_JCAP - 4096))) return;    // nobody to serve / ring full
-    const unsigned long long mask = __ballot(want);
-    if (!mask) return;
-    unsigned long long t0 = 0;
-    if (lane == 0) t0 = atomicAdd(look.ctrl + 0, (unsigned long long)__popcll(mask));
-    t0 = __shfl(t0, 0, 64);
+    if (kid || cand) want = pl_ld32(look.state + si) == 0u;
+    const unsigned long long helpers = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
+    const long long backlog = max((long long)(ta - ha), (long long)(tb - hb));
+    if (helpers == 0 || backlog > PL_JCAP - 4096) return;       // nobody to serve / a ring is full
+    if (backlog > PL_LOOK_BACKLOG && lane >= 32) want = false;
+    double x = 0.0, y = 0.0, th = 0.0;
+    unsigned long long w0 = 0;
     if (want) {
-        const unsigned long long t = t0 + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-        unsigned long long* e = look.jobs + (size_t)(t & (PL_JCAP - 1)) * PL_JOB_WORDS;
-        const PlNode& nd = w.nodes[node];
-        pl_st32(look.state + (size_t)pid * maxNodes + node, 1u);
-        pl_st64(e + 0, ((unsigned long long)pid << 32) | node);
-        pl_st64(e + 1, pl_bits(nd.x)); pl_st64(e + 2, pl_bits(nd.y)); pl_st64(e + 3, pl_bits(nd.th));
-        pl_st64(e + 4, pl_bits(s.goal[0])); pl_st64(e + 5, pl_bits(s.goal[1])); pl_st64(e + 6, pl_bits(s.goal[2]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pl_st64(e + 7, t + 1ull);
+        if (kid) {
+            // (the children stage's expressions, hybrid_a_star.py:134-151)
+            const double travel = cn.forward ? p.travel_dt : -p.travel_dt;
+            th = avp_pi_2_pi(cn.th + s.k_dth_dt[sc]);
+            double sth, cth;
+            avp_sincos(th, sth, cth);
+            x = cn.x + travel * cth;
+            y = cn.y + travel * sth;
+            w0 = (unsigned long long)(uint32_t)s.cur | ((unsigned long long)pid << 32) | ((unsigned long long)(2 + d) << 52);
+        } else {
+            const PlNode& nd = w.nodes[node];
+            x = nd.x; y = nd.y; th = nd.th;
+            w0 = (unsigned long long)node | ((unsigned long long)pid << 32);
+        }
+        pl_st32(look.state + si, 1u);
     }
+    pl_ring_post2(look, lane, want, w0, x, y, th, s.goal);
 }
 
 template <bool STAGE, bool PROFILE, bool LOOK = false>
@@ -1420,7 +1505,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         w.rsdir = (int8_t*)(look.hrs + (size_t)((int32_t)blockIdx.x - look.main_blocks) * PL_LOOK_HRS + pl_al((size_t)PL_RS_CAP * 3 * 8));
     }
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll
@@ -1460,6 +1545,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         const int64_t pid = s.pid;
         // no problem left: done -- or, with LOOK, serve the owners of the unfinished problems until all are finished
         const bool helper = LOOK && pid >= n;
+        const int hk = (int)(blockIdx.x & 1u);              // a helper serves one kind of job: 0 = children halves, 1 = shot halves
+        const bool hC = helper && hk == 0, hS = helper && hk == 1;
         if (pid >= n && !helper) break;
         // second launch behind plan_wave_kernel: only the problems it handed back (status 100 = AVP_PLAN_RETRY)
         if (!helper && retry_only && results[pid].status != 100) continue;
@@ -1529,8 +1616,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (helper) {
                     // next job of the ring (tickets are served in order; a ticket past the tail waits for its job)
                     if (tid == 0) {
-                        const unsigned long long ticket = atomicAdd(look.ctrl + 16, 1ull);
-                        const unsigned long long* e = look.jobs + (size_t)(ticket & (PL_JCAP - 1)) * PL_JOB_WORDS;
+                        const unsigned long long ticket = atomicAdd(look.ctrl + 64 * hk + 16, 1ull);
+                        const unsigned long long* e = look.jobs + ((size_t)hk * PL_JCAP + (size_t)(ticket & (PL_JCAP - 1))) * PL_JOB_WORDS;
                         int got = 0;
                         for (int spin = 0; spin < (1 << 23); spin++) {
                             const unsigned long long seq = pl_ld64(e + 7);
@@ -1564,12 +1651,15 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 cn.g = 0; cn.h = 0; cn.f = 0; cn.index = 0; cn.parent_index = -1; cn.parent_pos = -1; cn.forward = 1; cn.steer_i = -1; cn.state = 3; cn.heap_pos = -1;
             }
             const bool use_rec = LOOK && !helper && s.use_rec;
-            const bool ph_on = !LOOK || use_rec;      // (instrumented lookahead run: the per-wave timeline covers the record pops only)
-            if (PROFILE && LOOK && tid == 0 && use_rec) s.phase[PH_X0 + 7] += 1;
+#ifndef PL_PH_LONG
+#define PL_PH_LONG 0
+#endif
+            const bool ph_on = !LOOK || (PL_PH_LONG ? !use_rec : use_rec);      // (instrumented lookahead run: the per-wave timeline covers the record pops only; PL_PH_LONG: the long pops only)
+            if (PROFILE && LOOK && tid == 0 && ph_on) s.phase[PH_X0 + 7] += 1;
             uint32_t look_node = 0xffffffffu;
             if constexpr (LOOK) if (!helper && look.on && wave == nwave - 1) {
                 look_node = pl_look_candidate(w, s, lane);
-                if (!use_rec) pl_look_post(look, w, s, pid, maxNodes, lane, look_node);      // (hidden behind the sub-step checks)
+                if (!use_rec) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, true);      // (hidden behind the sub-step checks)
             }
             if (trace && tid == 0 && !helper && n_pops < max_trace) {
                 double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
@@ -1613,10 +1703,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 __syncthreads();
                 can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
                 t_f = PH_NOW();
-                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) pl_look_post(look, w, s, pid, maxNodes, lane, look_node);
+                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, PL_LOOK_KIDS_ON_HIT != 0);
             } else {
-            if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 0; }
-            if (tid < nchild) {
+            if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = hC ? 2 : 0; }
+            // a helper runs its half only: queries = the children (hC), the shot (hS), both (an owner)
+            const int qoff = hC ? 0 : 1, nq_all = hC ? nchild : (hS ? 1 : nchild + 1);
+            if (tid < nchild && !hS) {
                 PlChild& c = s.child[tid];
                 const int si = tid % p.n_steer;
                 const bool fwd = tid < p.n_steer;       // i < next_index / 2
@@ -1634,9 +1726,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 c.first_coll = 0x7fffffff;
                 c.rs_err = 0;
                 c.L = 0;
-                if (one_pass) s.frame[tid + 1] = rs_frame(c.x, c.y, c.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            } else if (one_pass && tid == PL_THREADS - 2) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nchild + 1) pl_rs_build_schedule(s, nchild + 1);
+                if (one_pass) s.frame[tid + qoff] = rs_frame(c.x, c.y, c.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            } else if (one_pass && tid == PL_THREADS - 2 && !hC) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nq_all) pl_rs_build_schedule(s, nq_all);
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
             if constexpr (LOOK) if (!helper && look.on && wave == 0) pl_look_prefetch(look, w, s, pid, maxNodes, lane);   // (wave 0 idles until the sub-step checks are done)
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
@@ -1645,7 +1737,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             {
                 const int nw = min(nwave - 2, PL_SUB_WAVES);
                 const int per = max(1, min(PL_WPOSE, (nsubs + nw - 1) / nw));      // spread the poses evenly over the waves
-                if (wave >= 1 && wave <= nw) {
+                if (wave >= 1 && wave <= nw && !hS) {
                     for (int base = (wave - 1) * per; base < nsubs; base += nw * per) {
                         const int cnt = min(per, nsubs - base);
                         pl_check_wave<PROFILE>(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
@@ -1662,7 +1754,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             PH_MARK(0);
             __syncthreads();
-            for (int t = tid; t < nsubs; t += PL_THREADS)
+            if (!hS) for (int t = tid; t < nsubs; t += PL_THREADS)
                 if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
             const long long t_e = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_CHILD] += t_e - t_d;
@@ -1672,13 +1764,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
             // ---- Reeds-Shepp words: query 0 = the shot from the popped node (:326-332), 1.. = children (:286-294)
             {
-                const int nq = nchild + 1;
+                const int nq = (hS && !in_radius) ? 0 : nq_all;      // (a shot half outside the radius has no shot)
                 for (int base = 0; base < nq; base += PL_RSQ) {
                     const int cnt = min(PL_RSQ, nq - base);
                     pl_rs_words(s, p, cnt, [&](int q, double& x, double& y, double& th) {
                         const int g = base + q;
-                        if (g == 0) { x = cn.x; y = cn.y; th = cn.th; }
-                        else { x = s.child[g - 1].x; y = s.child[g - 1].y; th = s.child[g - 1].th; }
+                        if (g < qoff) { x = cn.x; y = cn.y; th = cn.th; }
+                        else { x = s.child[g - qoff].x; y = s.child[g - qoff].y; th = s.child[g - qoff].th; }
                     }, one_pass);
                     if (base == 0) PH_MARK(1);
                     __syncthreads();
@@ -1687,9 +1779,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     // no cross-wave hand-over. Wave 0 owns the shot (query 0 of the first pass) and goes straight on to
                     // the sampler's index bookkeeping; the last wave, after its children, walks the chain of segment origins as
                     // soon as wave 0 has published the path -- two serial jobs hidden behind the children's queries.
-                    const int q_first = base == 0 ? 1 : 0;              // first query of this pass that is a child
+                    const int q_first = base == 0 ? qoff : 0;           // first query of this pass that is a child
                     if (wave == 0) {
-                        if (base == 0) {
+                        if (base == 0 && !hC) {
                             const long long t_a0 = PH_NOW();
                             if (lane < 20) pl_rs_accept_group(s, p, 0, lane);
                             wave_sync();
@@ -1720,10 +1812,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                 if (qq >= cnt) break;
                                 RsPath rp;
                                 const int st = pl_rs_fold_wave(s, qq, rp);
-                                if (lane == 0) { const int g = base + qq; s.child[g - 1].rs_err = (int8_t)st; s.child[g - 1].L = st ? 0.0 : rp.L / p.maxc; }
+                                if (lane == 0) { const int g = base + qq; s.child[g - qoff].rs_err = (int8_t)st; s.child[g - qoff].L = st ? 0.0 : rp.L / p.maxc; }
                             }
                         }
-                        if (wave == nwave - 1 && base == 0) {
+                        if (wave == nwave - 1 && base == 0 && !hC) {
                             if (lane == 0) while (*(volatile int32_t*)&s.shot_ready == 0) __builtin_amdgcn_s_sleep(1);
                             wave_sync();
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1740,7 +1832,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (PROFILE && tid == 0) s.phase[PH_CHILD_RS] += t_f0 - t_e;
             if (!helper && in_radius && s.rs_status) { if (tid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? 5 : 3; __syncthreads(); break; }
             const long long t_g = t_f0;
-            const bool do_shot = in_radius && !s.rs_status;       // (a helper reports a failed solve in its record instead)
+            const bool do_shot = in_radius && !s.rs_status && !hC; // (a helper reports a failed solve in its record instead)
             // The outcome of the shot is not an input of the child resolution, so when the resolution can take its
             // fast path, wave 0 runs it SPECULATIVELY while the other waves sample and check the shot; if the shot
             // then turns out collision free (the search ends at this pop, before expand_node), the counters are
@@ -1825,25 +1917,29 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             t_f = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
             if constexpr (LOOK) if (helper) {
-                // publish the record: payload, then the ready flag
+                // publish this half of the record: payload, then the half's ready bit
                 if (wave == 0) {
-                    const size_t ri = (size_t)(s.job[0] >> 32) * maxNodes + (size_t)(s.job[0] & 0xffffffffull);
+                    const unsigned long long j0 = s.job[0];
+                    const size_t ri = pl_look_idx(PL_JOB_PID(j0), maxNodes, PL_JOB_NODE(j0), PL_JOB_SLOT(j0));
                     unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
-                    if (lane < nchild) {
+                    if (hC && lane < nchild) {
                         const PlChild& c = s.child[lane];
                         pl_st64(rp + lane, pl_bits(c.x)); pl_st64(rp + 16 + lane, pl_bits(c.y)); pl_st64(rp + 32 + lane, pl_bits(c.th));
                         pl_st64(rp + 48 + lane, pl_bits(c.L));
                         pl_st64(rp + 64 + lane, (unsigned long long)(uint32_t)c.first_coll | ((unsigned long long)(uint8_t)c.rs_err << 32));
                     }
                     if (lane == 63) {
-                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, s.job[0] >> 32);
-                        pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
-                        pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
+                        // (the key words are written by both halves, with the same values)
+                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, (unsigned long long)PL_JOB_PID(j0));
                         pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
+                        if (hS) {
+                            pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
+                            pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
+                        }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     wave_sync();
-                    if (lane == 0) { pl_st32(look.state + ri, 2u); atomicAdd(look.ctrl + 24, 1ull); }      // ([24]: records made)
+                    if (lane == 0) { atomicOr(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
                 }
                 continue;
             }
@@ -1861,7 +1957,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
                     if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane); }
                 } else if (LOOK && use_rec && wave == nwave - 1) {
-                    if constexpr (LOOK) pl_look_post(look, w, s, pid, maxNodes, lane, look_node);    // (beside the resolution on wave 0)
+                    if constexpr (LOOK) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, PL_LOOK_KIDS_ON_HIT != 0);    // (beside the resolution on wave 0)
                 }
                 if (LOOK && use_rec) PH_MARK(3);
                 __syncthreads();
@@ -1961,7 +2057,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
         if (tid == 0) {
             pl_write_result<PROFILE>(p, w, s, s.k_travel_ddt, s.k_dth_ddt, results, paths, max_path, pid, n_pops, (int32_t)blockIdx.x, t_fin);
-            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } }   // ([8]: records used, a diagnostic)
+            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } }   // ([8]: records used, a diagnostic)
         }
         __syncthreads();
     }

@@ -42,9 +42,11 @@ def main():
         keep[name] = (rec, paths.cpu().numpy())
         e = {"ms_per_batch": [round(t, 3) for t in ts], "ms_best": min(ts), "pops": int(rec["n_pops"].sum()), "lookahead_used": bool(bp.last_lookahead)}
         if bp._look is not None:
-            c = bp._look[:512].cpu().numpy().view(np.uint64)
-            e.update(jobs_posted=int(c[0]), records_made=int(c[24]), records_used=int(c[8]), helper_workgroups=int(c[48]),
-                     record_pop_frac=float(c[8]) / max(int(rec["n_pops"].sum()), 1), lookahead_workspace_bytes=int(bp._look.numel()))
+            c = bp._look[:1024].cpu().numpy().view(np.uint64)
+            e.update(jobs_posted=int(c[0]), children_halves_made=int(c[24]), shot_halves_made=int(c[88]), records_used=int(c[8]),
+                     helper_workgroups=int(c[48]), record_pop_frac=float(c[8]) / max(int(rec["n_pops"].sum()), 1),
+                     child_lookups={"not_posted": int(c[72]), "pending": int(c[73]), "ready": int(c[74]), "waited": int(c[75])},
+                     lookahead_workspace_bytes=int(bp._look.numel()))
         out[name] = e
     a, b = keep["without_lookahead"], keep["with_lookahead"]
     same = all(np.array_equal(a[0][f], b[0][f]) for f in a[0].dtype.names if f not in ("slot", "phase_cycles"))
@@ -64,6 +66,8 @@ def main():
     out["record_pops_of_capped_problems"] = {
         "problems": int(long_.sum()), "pops": int(pops), "record_pops": int(hits), "record_pop_frac": hits / max(pops, 1),
         "cycles_since_pop_start_per_wave": {"children_ready": [ph[long_, 16 + 5 * w + 0].sum() / max(hits, 1) for w in range(8)],
+                                            "words_done": [ph[long_, 16 + 5 * w + 1].sum() / max(hits, 1) for w in range(8)],
+                                            "shot_chain_done": [ph[long_, 16 + 5 * w + 2].sum() / max(hits, 1) for w in range(8)],
                                             "resolution_done": [ph[long_, 16 + 5 * w + 3].sum() / max(hits, 1) for w in range(8)],
                                             "end_of_pop": [ph[long_, 16 + 5 * w + 4].sum() / max(hits, 1) for w in range(8)]},
         "resolution_classify_write_push_cycles_per_pop": [ph[long_, k].sum() / pops for k in (2, 3, 10)],
