@@ -378,6 +378,7 @@ struct PlShared {
     int32_t next_cur, have_next;      // node popped ahead by wave 0 at the end of its resolution (see pl_resolve_fast_wave)
     // expansion lookahead
     unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
+    int32_t fetch_go, fetch_nheap;              // pop-ahead -> record fetch hand-over (see pl_resolve_fast_wave)
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
     int32_t use_rec, job_skip, helper_reg, n_hits, n_sec[4];
@@ -1255,8 +1256,13 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     // top of the next iteration behind two workgroup barriers (the other waves are still checking the shot). If the shot
     // then succeeds the search is over and only the open-list COUNT is reported, which the caller restores.
     if (lane == 0 && pop_ahead && s.nheap > 0) {
+        // heappop returns the root; the sift that follows only restores the heap. Publish the node first: on a record pop
+        // another wave fetches its expansion record (and waits for a pending one) while this lane walks the heap.
+        const uint32_t root = pl_heap_get(w, s, 0).node;
+        s.next_cur = (int32_t)root; s.have_next = 1; s.fetch_nheap = s.nheap - 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        *(volatile int32_t*)&s.fetch_go = 1;
         const uint32_t c = pl_heap_pop(w, s);
-        s.next_cur = (int32_t)c; s.have_next = 1;
         w.nodes[c].state = 3;
     }
     wave_sync();
@@ -1385,10 +1391,10 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
 // else loaded now. Not for the only open node: the search may end with that pop and hand back its (colliding) shot,
 // which a record does not hold.
 template <class S>
-__device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane)
+__device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int32_t nheap_after)
 {
     int ok = 0;
-    if (s.status == 0 && s.nheap >= 1 && node >= 0) {
+    if (s.status == 0 && nheap_after >= 1 && node >= 0) {
         if (node == s.pre_node && s.pre_ok) ok = 1;
         else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true);
     }
@@ -1637,7 +1643,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 } else if (look.on && wave == 0 && !ahead) {
                     // (a node popped ahead had its record fetched right behind the resolution that popped it)
                     wave_sync();
-                    pl_look_fetch(look, w, s, pid, maxNodes, s.cur, lane);
+                    pl_look_fetch(look, w, s, pid, maxNodes, s.cur, lane, s.nheap);
                 }
             }
             PH_ACC(PH_POP, t_pop); }
@@ -1685,7 +1691,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (tid == 0) {
                     const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
                     s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
-                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2;
+                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0;
                     if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
                 }
                 if (tid < nchild) {
@@ -1851,7 +1857,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     wave_sync();
                     if (can_fast) {
                         pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
-                        if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane); }
+                        if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.nheap); }
                     }
                 }
                 if (wave >= w0 && wave < w0 + nw) {
@@ -1955,7 +1961,20 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (!tried && can_fast) {
                 if (wave == 0) {
                     pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
-                    if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane); }
+                    if constexpr (LOOK) if (look.on) {
+                        wave_sync();
+                        if (use_rec) { if (lane == 0 && *(volatile int32_t*)&s.fetch_go == 0) *(volatile int32_t*)&s.fetch_go = 2; }   // (nothing popped ahead: release wave 1)
+                        else if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.nheap);
+                    }
+                } else if (LOOK && use_rec && wave == 1) {
+                    // record pop: the other waves are idle, so this one fetches the next node's record as soon as wave 0
+                    // knows that node (before it sifts the heap), and does the bounded wait for a pending record
+                    if constexpr (LOOK) {
+                        if (lane == 0) while (*(volatile int32_t*)&s.fetch_go == 0) __builtin_amdgcn_s_sleep(2);
+                        wave_sync();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (*(volatile int32_t*)&s.fetch_go == 1) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.fetch_nheap);
+                    }
                 } else if (LOOK && use_rec && wave == nwave - 1) {
                     if constexpr (LOOK) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, PL_LOOK_KIDS_ON_HIT != 0);    // (beside the resolution on wave 0)
                 }
