@@ -354,8 +354,20 @@ def main():
             rl["wait_frac"] = pk.get("wait_any_frac")
             try:      # per-pop critical path of the capped problems, from the instrumented kernel (scripts/variant_bench.py)
                 rl["cycles_per_pop"] = json.load(open(os.path.join(ROOT, "profiles", "r02_plan_kernel_phase_cycles.json")))["cyc_per_pop"]
+                rl["cycles_per_pop_note"] = "the long way (no expansion record), instrumented kernel without lookahead"
             except Exception:
                 rl["cycles_per_pop"] = None
+            try:      # ... and with the expansion lookahead (scripts/look_bench.py): record pops of the capped searches
+                lk = json.load(open(os.path.join(ROOT, "profiles", "r02_lookahead.json")))
+                if lk.get("source_hash") == source_hash():
+                    rp = lk["record_pops_of_capped_problems"]
+                    rl["record_pop_frac"] = rp["record_pop_frac"]
+                    rl["cycles_per_record_pop"] = max(rp["cycles_since_pop_start_per_wave"]["end_of_pop"])
+                    # average over record pops and long pops: the long-way figure scaled by the measured launch-time ratio
+                    if rl["cycles_per_pop"]:
+                        rl["cycles_per_pop_with_lookahead"] = rl["cycles_per_pop"] * lk["with_lookahead"]["ms_best"] / lk["without_lookahead"]["ms_best"]
+            except Exception:
+                pass
             rl["pmc_source"] = "profiles/r02_pmc_summary.json (source hash %s)" % pmc["source_hash"]
         elif pmc and pmc.get("stale"):
             rl["pmc_source"] = "profiles/r02_pmc_summary.json is STALE (kernel sources changed): PMC-derived fields left null"
