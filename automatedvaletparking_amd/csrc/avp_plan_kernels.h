@@ -379,6 +379,7 @@ struct PlShared {
     // expansion lookahead
     unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
     int32_t fetch_go, fetch_nheap;              // pop-ahead -> record fetch hand-over (see pl_resolve_fast_wave)
+    int32_t wr_go, wr_done;                     // classification -> writer wave hand-over
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
     int32_t use_rec, job_skip, helper_reg, n_hits, n_sec[4];
@@ -1142,8 +1143,11 @@ __device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // s.fast (preset to 1) reports whether the pop was resolved here; when it is 0 nothing has been modified.
 template <bool PROFILE, class S>
 AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const PlanWs& w, S& s, const PlanDims& dims,
-                                const PlNode& cn, int nchild, bool pop_ahead)
+                                const PlNode& cn, int nchild, bool pop_ahead, bool split = false)
 {
+    // split (plan_kernel's record pops, where the other waves are idle): the heuristic distances were read ahead by
+    // another wave (c.pre_d), and the node / hash writes are handed to a writer wave (pl_resolve_writer_wave) that runs
+    // beside the heap pushes of this one.
     const long long t_r0 = PH_NOW();
     // Per-child state stays in the registers of the child's lane; the order dependent parts read it with ballots
     // and shuffles -- the serial sections below would otherwise spend most of their time on LDS round trips.
@@ -1152,7 +1156,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     double cg = 0.0, ch_ = 0.0, cf = 0.0, cx = 0.0, cy = 0.0, cth = 0.0;
     if (lane < nchild) {
         PlChild& c = s.child[lane];
-        c.pre_d = pl_id_in_range(m, c.id) ? w.dist[c.id] : PL_UNSEEN;
+        if (!split) c.pre_d = pl_id_in_range(m, c.id) ? w.dist[c.id] : PL_UNSEEN;
         found = c.found; first_coll = c.first_coll; cx = c.x; cy = c.y; cth = c.th;
         const int is_forward = lane < p.n_steer ? 1 : 0;
         const bool found_closed = found >= 0 && c.found_state == 2;
@@ -1198,7 +1202,12 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         s.n_rs += __popcll(m_rs);
     }
     const int32_t gidx = (int32_t)s.global_index, cur = s.cur;
-    if (cls == CL_NEW_CLOSED || cls == CL_NEW_OPEN) {
+    if (split) {
+        if (lane < nchild) { PlChild& c = s.child[lane]; c.cls = cls; c.pos = pos; c.g = cg; c.h = ch_; c.f = cf; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wave_sync();
+        if (lane == 0) *(volatile int32_t*)&s.wr_go = 1;
+    } else if (cls == CL_NEW_CLOSED || cls == CL_NEW_OPEN) {
         const bool open = cls == CL_NEW_OPEN;
         PlNode& nd = w.nodes[pos];
         nd.x = cx; nd.y = cy; nd.th = cth;
@@ -1208,7 +1217,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         nd.state = open ? 1 : 2; nd.heap_pos = -1;
         pl_hash_put_atomic(w, dims.hashCap, pos, cx, cy, cth);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (!split) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     wave_sync();
     const long long t_r2 = PH_NOW();
     // heap pushes / in-place improvements in child order; the operands come from the children's lanes, every push is
@@ -1255,6 +1264,12 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
     // Pop ahead: the open list is final for this pop, so lane 0 takes the next node off it right away instead of at the
     // top of the next iteration behind two workgroup barriers (the other waves are still checking the shot). If the shot
     // then succeeds the search is over and only the open-list COUNT is reported, which the caller restores.
+    if (split) {
+        // the popped node may be one of this pop's children: its record must be complete before its state is touched
+        if (lane == 0) while (*(volatile int32_t*)&s.wr_done == 0) __builtin_amdgcn_s_sleep(1);
+        wave_sync();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     if (lane == 0 && pop_ahead && s.nheap > 0) {
         // heappop returns the root; the sift that follows only restores the heap. Publish the node first: on a record pop
         // another wave fetches its expansion record (and waits for a pending one) while this lane walks the heap.
@@ -1273,6 +1288,37 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
 // pid straight to global memory (no local copy of the struct: its dynamically indexed arrays would be a stack object).
 // The counts and the RS fields are filled whether or not the caller asked for way-points (paths == NULL).
 // k_travel_ddt / k_dth_ddt: the LDS copies of the motion-primitive constants.
+// The writer wave of a split resolution (see pl_resolve_fast_wave): once wave 0 has classified the children it creates
+// the new nodes (arena records, pose hash) while wave 0 pushes them onto the heap. The two touch different bytes of a node
+// record (the pushes its heap_pos), and wave 0 waits for wr_done before it may pop one of these nodes ahead.
+template <class S>
+AVP_D void pl_resolve_writer_wave(const avp_params& p, const PlanWs& w, S& s, const PlanDims& dims, const PlNode& cn, int nchild)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) while (*(volatile int32_t*)&s.wr_go == 0) __builtin_amdgcn_s_sleep(1);
+    wave_sync();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (*(volatile int32_t*)&s.wr_go == 1) {
+        if (lane < nchild) {
+            const PlChild& c = s.child[lane];
+            if (c.cls == CL_NEW_CLOSED || c.cls == CL_NEW_OPEN) {
+                const bool open = c.cls == CL_NEW_OPEN;
+                PlNode& nd = w.nodes[c.pos];
+                nd.x = c.x; nd.y = c.y; nd.th = c.th;
+                nd.g = open ? c.g : 0.0; nd.h = open ? c.h : 0.0; nd.f = open ? c.f : 0.0;
+                nd.index = (int32_t)s.global_index + lane + 1; nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                nd.forward = (int8_t)(lane < p.n_steer ? 1 : 0); nd.steer_i = (int8_t)(lane % p.n_steer);
+                nd.state = open ? 1 : 2;
+                if (!open) nd.heap_pos = -1;              // (an open node's heap_pos belongs to the push on wave 0)
+                pl_hash_put_atomic(w, dims.hashCap, c.pos, c.x, c.y, c.th);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    wave_sync();
+    if (lane == 0) *(volatile int32_t*)&s.wr_done = 1;
+}
+
 template <bool PROFILE, class S>
 AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const double* k_travel_ddt, const double (*k_dth_ddt)[4],
                            avp_plan_result_dev* __restrict__ results, double* __restrict__ paths, int32_t max_path, int64_t pid,
@@ -1688,10 +1734,15 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
                 const unsigned long long* rec = s.recb[s.rec_cur];
                 if constexpr (LOOK) if (wave == 1) pl_look_prefetch(look, w, s, pid, maxNodes, lane);
+                if (wave == 2 && lane < nchild) {
+                    // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
+                    const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
+                    s.child[lane].pre_d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
+                }
                 if (tid == 0) {
                     const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
                     s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
-                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0;
+                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
                     if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
                 }
                 if (tid < nchild) {
@@ -1960,10 +2011,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
             if (!tried && can_fast) {
                 if (wave == 0) {
-                    pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
+                    pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops, LOOK && use_rec);
                     if constexpr (LOOK) if (look.on) {
                         wave_sync();
-                        if (use_rec) { if (lane == 0 && *(volatile int32_t*)&s.fetch_go == 0) *(volatile int32_t*)&s.fetch_go = 2; }   // (nothing popped ahead: release wave 1)
+                        if (use_rec) {       // (resolution left early / nothing popped ahead: release the writer and the fetcher)
+                            if (lane == 0 && *(volatile int32_t*)&s.wr_go == 0) *(volatile int32_t*)&s.wr_go = 2;
+                            if (lane == 0 && *(volatile int32_t*)&s.fetch_go == 0) *(volatile int32_t*)&s.fetch_go = 2;
+                        }
                         else if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.nheap);
                     }
                 } else if (LOOK && use_rec && wave == 1) {
@@ -1975,6 +2029,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         if (*(volatile int32_t*)&s.fetch_go == 1) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.fetch_nheap);
                     }
+                } else if (LOOK && use_rec && wave == 2) {
+                    pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
                 } else if (LOOK && use_rec && wave == nwave - 1) {
                     if constexpr (LOOK) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, PL_LOOK_KIDS_ON_HIT != 0);    // (beside the resolution on wave 0)
                 }

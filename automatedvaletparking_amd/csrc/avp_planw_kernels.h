@@ -105,6 +105,7 @@ struct PwShared {
     uint32_t chk_hit[PW_MAXCHILD * 4];
     static constexpr int RS_CAP = PW_RS_CAP;
     int32_t fetch_go, fetch_nheap;             // (written by the shared pl_resolve_fast_wave; read by plan_kernel's lookahead only)
+    int32_t wr_go, wr_done;
     static constexpr bool HEAP_POS = true;
     static constexpr int HEAP_LDS = 0;         // (no LDS heap top in the wave form: the whole open list stays in the workspace)
     __device__ __forceinline__ PlWaveChk& wave_chk() { return wchk1; }
