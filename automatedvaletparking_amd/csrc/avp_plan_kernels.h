@@ -170,7 +170,10 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 #define PL_LOOK_SLEEP 64                // s_sleep argument of a helper waiting for its job (x 64 cycles; 16 .. 127 measured alike)
 #endif
 #define PL_LOOK_HRS (pl_al((size_t)PL_RS_CAP * 3 * 8) + pl_al((size_t)PL_RS_CAP))   // sample scratch of a helper-only workgroup
-#define PL_LOOK_KIDS 3                // child records per node: same gear, steering index -1 / 0 / +1 from the node's own
+#ifndef PL_LOOK_KSPAN
+#define PL_LOOK_KSPAN 1                // the children posted ahead steer within this many steps of their parent
+#endif
+#define PL_LOOK_KIDS (2 * PL_LOOK_KSPAN + 1)   // child records per node: same gear, steering index -1 / 0 / +1 from the node's own
 #ifndef PL_LOOK_KIDS_ON_HIT
 #define PL_LOOK_KIDS_ON_HIT 0         // post the likely children on record pops too (they then need PL_LOOK_WAIT to be of use)
 #endif
@@ -207,7 +210,7 @@ static inline __host__ __device__ size_t pl_look_bytes(int64_t n, int32_t maxNod
 __device__ __forceinline__ size_t pl_look_idx(int64_t pid, int32_t maxNodes, int64_t node, int slot) { return ((size_t)pid * maxNodes + (size_t)node) * (1 + PL_LOOK_KIDS) + slot; }
 #define PL_JOB_NODE(w0) ((uint32_t)((w0) & 0xffffffffull))
 #define PL_JOB_PID(w0) ((int64_t)(((w0) >> 32) & 0xfffffull))
-#define PL_JOB_SLOT(w0) ((int)(((w0) >> 52) & 3ull))
+#define PL_JOB_SLOT(w0) ((int)(((w0) >> 52) & 15ull))
 // agent-scope relaxed accesses (sc1): payload stores, s_waitcnt vmcnt(0), flag store on the producer side; flag load,
 // then payload loads on the consumer side
 __device__ __forceinline__ unsigned long long pl_ld64(const unsigned long long* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1401,8 +1404,8 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
                 if (nn.parent_pos >= 0) {
                     const PlNode& pp = w.nodes[nn.parent_pos];
                     const int d = (int)nn.steer_i - (int)pp.steer_i;
-                    if (pp.steer_i >= 0 && nn.forward == pp.forward && d >= -1 && d <= 1) {
-                        ri = pl_look_idx(pid, maxNodes, nn.parent_pos, 2 + d);
+                    if (pp.steer_i >= 0 && nn.forward == pp.forward && d >= -PL_LOOK_KSPAN && d <= PL_LOOK_KSPAN) {
+                        ri = pl_look_idx(pid, maxNodes, nn.parent_pos, 1 + PL_LOOK_KSPAN + d);
                         st = pl_ld32(look.state + ri);
                         s.n_sec[(st & 6u) == 6u ? 2 : (st & 1u)] += 1;
                     }
@@ -1503,10 +1506,10 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     unsigned long long c = 0;
     if (lane < 5) c = pl_ld64(look.ctrl + (lane == 0 ? 48 : lane == 1 ? 0 : lane == 2 ? 16 : lane == 3 ? 64 : 80));
     // candidates: does the slot have a job already?
-    const int d = lane - 33, sc = (int)cn.steer_i + d;
+    const int d = lane - 32 - PL_LOOK_KSPAN, sc = (int)cn.steer_i + d;
     const bool kid = kids && lane >= 32 && lane < 32 + PL_LOOK_KIDS && cn.steer_i >= 0 && sc >= 0 && sc < p.n_steer;
     const bool cand = lane < 32 && node != 0xffffffffu;
-    const size_t si = kid ? pl_look_idx(pid, maxNodes, s.cur, 2 + d) : pl_look_idx(pid, maxNodes, cand ? node : 0, 0);
+    const size_t si = kid ? pl_look_idx(pid, maxNodes, s.cur, 1 + PL_LOOK_KSPAN + d) : pl_look_idx(pid, maxNodes, cand ? node : 0, 0);
     bool want = false;
     if (kid || cand) want = pl_ld32(look.state + si) == 0u;
     const unsigned long long helpers = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
@@ -1524,7 +1527,7 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
             avp_sincos(th, sth, cth);
             x = cn.x + travel * cth;
             y = cn.y + travel * sth;
-            w0 = (unsigned long long)(uint32_t)s.cur | ((unsigned long long)pid << 32) | ((unsigned long long)(2 + d) << 52);
+            w0 = (unsigned long long)(uint32_t)s.cur | ((unsigned long long)pid << 32) | ((unsigned long long)(1 + PL_LOOK_KSPAN + d) << 52);
         } else {
             const PlNode& nd = w.nodes[node];
             x = nd.x; y = nd.y; th = nd.th;
