@@ -383,6 +383,7 @@ struct PlShared {
     unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
     int32_t fetch_go, fetch_nheap;              // pop-ahead -> record fetch hand-over (see pl_resolve_fast_wave)
     int32_t wr_go, wr_done;                     // classification -> writer wave hand-over
+    int32_t look_calm, look_live;               // as of the last posting round: helpers alive and at most PL_LOOK_BACKLOG jobs waiting / helpers alive
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
     int32_t use_rec, job_skip, helper_reg, n_hits, n_sec[4];
@@ -1411,7 +1412,7 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
                     }
                 }
             }
-            if (PL_LOOK_WAIT > 0 && wait && (st & 1u) && (st & 6u) != 6u) {
+            if (PL_LOOK_WAIT > 0 && wait && s.look_calm && (st & 1u) && (st & 6u) != 6u) {
                 const long long t0 = clock64();
                 while ((st & 6u) != 6u && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = pl_ld32(look.state + ri); }
                 s.n_sec[3] += 1;
@@ -1443,7 +1444,7 @@ template <class S>
 __device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int32_t nheap_after)
 {
     int ok = 0;
-    if (s.status == 0 && nheap_after >= 1 && node >= 0) {
+    if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
         if (node == s.pre_node && s.pre_ok) ok = 1;
         else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true);
     }
@@ -1457,7 +1458,7 @@ template <class S>
 __device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane)
 {
     int32_t node = -1;
-    if (s.nheap >= 2) node = (int32_t)pl_heap_get(w, s, 0).node;      // (with one open node left the record would not be used)
+    if (s.look_live && s.nheap >= 2) node = (int32_t)pl_heap_get(w, s, 0).node;      // (with one open node left the record would not be used)
     const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, false);
     if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
 }
@@ -1514,6 +1515,7 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     if (kid || cand) want = pl_ld32(look.state + si) == 0u;
     const unsigned long long helpers = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
     const long long backlog = max((long long)(ta - ha), (long long)(tb - hb));
+    if (lane == 0) { s.look_calm = (helpers != 0 && backlog <= PL_LOOK_BACKLOG) ? 1 : 0; s.look_live = helpers != 0 ? 1 : 0; }   // (calm: the helpers keep up, a pending record is worth a short wait)
     if (helpers == 0 || backlog > PL_JCAP - 4096) return;       // nobody to serve / a ring is full
     if (backlog > PL_LOOK_BACKLOG && lane >= 32) want = false;
     double x = 0.0, y = 0.0, th = 0.0;
@@ -1560,7 +1562,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         w.rsdir = (int8_t*)(look.hrs + (size_t)((int32_t)blockIdx.x - look.main_blocks) * PL_LOOK_HRS + pl_al((size_t)PL_RS_CAP * 3 * 8));
     }
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.look_calm = 0; s.look_live = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll

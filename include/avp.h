@@ -211,7 +211,7 @@ int32_t avp_plan_slots(avp_map* map, int32_t mode);
  * pops the node. The record store takes n x max_nodes x 4 x 708 bytes. Whether a record exists changes the time of a pop, never its result
  * (tests/test_gpu_lookahead.py: bit-identical records, paths and traces with and without).
  * avp_plan_look_bytes: bytes of the lookahead workspace for a batch of n (0 = the library would not use one: mode 2
- * batch, more than 16 children). The helpers occupy every CU their launch leaves free until its last problem is done:
+ * batch, more than two problems per CU, more than 16 children). The helpers occupy every CU their launch leaves free until its last problem is done:
  * meant for a launch that has the device to itself, not for several concurrent launches on different streams.
  *
  * Problem order. The persistent workgroups (waves) take problems off a counter; when the batch is larger than the chip the

@@ -19,7 +19,7 @@ def _pairs(m, dm, n, seed):
     return free[0:2 * n:2], free[1:2 * n:2]
 
 
-@pytest.mark.parametrize("n", [1, 5, 40, 256, 300, 1100])
+@pytest.mark.parametrize("n", [1, 5, 40, 256, 300, 512])
 def test_lookahead_changes_no_result(vehicle, cfg, n):
     from automatedvaletparking_amd import _native, path_planner
     m = case_map_from_gold(1)
@@ -64,7 +64,7 @@ def test_lookahead_not_used_for_large_batches(vehicle, cfg):
     L = _native.lib()
     ncu = int(L.avp_plan_slots(dm.h, C.c_int32(1)))
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu), C.c_int32(4096))) > 0
-    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(32 * ncu - 1), C.c_int32(4096))) > 0      # the tail of a large workgroup-form batch
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu + 1), C.c_int32(4096))) == 0       # every CU busy with its own problems
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(32 * ncu), C.c_int32(4096))) == 0          # wave form: no helpers
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(64 * ncu), C.c_int32(4096))) == 0
 
