@@ -383,6 +383,7 @@ struct PlShared {
     unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
     int32_t fetch_go, fetch_nheap;              // pop-ahead -> record fetch hand-over (see pl_resolve_fast_wave)
     int32_t wr_go, wr_done;                     // classification -> writer wave hand-over
+    int32_t nf_node, nf_found[16]; int8_t nf_state[16];   // the popped-ahead node's children: pose-hash look-ups done by the fetching wave
     int32_t look_calm, look_live;               // as of the last posting round: helpers alive and at most PL_LOOK_BACKLOG jobs waiting / helpers alive
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
@@ -1441,7 +1442,8 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
 // else loaded now. Not for the only open node: the search may end with that pop and hand back its (colliding) shot,
 // which a record does not hold.
 template <class S>
-__device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int32_t nheap_after)
+__device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int32_t nheap_after,
+                                              int64_t hashCap = 0, int nchild = 0, bool lookups = false)
 {
     int ok = 0;
     if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
@@ -1451,14 +1453,35 @@ __device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& 
     wave_sync();
     if (lane == 0) { s.use_rec = ok; s.n_hits += ok; if (ok) s.rec_cur ^= 1; s.pre_node = -1; s.pre_ok = 0; }
     wave_sync();
+    if (lookups && ok) {
+        // (record pop, fetching wave) This pop creates no more nodes -- the writer wave is done before the pop-ahead that
+        // named `node` --, so the pose-hash look-ups of the NEXT pop's children are final now: do them here, beside the
+        // heap sift on wave 0, instead of at the start of that pop. Two states move until then and are set as they will
+        // be: the node being expanded now will be closed, the popped node is marked as such.
+        const unsigned long long* rec = s.recb[s.rec_cur];
+        if (lane < nchild) {
+            const int32_t f = pl_hash_find(w, hashCap, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]), pl_unbits(rec[32 + lane]));
+            int st = f >= 0 ? w.nodes[f].state : 0;
+            if (f == s.cur) st = 2;
+            if (f == node) st = 3;
+            s.nf_found[lane] = f; s.nf_state[lane] = (int8_t)st;
+        }
+        if (lane == 0) s.nf_node = node;
+        wave_sync();
+    }
 }
 // Ahead of that: while the pop is busy elsewhere, an otherwise idle wave copies the record of the node on top of the open
 // list -- the next pop's node unless a child of this one beats it.
 template <class S>
-__device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane)
+__device__ __forceinline__ int32_t pl_look_prefetch_node(const PlanWs& w, S& s)       // (reads the heap: while nobody changes it)
 {
     int32_t node = -1;
     if (s.look_live && s.nheap >= 2) node = (int32_t)pl_heap_get(w, s, 0).node;      // (with one open node left the record would not be used)
+    return node;
+}
+template <class S>
+__device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane, int32_t node)
+{
     const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, false);
     if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
 }
@@ -1623,7 +1646,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         for (int64_t i = tid; i < dims.hashCap; i += PL_THREADS) w.hash[i] = 0;
         if (tid == 0) {
             s.status = 0; s.done = 0;
-            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
+            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1; s.nf_node = -1;
             s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
             for (int k = 0; k < PH_COUNT; k++) s.phase[k] = 0;
             s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
@@ -1735,10 +1758,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const bool in_radius = distance < p.flag_radius;
             bool can_fast = false;
             long long t_f = 0;
+            int32_t pre_cand = -1;
             if (use_rec) {
                 // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
                 const unsigned long long* rec = s.recb[s.rec_cur];
-                if constexpr (LOOK) if (wave == 1) pl_look_prefetch(look, w, s, pid, maxNodes, lane);
+                if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s);      // (its record is fetched beside the resolution)
+                const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
                 if (wave == 2 && lane < nchild) {
                     // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
                     const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
@@ -1754,8 +1779,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     PlChild& c = s.child[tid];
                     c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
                     c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
-                    c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
-                    c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
+                    if (nf) { c.found = s.nf_found[tid]; c.found_state = s.nf_state[tid]; }
+                    else {
+                        c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
+                        c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
+                    }
                     c.id = avp_pos_to_index(m, c.x, c.y);
                     c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
                     c.rs_err = (int8_t)(rec[64 + tid] >> 32);
@@ -1792,7 +1820,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             } else if (one_pass && tid == PL_THREADS - 2 && !hC) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nq_all) pl_rs_build_schedule(s, nq_all);
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
-            if constexpr (LOOK) if (!helper && look.on && wave == 0) pl_look_prefetch(look, w, s, pid, maxNodes, lane);   // (wave 0 idles until the sub-step checks are done)
+            if constexpr (LOOK) if (!helper && look.on && wave == 0) pl_look_prefetch(look, w, s, pid, maxNodes, lane, pl_look_prefetch_node(w, s));   // (wave 0 idles until the sub-step checks are done)
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
             const int nsubs = nchild * p.n_sub;
@@ -2029,10 +2057,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     // record pop: the other waves are idle, so this one fetches the next node's record as soon as wave 0
                     // knows that node (before it sifts the heap), and does the bounded wait for a pending record
                     if constexpr (LOOK) {
+                        pl_look_prefetch(look, w, s, pid, maxNodes, lane, pre_cand);
                         if (lane == 0) while (*(volatile int32_t*)&s.fetch_go == 0) __builtin_amdgcn_s_sleep(2);
                         wave_sync();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        if (*(volatile int32_t*)&s.fetch_go == 1) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.fetch_nheap);
+                        if (*(volatile int32_t*)&s.fetch_go == 1) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.fetch_nheap, dims.hashCap, nchild, true);
                     }
                 } else if (LOOK && use_rec && wave == 2) {
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
