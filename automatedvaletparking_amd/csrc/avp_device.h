@@ -52,10 +52,10 @@ struct Footprint {
 
 // Footprint corners: world = R(theta).local + (x, y), the 2x2 product rounded the way the
 // reference's BLAS call rounds it: acc = a0*b0; acc = fma(a1, b1, acc)  (numerics).
-AVP_HD void avp_footprint_setup(const avp_params& p, double x, double y, double th, Footprint& f)
+// (the parameter block is any struct with the members fp_xr, fp_xf, fp_yr, fp_yl: avp_params or the planner's LDS copy)
+template <class P>
+AVP_HD void avp_footprint_setup_cs(const P& p, double x, double y, double cs, double sn, Footprint& f)
 {
-    double cs, sn;
-    avp_sincos(th, sn, cs);
     const double lx[4] = { p.fp_xr, p.fp_xf, p.fp_xf, p.fp_xr };
     const double ly[4] = { p.fp_yr, p.fp_yr, p.fp_yl, p.fp_yl };
 #pragma unroll
@@ -75,6 +75,12 @@ AVP_HD void avp_footprint_setup(const avp_params& p, double x, double y, double 
         f.den[i] = sqrt(1 + f.k[i] * f.k[i]);
     }
     f.pad0 = f.pad1 = 0.0;
+}
+AVP_HD void avp_footprint_setup(const avp_params& p, double x, double y, double th, Footprint& f)
+{
+    double cs, sn;
+    avp_sincos(th, sn, cs);
+    avp_footprint_setup_cs(p, x, y, cs, sn, f);
 }
 
 // AABB of the 4 corners (collision_check.py:49-52)

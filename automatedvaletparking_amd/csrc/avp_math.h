@@ -321,8 +321,9 @@ AVP_HD double avp_hypot(double a, double b)
 }
 
 // ---- index searches on an ascending node table (map_position of map/costmap.py) ---------------------
+// (PT: any pointer to const double -- plain, or LDS-qualified in the planner's called collision passes)
 // First node index i with A[i] >= v (A ascending, n entries): exact against the table, any v.
-AVP_HD int avp_first_ge(const double* A, int n, double a0, double pitch, double v)
+template <class PT> AVP_HD int avp_first_ge(PT A, int n, double a0, double pitch, double v)
 {
     double g = floor((v - a0) / pitch);
     int i = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);
@@ -331,7 +332,7 @@ AVP_HD int avp_first_ge(const double* A, int n, double a0, double pitch, double 
     return i;
 }
 // Last node index i with A[i] <= v, or -1.
-AVP_HD int avp_last_le(const double* A, int n, double a0, double pitch, double v)
+template <class PT> AVP_HD int avp_last_le(PT A, int n, double a0, double pitch, double v)
 {
     double g = floor((v - a0) / pitch);
     int i = !(g >= 0.0) ? -1 : (g >= (double)n ? n - 1 : (int)g);
@@ -340,7 +341,7 @@ AVP_HD int avp_last_le(const double* A, int n, double a0, double pitch, double v
     return i;
 }
 // strict versions for the two-circle checker's exclusive filter (collision_check.py:119-127)
-AVP_HD int avp_first_gt(const double* A, int n, double a0, double pitch, double v)
+template <class PT> AVP_HD int avp_first_gt(PT A, int n, double a0, double pitch, double v)
 {
     double g = floor((v - a0) / pitch);
     int i = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);
@@ -348,7 +349,7 @@ AVP_HD int avp_first_gt(const double* A, int n, double a0, double pitch, double 
     while (i < n && !(A[i] > v)) ++i;
     return i;
 }
-AVP_HD int avp_last_lt(const double* A, int n, double a0, double pitch, double v)
+template <class PT> AVP_HD int avp_last_lt(PT A, int n, double a0, double pitch, double v)
 {
     double g = floor((v - a0) / pitch);
     int i = !(g >= 0.0) ? -1 : (g >= (double)n ? n - 1 : (int)g);
@@ -359,7 +360,7 @@ AVP_HD int avp_last_lt(const double* A, int n, double a0, double pitch, double v
 
 // first_ge (upper = false) / last_le (upper = true) as ONE instruction stream, so that lanes searching different
 // bounds of different axes do not diverge (same results as avp_first_ge / avp_last_le for finite v)
-AVP_HD int avp_node_search(const double* A, int n, double a0, double pitch, double v, bool upper)
+template <class PT> AVP_HD int avp_node_search(PT A, int n, double a0, double pitch, double v, bool upper)
 {
     const double g = floor((v - a0) / pitch) + (upper ? 1.0 : 0.0);
     int c = !(g >= 0.0) ? 0 : (g >= (double)n ? n : (int)g);          // estimate of #{A[i] < v} resp. #{A[i] <= v}

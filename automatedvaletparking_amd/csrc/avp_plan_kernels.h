@@ -220,31 +220,68 @@ __device__ __forceinline__ void pl_st32(uint32_t* q, uint32_t v) { __hip_atomic_
 __device__ __forceinline__ unsigned long long pl_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ double pl_unbits(unsigned long long v) { return __longlong_as_double((long long)v); }
 
-// ---- lane-per-pose collision test through the column bitmaps (reads L1/L2-resident tables) -----
-__device__ __forceinline__ bool pl_check_pose(const DevMap& m, const avp_params& p, double x, double y, double th)
+// ---- what a collision pass reads of the map and the vehicle: one copy per workgroup in LDS ------------
+// The passes are CALLED functions (pl_check_pass below): everything they need travels as three LDS addresses, so no
+// kernel argument has to be handed through registers or the stack, and their register demand is their own.
+#define AVP_LDS __attribute__((address_space(3)))
+// register budget of plan_wave_kernel and of the functions it calls (the attribute propagates): 512 / PW_WAVES_PER_EU per lane
+#ifndef PW_WAVES_PER_EU
+#define PW_WAVES_PER_EU 2
+#endif
+#define PW_OCC __attribute__((amdgpu_waves_per_eu(PW_WAVES_PER_EU, PW_WAVES_PER_EU)))
+struct PlChkEnv {
+    int32_t nx, ny, wpc, kind;                        // kind: avp_params.checker_kind
+    double b0, dx, b2, dy;
+    double fp_xr, fp_xf, fp_yr, fp_yl;                // inflated footprint (map/costmap.py:97-101)
+    double circ_rd, circ_cf, circ_cr;                 // two-circle model (collision_check.py:92-98)
+    uint32_t lX, lY, lBits, pad;                      // LDS addresses of the staged tables (STAGE)
+    const double* gX; const double* gY; const uint64_t* gBits;   // ... or the tables in HBM / L2
+};
+// the map tables as a collision pass reads them: LDS copies (STAGE) or through L1 / L2
+template <bool STAGE> struct PlTabs;
+template <> struct PlTabs<true> {
+    AVP_LDS const double* X; AVP_LDS const double* Y; AVP_LDS const uint64_t* bits;
+    __device__ __forceinline__ PlTabs(const PlChkEnv& e) : X((AVP_LDS const double*)(uintptr_t)e.lX), Y((AVP_LDS const double*)(uintptr_t)e.lY), bits((AVP_LDS const uint64_t*)(uintptr_t)e.lBits) {}
+};
+template <> struct PlTabs<false> {
+    const double* X; const double* Y; const uint64_t* bits;
+    __device__ __forceinline__ PlTabs(const PlChkEnv& e) : X(e.gX), Y(e.gY), bits(e.gBits) {}
+};
+__device__ __forceinline__ void pl_chk_env_fill(PlChkEnv& e, const DevMap& m, const avp_params& p, const void* lX, const void* lY, const void* lBits)
 {
-    if (p.checker_kind == 1) {
-        double cs, sn;
-        avp_sincos(th, sn, cs);
-        const double Rd = p.circ_rd;
-        const double fx = x + p.circ_cf * cs, fy = y + p.circ_cf * sn;
-        const double rx = x + p.circ_cr * cs, ry = y + p.circ_cr * sn;
+    e.nx = m.nx; e.ny = m.ny; e.wpc = m.wpc; e.kind = p.checker_kind;
+    e.b0 = m.b0; e.dx = m.dx; e.b2 = m.b2; e.dy = m.dy;
+    e.fp_xr = p.fp_xr; e.fp_xf = p.fp_xf; e.fp_yr = p.fp_yr; e.fp_yl = p.fp_yl;
+    e.circ_rd = p.circ_rd; e.circ_cf = p.circ_cf; e.circ_cr = p.circ_cr;
+    e.lX = lX ? (uint32_t)(uintptr_t)(AVP_LDS const void*)lX : 0u; e.lY = lY ? (uint32_t)(uintptr_t)(AVP_LDS const void*)lY : 0u;
+    e.lBits = lBits ? (uint32_t)(uintptr_t)(AVP_LDS const void*)lBits : 0u; e.pad = 0;
+    e.gX = m.X; e.gY = m.Y; e.gBits = m.colBits;
+}
+
+// ---- lane-per-pose collision test through the column bitmaps (the fallback of a pass; the two-circle model) -----
+template <class TX, class TB>
+__device__ __forceinline__ bool pl_check_pose(const PlChkEnv& e, TX X, TX Y, TB colBits, double x, double y, double th, double cs, double sn)
+{
+    if (e.kind == 1) {
+        const double Rd = e.circ_rd;
+        const double fx = x + e.circ_cf * cs, fy = y + e.circ_cf * sn;
+        const double rx = x + e.circ_cr * cs, ry = y + e.circ_cr * sn;
         double right, left, upper, down;
         if (fx >= rx) { right = fx + Rd; left = rx - Rd; } else { right = rx + Rd; left = fx - Rd; }
         if (fy >= ry) { upper = fy + Rd; down = ry - Rd; } else { upper = ry + Rd; down = fy - Rd; }
-        const int ixlo = avp_first_gt(m.X, m.nx, m.b0, m.dx, left), ixhi = avp_last_lt(m.X, m.nx, m.b0, m.dx, right);
-        const int iylo = avp_first_gt(m.Y, m.ny, m.b2, m.dy, down), iyhi = avp_last_lt(m.Y, m.ny, m.b2, m.dy, upper);
+        const int ixlo = avp_first_gt(X, e.nx, e.b0, e.dx, left), ixhi = avp_last_lt(X, e.nx, e.b0, e.dx, right);
+        const int iylo = avp_first_gt(Y, e.ny, e.b2, e.dy, down), iyhi = avp_last_lt(Y, e.ny, e.b2, e.dy, upper);
         if (iylo > iyhi) return false;
         for (int ix = ixlo; ix <= ixhi; ix++) {
-            const double px = m.X[ix];
+            const double px = X[ix];
             for (int w = iylo >> 6; w <= (iyhi >> 6); w++) {
-                uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+                uint64_t bits = colBits[(size_t)ix * e.wpc + w];
                 if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
                 if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
                 while (bits) {
                     const int bpos = __ffsll((unsigned long long)bits) - 1;
                     bits &= bits - 1;
-                    const double py = m.Y[(w << 6) + bpos];
+                    const double py = Y[(w << 6) + bpos];
                     const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
                     if (sqrt(d0x * d0x + d0y * d0y) <= Rd) return true;
                     if (sqrt(d1x * d1x + d1y * d1y) <= Rd) return true;
@@ -254,22 +291,22 @@ __device__ __forceinline__ bool pl_check_pose(const DevMap& m, const avp_params&
         return false;
     }
     Footprint f;
-    avp_footprint_setup(p, x, y, th, f);
+    avp_footprint_setup_cs(e, x, y, cs, sn, f);
     double xmin, xmax, ymin, ymax;
     avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
-    const int ixlo = avp_first_ge(m.X, m.nx, m.b0, m.dx, xmin), ixhi = avp_last_le(m.X, m.nx, m.b0, m.dx, xmax);
-    const int iylo = avp_first_ge(m.Y, m.ny, m.b2, m.dy, ymin), iyhi = avp_last_le(m.Y, m.ny, m.b2, m.dy, ymax);
+    const int ixlo = avp_first_ge(X, e.nx, e.b0, e.dx, xmin), ixhi = avp_last_le(X, e.nx, e.b0, e.dx, xmax);
+    const int iylo = avp_first_ge(Y, e.ny, e.b2, e.dy, ymin), iyhi = avp_last_le(Y, e.ny, e.b2, e.dy, ymax);
     if (iylo > iyhi) return false;
     for (int ix = ixlo; ix <= ixhi; ix++) {
-        const double px = m.X[ix];
+        const double px = X[ix];
         for (int w = iylo >> 6; w <= (iyhi >> 6); w++) {
-            uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+            uint64_t bits = colBits[(size_t)ix * e.wpc + w];
             if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
             if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
             while (bits) {
                 const int bpos = __ffsll((unsigned long long)bits) - 1;
                 bits &= bits - 1;
-                if (avp_footprint_point_hit(f, px, m.Y[(w << 6) + bpos])) return true;
+                if (avp_footprint_point_hit(f, px, Y[(w << 6) + bpos])) return true;
             }
         }
     }
@@ -307,13 +344,17 @@ struct MapTabs { const double* X; const double* Y; const uint64_t* bits; };
 #ifndef PL_WQCAP
 #define PL_WQCAP (PL_THREADS >= 512 ? 1024 : 512)   // (pose, point) candidates per wave; more fall back to the lane-per-pose walk
 #endif
-struct PlWaveChk {
+template <int QCAP>
+struct PlWaveChkT {
+    static constexpr int WQCAP = QCAP;
     Footprint fp[PL_WPOSE];
     int16_t rng[PL_WPOSE][4];         // ixlo, ixhi, iylo, iyhi
     uint32_t hit[PL_WPOSE];
+    double pose[PL_WPOSE][5];         // x, y, theta, cos, sin of the poses of the pass (staged by the caller)
     int32_t qn, over;
-    uint32_t q[PL_WQCAP];             // pose << 24 | ix << 12 | iy   (nx, ny < 4096 on this path)
+    uint32_t q[QCAP];                 // pose << 24 | ix << 12 | iy   (nx, ny < 4096 on this path)
 };
+typedef PlWaveChkT<PL_WQCAP> PlWaveChk;
 
 struct PlShared {
     // lattice / id space (compute_h.py lattice anchored at the goal)
@@ -342,6 +383,7 @@ struct PlShared {
     unsigned long long fold_key[PL_THREADS / 64];   // per-wave scratch of pl_rs_fold_wave
     int32_t fold_idx[PL_THREADS / 64];
     MapTabs mt;                       // the map tables as the kernel sees them (LDS copies when staged)
+    PlChkEnv env;                     // what the called collision passes read of the map and the vehicle
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
@@ -1008,32 +1050,34 @@ AVP_D void pl_rs_sample_world(const PlanWs& w, S& s, const avp_params& p, const 
 // ---- wave-local cooperative collision pass (distance_checker semantics, collision_check.py:144-240) ----
 // One wave checks up to PL_WPOSE poses without any workgroup barrier: lanes set up the footprints, one
 // lane per (pose, map column under the AABB) gathers the near obstacle points from the column bitmaps into
-// the wave's LDS queue, one lane per (pose, point) runs the exact test. pose(k, x, y, th) supplies pose k of
-// this wave's chunk; hit flags are returned through out_hit[k] (LDS).
-template <bool PROFILE = false, class S, typename PoseFn>
-AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p, S& s, int count, PoseFn pose, uint32_t* out_hit, bool probe = false)
+// the wave's LDS queue, one lane per (pose, point) runs the exact test.
+// pl_check_pass is a CALLED function: the poses (x, y, theta, cos, sin) are staged in wc.pose[] by the caller
+// (pl_check_wave below), the map / vehicle constants come from the workgroup's PlChkEnv, the hit flags go to
+// out_hit[k] (LDS). Its registers are its own -- inlined into the pop loops (twice per kernel) it set their
+// register demand.
+template <bool STAGE, int QCAP>
+__device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp, int count, AVP_LDS uint32_t* out_hit_p)
 {
-    const long long t_c0 = PH_NOW();
+    const PlChkEnv& env = *(const PlChkEnv*)envp;
+    PlWaveChkT<QCAP>& wc = *(PlWaveChkT<QCAP>*)wcp;
+    uint32_t* out_hit = (uint32_t*)out_hit_p;
+    const PlTabs<STAGE> mt(env);
     const int lane = threadIdx.x & 63;
-    PlWaveChk& wc = s.wave_chk();
-    if (count <= 0) return;
-    if (p.checker_kind == 1) {
-        if (lane < count) { double x, y, th, cs, sn; pose(lane, x, y, th, cs, sn); out_hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
+    if (env.kind == 1) {
+        if (lane < count) out_hit[lane] = pl_check_pose(env, mt.X, mt.Y, mt.bits, wc.pose[lane][0], wc.pose[lane][1], wc.pose[lane][2], wc.pose[lane][3], wc.pose[lane][4]) ? 1u : 0u;
         wave_sync();
         return;
     }
-    if (lane == 0) { wc.qn = 0; wc.over = 0; }
-    // Footprint set-up, 8 lanes per pose: every lane of a group evaluates the pose and the corners, then the
-    // group's lanes split what is data parallel: 4 edges (slope / intercept / norm: the divisions and square
-    // roots), 2 side lengths, and the 4 index searches (2 code paths x 2 axes). Same arithmetic per value as
-    // avp_footprint_setup / avp_footprint_aabb -- only who computes it changes.
+    // Footprint set-up, 8 lanes per pose: every lane of a group evaluates the corners, then the group's lanes split
+    // what is data parallel: 4 edges (slope / intercept / norm: the divisions and square roots), 2 side lengths, and
+    // the 4 index searches (2 code paths x 2 axes). Same arithmetic per value as avp_footprint_setup /
+    // avp_footprint_aabb -- only who computes it changes.
     {
         const int grp = lane >> 3, sub = lane & 7;
         if (grp < count) {
-            double x, y, th, cs, sn;
-            pose(grp, x, y, th, cs, sn);                  // cs, sn = cos / sin of th (the pose's own, not recomputed)
-            const double lx[4] = { p.fp_xr, p.fp_xf, p.fp_xf, p.fp_xr };
-            const double ly[4] = { p.fp_yr, p.fp_yr, p.fp_yl, p.fp_yl };
+            const double x = wc.pose[grp][0], y = wc.pose[grp][1], cs = wc.pose[grp][3], sn = wc.pose[grp][4];
+            const double lx[4] = { env.fp_xr, env.fp_xf, env.fp_xf, env.fp_xr };
+            const double ly[4] = { env.fp_yr, env.fp_yr, env.fp_yl, env.fp_yl };
             double cx[4], cy[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -1069,71 +1113,96 @@ AVP_D void pl_check_wave(const DevMap& m, const MapTabs& mt, const avp_params& p
             if (sub < 4) {
                 // ixlo = first node >= xmin, ixhi = last node <= xmax, iylo, iyhi likewise: one code path for the four
                 const bool ax = sub < 2, upper = sub & 1;
-                wc.rng[grp][sub] = (int16_t)avp_node_search(ax ? mt.X : mt.Y, ax ? m.nx : m.ny, ax ? m.b0 : m.b2, ax ? m.dx : m.dy,
+                wc.rng[grp][sub] = (int16_t)avp_node_search(ax ? mt.X : mt.Y, ax ? env.nx : env.ny, ax ? env.b0 : env.b2, ax ? env.dx : env.dy,
                                                             ax ? (upper ? xmax : xmin) : (upper ? ymax : ymin), upper);
             }
             if (sub == 7) wc.hit[grp] = 0;
         }
     }
     wave_sync();
-    if (PROFILE && probe && lane == 0) PH_X(0, t_c0);
-    // Gather: lane c owns map column ixlo + c of EVERY pose of the pass. All bitmap words of the lane are fetched first
-    // (their LDS latencies overlap), the lane reserves queue room for all its candidates with ONE atomic, then writes them
-    // -- one LDS round trip and one atomic per pass instead of one of each per pose.
-    {
-        uint64_t b0[PL_WPOSE], b1[PL_WPOSE];
-        int tot = 0;
-        bool wide = false;
-#pragma unroll
-        for (int i = 0; i < PL_WPOSE; i++) {
-            b0[i] = 0; b1[i] = 0;
-            if (i < count) {
-                const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
-                if (iylo <= iyhi && lane <= ixhi - ixlo) {
-                    const int ix = ixlo + lane, w0 = iylo >> 6, w1 = iyhi >> 6;
-                    if (w1 - w0 > 1) wide = true;                 // (cannot happen under avp_plan_batch's guard; handled by the fallback)
-                    uint64_t x0 = mt.bits[(size_t)ix * m.wpc + w0] & (~0ull << (iylo & 63));
-                    if (w1 == w0) x0 &= ~0ull >> (63 - (iyhi & 63));
-                    const uint64_t x1 = w1 > w0 ? (mt.bits[(size_t)ix * m.wpc + w1] & (~0ull >> (63 - (iyhi & 63)))) : 0ull;
-                    b0[i] = x0; b1[i] = x1;
-                    tot += __popcll(x0) + __popcll(x1);
-                }
-            }
-        }
-        int pos = tot ? atomicAdd(&wc.qn, tot) : 0;
-        if (wide || pos + tot > PL_WQCAP) { if (tot || wide) wc.over = 1; }
-        else {
+    // Gather: lane c owns map column ixlo + c of EVERY pose of the range. The lane counts the candidates of all its
+    // (pose, column) pairs first (the bitmap words are fetched together: their LDS latencies overlap), reserves queue
+    // room for them with ONE atomic, then walks the words again and writes them -- one atomic per range instead of
+    // one per pose, and no per-pose words kept in registers between the two walks. The range is the whole pass; when
+    // its candidates do not fit the queue it is halved (dense clutter), down to single poses.
+    const int wpc = env.wpc;
+    int lo = 0, span = count;
+    while (lo < count) {
+        const int hi = min(lo + span, count);
+        if (lane == 0) { wc.qn = 0; wc.over = 0; }
+        wave_sync();
+        {
+            int tot = 0;
+            bool wide = false;
 #pragma unroll
             for (int i = 0; i < PL_WPOSE; i++) {
-                if (i < count && (b0[i] | b1[i])) {
-                    const int ix = wc.rng[i][0] + lane, w0 = wc.rng[i][2] >> 6;
-                    const uint32_t tag = ((uint32_t)i << 24) | ((uint32_t)ix << 12);
-                    uint64_t bits = b0[i];
-                    while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)((w0 << 6) + bpos); }
-                    bits = b1[i];
-                    while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)(((w0 + 1) << 6) + bpos); }
+                if (i >= lo && i < hi) {
+                    const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
+                    if (iylo <= iyhi && lane <= ixhi - ixlo) {
+                        const int ix = ixlo + lane, w0 = iylo >> 6, w1 = iyhi >> 6;
+                        if (w1 - w0 > 1) wide = true;                 // (cannot happen under avp_plan_batch's guard; handled by the fallback)
+                        uint64_t x0 = mt.bits[(size_t)ix * wpc + w0] & (~0ull << (iylo & 63));
+                        if (w1 == w0) x0 &= ~0ull >> (63 - (iyhi & 63));
+                        const uint64_t x1 = w1 > w0 ? (mt.bits[(size_t)ix * wpc + w1] & (~0ull >> (63 - (iyhi & 63)))) : 0ull;
+                        tot += __popcll(x0) + __popcll(x1);
+                    }
+                }
+            }
+            int pos = tot ? atomicAdd(&wc.qn, tot) : 0;
+            if (wide || pos + tot > QCAP) { if (tot || wide) wc.over = 1; }
+            else if (tot) {
+#pragma nounroll
+                for (int i = lo; i < hi; i++) {
+                    const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
+                    if (iylo <= iyhi && lane <= ixhi - ixlo) {
+                        const int ix = ixlo + lane, w0 = iylo >> 6, w1 = iyhi >> 6;
+                        uint64_t bits = mt.bits[(size_t)ix * wpc + w0] & (~0ull << (iylo & 63));
+                        if (w1 == w0) bits &= ~0ull >> (63 - (iyhi & 63));
+                        const uint32_t tag = ((uint32_t)i << 24) | ((uint32_t)ix << 12);
+                        while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)((w0 << 6) + bpos); }
+                        bits = w1 > w0 ? (mt.bits[(size_t)ix * wpc + w1] & (~0ull >> (63 - (iyhi & 63)))) : 0ull;
+                        while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)(((w0 + 1) << 6) + bpos); }
+                    }
                 }
             }
         }
-    }
-    wave_sync();
-    if (PROFILE && probe && lane == 0) PH_X(1, t_c0);
-    if (wc.over) {
-        // more candidates than the queue holds (dense clutter): every lane checks its own pose serially
-        if (lane < count) { double x, y, th, cs, sn; pose(lane, x, y, th, cs, sn); wc.hit[lane] = pl_check_pose(m, p, x, y, th) ? 1u : 0u; }
-    } else {
-        const int qn = wc.qn;
-        for (int e = lane; e < qn; e += 64) {
-            const uint32_t ent = wc.q[e];
-            const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
-            if (wc.hit[i]) continue;
-            if (avp_footprint_point_hit(wc.fp[i], mt.X[ix], mt.Y[iy])) wc.hit[i] = 1;
+        wave_sync();
+        if (wc.over) {
+            if (hi - lo > 1) { span = (hi - lo + 1) >> 1; continue; }
+            // one pose with more candidates than the queue holds: a lane walks its columns serially
+            if (lane == lo) wc.hit[lane] = pl_check_pose(env, mt.X, mt.Y, mt.bits, wc.pose[lane][0], wc.pose[lane][1], wc.pose[lane][2], wc.pose[lane][3], wc.pose[lane][4]) ? 1u : 0u;
+        } else {
+            const int qn = wc.qn;
+            for (int e = lane; e < qn; e += 64) {
+                const uint32_t ent = wc.q[e];
+                const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
+                if (wc.hit[i]) continue;
+                if (avp_footprint_point_hit(wc.fp[i], mt.X[ix], mt.Y[iy])) wc.hit[i] = 1;
+            }
         }
+        wave_sync();
+        lo = hi;
     }
-    wave_sync();
     if (lane < count) out_hit[lane] = wc.hit[lane];
     wave_sync();
-    if (PROFILE && probe && lane == 0) PH_X(2, t_c0);
+}
+
+// The caller's side of a pass: pose(k, x, y, th, cs, sn) supplies pose k of this wave's chunk (cs, sn = cos / sin of
+// th: the pose's own); lane k evaluates it and stages it for the pass. out_hit: LDS.
+template <bool STAGE, class S, typename PoseFn>
+AVP_D void pl_check_wave(const PlChkEnv& env, S& s, int count, PoseFn pose, uint32_t* out_hit)
+{
+    if (count <= 0) return;
+    const int lane = threadIdx.x & 63;
+    auto& wc = s.wave_chk();
+    constexpr int QCAP = std::remove_reference<decltype(wc)>::type::WQCAP;
+    if (lane < count) {
+        double x, y, th, cs, sn;
+        pose(lane, x, y, th, cs, sn);
+        wc.pose[lane][0] = x; wc.pose[lane][1] = y; wc.pose[lane][2] = th; wc.pose[lane][3] = cs; wc.pose[lane][4] = sn;
+    }
+    wave_sync();
+    pl_check_pass<STAGE, QCAP>((AVP_LDS const PlChkEnv*)&env, (AVP_LDS PlWaveChkT<QCAP>*)&wc, count, (AVP_LDS uint32_t*)out_hit);
 }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits until every global store of the wave
@@ -1610,7 +1679,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         mt.X = lx; mt.Y = ly; mt.bits = lb;
         __syncthreads();
     } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
-    if (tid == 0) s.mt = mt;
+    if (tid == 0) { s.mt = mt; pl_chk_env_fill(s.env, m, p, STAGE ? mt.X : nullptr, STAGE ? mt.Y : nullptr, STAGE ? mt.bits : nullptr); }
     const int nchild = 2 * p.n_steer;
     const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
 
@@ -1830,7 +1899,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (wave >= 1 && wave <= nw && !hS) {
                     for (int base = (wave - 1) * per; base < nsubs; base += nw * per) {
                         const int cnt = min(per, nsubs - base);
-                        pl_check_wave<PROFILE>(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+                        pl_check_wave<STAGE>(s.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             const int t = base + k;
                             const int ci = s.sub_child[t], j = s.sub_j[t], si = s.sub_steer[t];
                             const double td = ci < p.n_steer ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
@@ -1838,7 +1907,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             avp_sincos(th, sn, cs);
                             x = cn.x + td * cs;
                             y = cn.y + td * sn;
-                        }, &s.chk_hit[base], wave == 1);
+                        }, &s.chk_hit[base]);
                     }
                 }
             }
@@ -1952,10 +2021,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         double tx = 0.0, ty = 0.0, tth = 0.0;
                         const int mine = base + lane * stride;
                         if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
-                        // lane k holds pose k: broadcast it to whichever lanes ask for it
+                        // lane k holds pose k and stages it for the pass
                         uint32_t* hits = &s.wave_chk().hit[0];
-                        pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
-                            x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
+                        pl_check_wave<STAGE>(s.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+                            x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
                             avp_sincos(th, sn, cs);
                         }, hits);
                         if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);

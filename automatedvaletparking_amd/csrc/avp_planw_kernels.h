@@ -24,12 +24,25 @@
 #pragma once
 #include "avp_plan_kernels.h"
 
-#define PW_WAVES 8
+#ifndef PW_WAVES
+#define PW_WAVES 8                    // problems (waves) per workgroup = per CU
+#endif
 #define PW_THREADS (64 * PW_WAVES)
+#ifndef PW_RS_CAP
 #define PW_RS_CAP 256                 // samples of one RS shot held per wave
+#endif
+#ifndef PW_WQCAP
+#define PW_WQCAP 1024                 // (pose, point) candidates of one collision pass; more fall back to the lane-per-pose walk
+#endif
 #define PW_MAXCHILD 16
 #define PW_RSQ (PW_MAXCHILD + 1)      // RS queries per pop: the shot + the children
 #define AVP_PLAN_RETRY 100            // internal: plan this problem with plan_kernel (never returned to the caller)
+// phase timers of the instrumented instantiation (avp_plan_batch_ex, mode 2 | 0x100), written to phase_cycles[0 ..]:
+// per-problem set-up, heap pop, children poses + hash look-ups + frames, sub-step collision passes, Reeds-Shepp
+// evaluation, the shot (origins, samples, collision passes), the wave-parallel resolution, the serial resolution with
+// its sweep extensions, the result record; [9] the number of collision passes, [10] of RS rounds
+enum { PW_PH_INIT = 0, PW_PH_POP, PW_PH_CHILD, PW_PH_SUB, PW_PH_RS, PW_PH_SHOT, PW_PH_RESOLVE, PW_PH_SLOW, PW_PH_FINISH, PW_PH_NPASS, PW_PH_NROUND, PW_PH_COUNT = 12 };
+#define PW_T(k) do { if constexpr (PROFILE) { if (lane == 0) { const long long t_ = clock64(); s.phase[k] += (uint32_t)(t_ - t_ph); t_ph = t_; } } } while (0)
 
 // Words of one solver group in lane order: the members of a set_path type group are adjacent and aligned to the group
 // size (1, 2 or 4), the groups of a query are adjacent, queries follow each other: item = query * L + j.
@@ -54,11 +67,21 @@ static __device__ const int8_t PW_ITEM_M[46] = { 0, 0,  0, 1, 0, 1,  0, 1, 0, 1,
                                                  0, 1, 0, 1, 0, 1, 0, 1,  0, 1, 0, 1, 0, 1, 0, 1,  0, 1, 0, 1 };
 
 // Constants every wave of the workgroup reads (LDS): the lane-indexed members of avp_params (a dynamically indexed
-// by-value kernel argument would be copied to every lane's scratch) and the sub-step index tables.
+// by-value kernel argument would be copied to every lane's scratch), the sub-step index tables, and COPIES of the
+// kernel's arguments -- the phases of a pop are called functions (below) that take two LDS addresses, nothing else.
 struct PwCommon {
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];
     int8_t sub_child[PW_MAXCHILD * 4], sub_j[PW_MAXCHILD * 4], sub_steer[PW_MAXCHILD * 4];
     int8_t item_word[46], item_g[46], item_m[46], sg_l[8], sg_shift[8], sg_off[8], sg_gmax[8];
+    PlChkEnv env;                     // what the called collision passes read of the map and the vehicle
+    DevMap m;
+    avp_params p;
+    PlanDims dims;
+    const double* starts; const double* goals;
+    avp_plan_result_dev* results;
+    double* paths; double* trace;
+    int32_t max_path, max_trace, maxNodes, nchild, nsubs, pad;
+    int64_t max_pops;
 };
 
 // State of one problem = one wave (LDS). Field names follow PlShared where the shared device functions read them.
@@ -88,38 +111,57 @@ struct PwShared {
     int32_t next_child, need_sweep, have_d, fast;
     int64_t pending_id;
     int32_t next_cur, have_next;
+    // per wave, set once / per pop
+    PlanWs w;                                  // this wave's workspace slot
+    int32_t slot, can_fast;
+    int64_t n_pops;
+    PlNode cn;                                 // the node being expanded (copy of its arena record)
+    int32_t nq, rsq[PW_RSQ];                   // the Reeds-Shepp queries of this pop: 0 = the shot, 1 + i = child i
     PlChild child[PW_MAXCHILD];
-    // Reeds-Shepp: frames, running best per query, round scratch
-    RsFrame frame[PW_RSQ];
-    unsigned long long bestL[PW_RSQ], tmpL[PW_RSQ];
-    int32_t bestW[PW_RSQ], tmpW[PW_RSQ];
-    double best_l[PW_RSQ][AVP_RS_MAXSEG];
-    uint8_t w_err[PW_RSQ];
     // shot sampling
     int32_t smp_hi, smp_point_num;
     double smp_l[PW_RS_CAP];
     int8_t smp_seg[PW_RS_CAP];
     double seg_o[AVP_RS_MAXSEG][3];
-    // collision passes
-    PlWaveChk wchk1;
     uint32_t chk_hit[PW_MAXCHILD * 4];
+    // Scratch of the two kinds of phases that never overlap in a pop: the Reeds-Shepp evaluation (pw_ph_rs: its results
+    // are copied to child[].L / rs before it returns) and the collision passes (their results go to chk_hit / rs_first_coll).
+    union {
+        struct {
+            RsFrame frame[PW_RSQ];                       // frames, running best per query, round scratch (indexed by position in rsq)
+            unsigned long long bestL[PW_RSQ], tmpL[PW_RSQ];
+            int32_t bestW[PW_RSQ], tmpW[PW_RSQ];
+            double best_l[PW_RSQ][AVP_RS_MAXSEG];
+            uint8_t w_err[PW_RSQ];
+        };
+        PlWaveChkT<PW_WQCAP> wchk1;
+    };
     static constexpr int RS_CAP = PW_RS_CAP;
     int32_t fetch_go, fetch_nheap;             // (written by the shared pl_resolve_fast_wave; read by plan_kernel's lookahead only)
     int32_t wr_go, wr_done;
     static constexpr bool HEAP_POS = true;
     static constexpr int HEAP_LDS = 0;         // (no LDS heap top in the wave form: the whole open list stays in the workspace)
-    __device__ __forceinline__ PlWaveChk& wave_chk() { return wchk1; }
+    uint32_t phase[PW_PH_COUNT];               // instrumented instantiation only: shader cycles per phase (lane 0)
+    __device__ __forceinline__ PlWaveChkT<PW_WQCAP>& wave_chk() { return wchk1; }
 };
 
 static inline __host__ __device__ size_t pw_lds_waves_offset() { return (sizeof(PwCommon) + 15) & ~(size_t)15; }
 static inline __host__ __device__ size_t pw_lds_wave_stride() { return (sizeof(PwShared) + 15) & ~(size_t)15; }
 static inline __host__ __device__ size_t pw_lds_tables_offset() { return pw_lds_waves_offset() + PW_WAVES * pw_lds_wave_stride(); }
 
-// Reeds-Shepp optimal paths of queries [0, nq) of this wave (s.frame[q] set): calc_optimal_path's result per query in
-// s.bestW / s.best_l / s.w_err. Whole wave.
-AVP_D void pw_rs_eval(PwShared& s, const PwCommon& c, const avp_params& p, int nq)
+// Every phase of a pop is a CALLED function on (this wave's state, the workgroup's constants), both in LDS: the
+// register demand of a phase is its own (fully inlined, the pop loop held the union of all of them: 256 VGPRs plus
+// spills, two waves per SIMD), and nothing but two LDS addresses crosses a call.
+#define PW_PHASE_ARGS AVP_LDS PwShared* sp, AVP_LDS const PwCommon* cp
+#define PW_PHASE_REFS PwShared& s = *(PwShared*)sp; const PwCommon& c = *(const PwCommon*)cp; const int lane = threadIdx.x & 63; (void)lane
+
+// Reeds-Shepp optimal paths of the queries s.rsq[0 .. s.nq) of this wave (s.frame[k] set): calc_optimal_path's result
+// per query in s.bestW / s.best_l / s.w_err. Whole wave.
+__device__ __noinline__ void pw_rs_eval(PW_PHASE_ARGS)
 {
-    const int lane = threadIdx.x & 63;
+    PW_PHASE_REFS;
+    const int nq = s.nq;
+    const double maxc = c.p.maxc;
     if (lane < nq) { s.bestL[lane] = ~0ull; s.bestW[lane] = -1; s.w_err[lane] = 0; }
     wave_sync();
     for (int sg = 0; sg < 8; sg++) {
@@ -156,7 +198,7 @@ AVP_D void pw_rs_eval(PwShared& s, const PwCommon& c, const avp_params& p, int n
             }
             // arg-min of the round per query, then merged into the running best: smaller length, or the same length and a
             // later word (calc_optimal_path's "<=" keeps the last of equal minima in word order)
-            const double Lm = Lsum / p.maxc;
+            const double Lm = Lsum / maxc;
             const unsigned long long lb = (unsigned long long)__double_as_longlong(Lm);
             if (lane < nq) { s.tmpL[lane] = ~0ull; s.tmpW[lane] = -1; }
             wave_sync();
@@ -178,7 +220,7 @@ AVP_D void pw_rs_eval(PwShared& s, const PwCommon& c, const avp_params& p, int n
     }
 }
 
-// Result of query q as pl_rs_fold_wave returns it: 0 path in `out` (normalised lengths), 1 no candidate, 2 assertion.
+// Result of query slot q as pl_rs_fold_wave returns it: 0 path in `out` (normalised lengths), 1 no candidate, 2 assertion.
 AVP_D int pw_rs_result(const PwShared& s, int q, RsPath& out)
 {
     out.n = 0; out.L = 0;
@@ -196,8 +238,327 @@ AVP_D int pw_rs_result(const PwShared& s, int q, RsPath& out)
     return 0;
 }
 
+// ---- per-problem set-up: hybrid_a_star.__init__ (hybrid_a_star.py:72-124) ------------------------------------------
+__device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const DevMap& m = c.m;
+    const PlanWs& w = s.w;
+    const int64_t pid = s.pid;
+    const double sx = c.starts[3 * pid], sy = c.starts[3 * pid + 1], sth = c.starts[3 * pid + 2];
+    const double gx = c.goals[3 * pid], gy = c.goals[3 * pid + 1], gth = c.goals[3 * pid + 2];
+    for (int64_t i = lane; i < c.dims.hashCap; i += 64) w.hash[i] = 0;
+    if (lane == 0) {
+        s.status = (c.nchild > PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;
+        s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
+        s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0; s.n_pops = 0;
+        s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
+        s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
+        s.E = 0; s.h_cells = 0; s.h_misses = 0;
+    }
+    CoopWave::sync();
+    if (s.status == 0) pl_sweep_init<CoopWave>(m, w, s, c.dims, gx, gy);
+    if (s.status == 0) {
+        // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
+        const int64_t sid = avp_pos_to_index(m, sx, sy);
+        pl_hquery_miss<false, CoopWave>(m, w, s, sid);
+        if (lane == 0) {
+            if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
+            else {
+                PlNode& nd = w.nodes[0];
+                nd.x = sx; nd.y = sy; nd.th = avp_pi_2_pi(sth); nd.g = 0; nd.h = 0; nd.f = 0;
+                nd.index = 0; nd.parent_index = -1; nd.parent_pos = -1; nd.forward = 1; nd.steer_i = -1; nd.state = 1;
+                s.nnodes = 1;
+                pl_heap_push(w, s, 0, 0.0);
+                pl_hash_put(w, c.dims.hashCap, 0);
+            }
+        }
+        CoopWave::sync();
+    }
+}
+
+// ---- the next node (path_planner.py:68-76): popped ahead by the previous resolution, or popped now ----------------------
+__device__ __noinline__ void pw_ph_pop(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const PlanWs& w = s.w;
+    CoopWave::sync();
+    if (lane == 0) {
+        if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }
+        else if (s.nheap == 0) { s.status = 1; }
+        else if (s.n_pops >= c.max_pops) { s.status = 4; }
+        else {
+            const uint32_t cc = pl_heap_pop(w, s);
+            s.cur = (int32_t)cc;
+            w.nodes[cc].state = 3;
+        }
+    }
+    CoopWave::sync();
+    if (s.status != 0) return;
+    const PlNode cn = w.nodes[s.cur];
+    if (lane == 0) {
+        s.cn = cn;
+        const int64_t n_pops = s.n_pops;
+        if (c.trace && n_pops < c.max_trace) {
+            double* t = c.trace + ((size_t)s.pid * c.max_trace + n_pops) * PL_TRACE_W;
+            t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(c.m, cn.x, cn.y);
+            t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
+            t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : c.k_steer[cn.steer_i];
+        }
+        s.n_pops = n_pops + 1;
+    }
+    wave_sync();
+}
+
+// ---- children poses (expand_node :134-151), their exact-equality look-ups, try_reach_goal's radius test (:308-312) ----
+__device__ __noinline__ void pw_ph_children(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const DevMap& m = c.m;
+    const avp_params& p = c.p;
+    const PlanWs& w = s.w;
+    const int nchild = c.nchild;
+    const double cnx = s.cn.x, cny = s.cn.y, cnth = s.cn.th;
+    const double ddx = cnx - s.goal[0], ddy = cny - s.goal[1];
+    const double distance = sqrt(ddx * ddx + ddy * ddy);
+    const bool in_radius = distance < p.flag_radius;
+    if (lane == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
+    if (lane < nchild) {
+        PlChild& ch = s.child[lane];
+        const int si = lane % p.n_steer;
+        const bool fwd = lane < p.n_steer;
+        const double travel = fwd ? p.travel_dt : -p.travel_dt;
+        const double th_ = avp_pi_2_pi(cnth + c.k_dth_dt[si]);
+        ch.th = th_;
+        double sth_, cth_;
+        avp_sincos(th_, sth_, cth_);
+        ch.x = cnx + travel * cth_;
+        ch.y = cny + travel * sth_;
+        ch.oob = (ch.x > m.b1 || ch.x < m.b0 || ch.y > m.b3 || ch.y < m.b2) ? 1 : 0;
+        ch.found = pl_hash_find(w, c.dims.hashCap, ch.x, ch.y, ch.th);
+        ch.found_state = ch.found >= 0 ? w.nodes[ch.found].state : 0;
+        ch.id = avp_pos_to_index(m, ch.x, ch.y);
+        ch.first_coll = 0x7fffffff;
+        ch.rs_err = 0;
+        ch.L = 0;
+    }
+    wave_sync();
+}
+
+// ---- sub-step collision checks of every child (:185-204), PL_WPOSE poses per pass ------------------------------------
 template <bool STAGE>
-__global__ __launch_bounds__(PW_THREADS) void plan_wave_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
+__device__ __noinline__ void pw_ph_substeps(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const avp_params& p = c.p;
+    const int nsubs = c.nsubs;
+    const double cnx = s.cn.x, cny = s.cn.y, cnth = s.cn.th;
+    for (int base = 0; base < nsubs; base += PL_WPOSE) {
+        const int cnt = min(PL_WPOSE, nsubs - base);
+        pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+            const int t = base + k;
+            const int ci = c.sub_child[t], j = c.sub_j[t], si = c.sub_steer[t];
+            const double td = ci < p.n_steer ? c.k_travel_ddt[j] : -c.k_travel_ddt[j];
+            th = avp_pi_2_pi(cnth + c.k_dth_ddt[si][j]);
+            avp_sincos(th, sn, cs);
+            x = cnx + td * cs;
+            y = cny + td * sn;
+        }, &s.chk_hit[base]);
+    }
+    for (int t = lane; t < nsubs; t += 64)
+        if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
+    if (lane == 0) s.can_fast = (s.closed_nonempty && (s.nnodes + c.nchild <= c.maxNodes)) ? 1 : 0;
+    wave_sync();
+}
+
+// ---- Reeds-Shepp: the shot from the popped node (:326-332) and the children's lengths (:286-294) ----------------------
+// Only the queries whose result the pop can use are evaluated: the shot inside flag_radius; a child unless expand_node
+// drops it before it reaches calc_node_heuristic -- equal to a closed node or out of bounds (:155-165, once the closed
+// list is non-empty), or new and colliding (:197-204). The reference does not solve those either.
+__device__ __noinline__ void pw_ph_rs(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const avp_params& p = c.p;
+    const int nchild = c.nchild;
+    const bool in_radius = s.in_radius != 0;
+    bool need = false;
+    if (lane == 0) need = in_radius;
+    else if (lane <= nchild) {
+        const PlChild& ch = s.child[lane - 1];
+        const bool found_closed = ch.found >= 0 && ch.found_state == 2, found_open = ch.found >= 0 && ch.found_state == 1;
+        need = !(s.closed_nonempty && (found_closed || ch.oob)) && !(!found_open && ch.first_coll != 0x7fffffff);
+    }
+    const unsigned long long mk = __ballot(need);
+    const int k = __popcll(mk & ((1ull << lane) - 1ull));
+    if (need) {
+        s.rsq[k] = lane;
+        if (lane == 0) s.frame[k] = rs_frame(s.cn.x, s.cn.y, s.cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+        else { const PlChild& ch = s.child[lane - 1]; s.frame[k] = rs_frame(ch.x, ch.y, ch.th, s.goal[0], s.goal[1], s.goal[2], p.maxc); }
+    }
+    if (lane == 0) s.nq = __popcll(mk);
+    wave_sync();
+    pw_rs_eval(sp, cp);
+    if (need && lane >= 1) {
+        RsPath rp;
+        const int st = pw_rs_result(s, k, rp);
+        s.child[lane - 1].rs_err = (int8_t)st; s.child[lane - 1].L = st ? 0.0 : rp.L / p.maxc;
+    }
+    if (lane == 0 && in_radius) {
+        RsPath rp;
+        const int st = pw_rs_result(s, 0, rp);
+        s.rs_status = st;
+        if (!st) { s.rs = rp; s.n_rs += 1; pl_rs_sample_book(s, p); }
+    }
+    wave_sync();
+    if (in_radius && s.rs_status) { if (lane == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? AVP_PLAN_RETRY : 3; wave_sync(); }
+}
+
+// ---- the shot: sample in path order, check, stop at the first colliding sample (:335-345) ------------------------------
+template <bool STAGE, bool PROFILE>
+__device__ __noinline__ void pw_ph_shot(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const avp_params& p = c.p;
+    const PlanWs& w = s.w;
+    const PlNode cn = s.cn;
+    pl_rs_sample_origins(s, p);
+    wave_sync();
+    const int total = s.smp_hi + 1;
+    double cm, sm;
+    avp_sincos(-cn.th, sm, cm);
+    for (int base = 0; base < total; base += PL_WPOSE) {
+        const int cnt = min(PL_WPOSE, total - base);
+        if constexpr (PROFILE) { if (lane == 0) s.phase[PW_PH_NPASS] += 1; }
+        double tx = 0.0, ty = 0.0, tth = 0.0;
+        const int mine = base + lane;
+        if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
+        uint32_t* hits = &s.wave_chk().hit[0];
+        pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+            x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
+            avp_sincos(th, sn, cs);
+        }, hits);
+        if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
+        wave_sync();
+        // stop at the first colliding sample -- unless it may lie in the trailing px == 0.0 tail the reference pops
+        // (rs_curve.py:588-592): that is only known once every sample has been produced, so keep going then
+        if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll < s.rs_npts) break;
+    }
+    if (lane == 0) {
+        // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
+        if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
+        if (s.rs_first_coll == 0x7fffffff) { s.n_checks += s.rs_npts; s.done = 1; }
+        else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
+    }
+    wave_sync();
+}
+
+// ---- child resolution in child order (:153-232): wave-parallel when every heuristic query hits the closed frontier ------
+__device__ __noinline__ void pw_ph_resolve_fast(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const PlNode cn = s.cn;
+    pl_resolve_fast_wave<false>(c.m, c.p, s.w, s, c.dims, cn, c.nchild, s.n_pops < c.max_pops);
+    wave_sync();
+}
+// ... else lane 0 in child order, the wave extending the heuristic sweep at every miss
+__device__ __noinline__ void pw_ph_resolve_slow(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const DevMap& m = c.m;
+    const avp_params& p = c.p;
+    const PlanWs& w = s.w;
+    const int nchild = c.nchild, maxNodes = c.maxNodes;
+    for (;;) {
+        if (lane == 0) {
+            const PlNode cn = s.cn;
+            s.need_sweep = 0;
+            int i = s.next_child;
+            for (; i < nchild && s.status == 0; i++) {
+                const PlChild ch = s.child[i];
+                const int si = i % p.n_steer;
+                const int is_forward = i < p.n_steer ? 1 : 0;
+                const bool found_closed = ch.found >= 0 && ch.found_state == 2;
+                if (s.closed_nonempty && (found_closed || ch.oob)) continue;          // :155-165
+                const bool found_open = ch.found >= 0 && ch.found_state == 1;
+                if (!found_open && ch.first_coll != 0x7fffffff) {
+                    s.n_checks += ch.first_coll + 1;
+                    if (s.nnodes >= maxNodes) { s.status = 5; break; }
+                    const int32_t pos = s.nnodes++;
+                    PlNode& nd = w.nodes[pos];
+                    nd.x = ch.x; nd.y = ch.y; nd.th = ch.th; nd.g = 0; nd.h = 0; nd.f = 0;
+                    nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                    nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
+                    pl_hash_put(w, c.dims.hashCap, pos);
+                    s.nclosed++; s.closed_nonempty = 1;
+                    continue;
+                }
+                uint32_t hd;
+                if (s.have_d) { hd = s.hq_d; s.have_d = 0; }
+                else if (!pl_hquery_hit(m, s, ch.id, ch.pre_d, hd)) { s.pending_id = ch.id; s.need_sweep = 1; break; }
+                if (hd == PL_UNSEEN) { if (!found_open) s.n_checks += p.n_sub; s.status = s.qover ? 5 : 2; break; }
+                s.n_rs += 1;
+                if (ch.rs_err) { s.status = ch.rs_err == 4 ? 5 : 3; break; }
+                const double hv1 = (double)hd / 100, hv2 = ch.L;
+                const double hval = hv2 > hv1 ? hv2 : hv1;
+                if (!found_open) {
+                    s.n_checks += p.n_sub;
+                    if (s.nnodes >= maxNodes) { s.status = 5; break; }
+                    const double g = pl_node_cost(p, is_forward, ch.th, cn.th, cn.forward);
+                    const int32_t pos = s.nnodes++;
+                    PlNode& nd = w.nodes[pos];
+                    nd.x = ch.x; nd.y = ch.y; nd.th = ch.th; nd.g = g; nd.h = hval; nd.f = g + hval;
+                    nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+                    nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
+                    pl_heap_push(w, s, (uint32_t)pos, g + hval);
+                    pl_hash_put(w, c.dims.hashCap, pos);
+                } else {
+                    PlNode& chn = w.nodes[ch.found];
+                    const double new_g = pl_node_cost(p, chn.forward, chn.th, cn.th, cn.forward);
+                    const double new_f = hval + new_g;
+                    if (new_f < chn.f) {
+                        chn.f = new_f; chn.g = new_g; chn.h = hval;
+                        pl_heap_set_key(w, s, chn.heap_pos, new_f);
+                        chn.parent_index = cn.index; chn.parent_pos = s.cur;
+                        chn.forward = (int8_t)is_forward; chn.steer_i = (int8_t)si;
+                    }
+                }
+            }
+            s.next_child = i;
+        }
+        CoopWave::sync();
+        if (!s.need_sweep) break;
+        pl_hquery_miss<false, CoopWave>(m, w, s, s.pending_id);
+        if (lane == 0) s.have_d = 1;
+        if (lane < nchild) s.child[lane].pre_d = pl_id_in_range(m, s.child[lane].id) ? w.dist[s.child[lane].id] : PL_UNSEEN;
+        CoopWave::sync();
+    }
+}
+
+// ---- finish_path (:351-389) + assembly (path_planner.py:100-108) ------------------------------------------------------------
+__device__ __noinline__ void pw_ph_finish(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const avp_params& p = c.p;
+    const PlanWs& w = s.w;
+    CoopWave::sync();
+    if (s.status == 1 && s.cur >= 0 && s.in_radius && s.rs.n > 0 && s.rs_status == 0 && s.collision) {
+        // the reference hands back the last (colliding) shot when the open list runs empty (path_planner.py:100-108):
+        // the early exit of the shot's checks may have left samples unproduced
+        const PlNode cl = w.nodes[s.cur];
+        double cm, sm;
+        avp_sincos(-cl.th, sm, cm);
+        for (int i = lane; i <= s.smp_hi; i += 64) { double a, b, cc; pl_rs_sample_world(w, s, p, cl, cm, sm, i, a, b, cc); }
+        CoopWave::sync();
+    }
+    if (lane == 0) {
+        if (s.status == AVP_PLAN_RETRY) { c.results[s.pid].status = AVP_PLAN_RETRY; }
+        else pl_write_result<false>(p, w, s, c.k_travel_ddt, c.k_dth_ddt, c.results, c.paths, c.max_path, s.pid, s.n_pops, s.slot, 0ll);
+    }
+    CoopWave::sync();
+}
+
+template <bool STAGE, bool PROFILE = false>
+__global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                                const double* __restrict__ goals, int64_t n, int32_t maxNodes,
                                                                char* __restrict__ workspace, unsigned int* __restrict__ counter,
                                                                avp_plan_result_dev* __restrict__ results,
@@ -205,16 +566,25 @@ __global__ __launch_bounds__(PW_THREADS) void plan_wave_kernel(DevMap m, avp_par
                                                                double* __restrict__ trace, int32_t max_trace,
                                                                const int32_t* __restrict__ order)
 {
-    constexpr bool PROFILE = false;
     avp_lds_tables_fill<true>();
     rs_lds_tables_fill();
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
     PwCommon& c = *reinterpret_cast<PwCommon*>(pw_smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     PwShared& s = *reinterpret_cast<PwShared*>(pw_smem + pw_lds_waves_offset() + (size_t)wave * pw_lds_wave_stride());
-    const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
-    const int32_t slot = (int32_t)blockIdx.x * PW_WAVES + wave;
-    const PlanWs w = plan_carve(workspace + (size_t)slot * dims.bytes, dims);
+    AVP_LDS PwShared* const sp = (AVP_LDS PwShared*)&s;
+    AVP_LDS const PwCommon* const cp = (AVP_LDS const PwCommon*)&c;
+    {
+        const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
+        const int32_t slot = (int32_t)blockIdx.x * PW_WAVES + wave;
+        if (lane == 0) { s.w = plan_carve(workspace + (size_t)slot * dims.bytes, dims); s.slot = slot; }
+        if (tid == 0) {
+            c.m = m; c.p = p; c.dims = dims;
+            c.starts = starts; c.goals = goals; c.results = results; c.paths = paths; c.trace = trace;
+            c.max_path = max_path; c.max_trace = max_trace; c.maxNodes = maxNodes; c.nchild = 2 * p.n_steer; c.nsubs = 2 * p.n_steer * p.n_sub; c.pad = 0;
+            c.max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
         c.k_steer[k] = p.steer[k]; c.k_dth_dt[k] = p.dth_dt[k];
@@ -237,262 +607,52 @@ __global__ __launch_bounds__(PW_THREADS) void plan_wave_kernel(DevMap m, avp_par
         mt.X = lx; mt.Y = ly; mt.bits = lb;
     } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
     if (lane == 0) s.mt = mt;
+    if (tid == 0) pl_chk_env_fill(c.env, m, p, STAGE ? mt.X : nullptr, STAGE ? mt.Y : nullptr, STAGE ? mt.bits : nullptr);
     __syncthreads();                                   // the last workgroup barrier: from here on every wave is on its own
-    const int nchild = 2 * p.n_steer;
-    const int nq = nchild + 1;
-    const int nsubs = nchild * p.n_sub;
-    const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
 
     for (;;) {
         CoopWave::sync();
         if (lane == 0) { const uint32_t t = atomicAdd(counter, 1u); s.pid = (int64_t)t < n ? (order ? order[t] : (int32_t)t) : 0x7fffffff; }
         CoopWave::sync();
-        const int64_t pid = s.pid;
-        if (pid >= n) break;
-        const double sx = starts[3 * pid], sy = starts[3 * pid + 1], sth = starts[3 * pid + 2];
-        const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
-
-        // ---- init ------------------------------------------------------------------------------
-        for (int64_t i = lane; i < dims.hashCap; i += 64) w.hash[i] = 0;
-        if (lane == 0) {
-            s.status = (nchild > PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;
-            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
-            s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
-            s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
-            s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
-            s.E = 0; s.h_cells = 0; s.h_misses = 0;
-        }
-        CoopWave::sync();
-        if (s.status == 0) pl_sweep_init<CoopWave>(m, w, s, dims, gx, gy);
-        if (s.status == 0) {
-            // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
-            const int64_t sid = avp_pos_to_index(m, sx, sy);
-            pl_hquery_miss<false, CoopWave>(m, w, s, sid);
-            if (lane == 0) {
-                if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
-                else {
-                    PlNode& nd = w.nodes[0];
-                    nd.x = sx; nd.y = sy; nd.th = avp_pi_2_pi(sth); nd.g = 0; nd.h = 0; nd.f = 0;
-                    nd.index = 0; nd.parent_index = -1; nd.parent_pos = -1; nd.forward = 1; nd.steer_i = -1; nd.state = 1;
-                    s.nnodes = 1;
-                    pl_heap_push(w, s, 0, 0.0);
-                    pl_hash_put(w, dims.hashCap, 0);
-                }
-            }
-            CoopWave::sync();
-        }
-
-        int64_t n_pops = 0;
+        if (s.pid >= n) break;
+        long long t_ph = PROFILE ? clock64() : 0ll;
+        if constexpr (PROFILE) { if (lane == 0) for (int k = 0; k < PW_PH_COUNT; k++) s.phase[k] = 0; }
+        pw_ph_init(sp, cp);
+        PW_T(PW_PH_INIT);
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
         while (s.status == 0 && !s.done) {
-            CoopWave::sync();
-            if (lane == 0) {
-                if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }
-                else if (s.nheap == 0) { s.status = 1; }
-                else if (n_pops >= max_pops) { s.status = 4; }
-                else {
-                    const uint32_t cc = pl_heap_pop(w, s);
-                    s.cur = (int32_t)cc;
-                    w.nodes[cc].state = 3;
-                }
-            }
-            CoopWave::sync();
+            pw_ph_pop(sp, cp);
             if (s.status != 0) break;
-            const PlNode cn = w.nodes[s.cur];
-            if (trace && lane == 0 && n_pops < max_trace) {
-                double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
-                t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(m, cn.x, cn.y);
-                t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
-                t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : c.k_steer[cn.steer_i];
-            }
-            n_pops++;
-
-            // ---- children poses (expand_node :134-151) + try_reach_goal radius test (:308-312) ----------
-            const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
-            const double distance = sqrt(ddx * ddx + ddy * ddy);
-            const bool in_radius = distance < p.flag_radius;
-            if (lane == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
-            if (lane < nchild) {
-                PlChild& ch = s.child[lane];
-                const int si = lane % p.n_steer;
-                const bool fwd = lane < p.n_steer;
-                const double travel = fwd ? p.travel_dt : -p.travel_dt;
-                const double th_ = avp_pi_2_pi(cn.th + c.k_dth_dt[si]);
-                ch.th = th_;
-                double sth_, cth_;
-                avp_sincos(th_, sth_, cth_);
-                ch.x = cn.x + travel * cth_;
-                ch.y = cn.y + travel * sth_;
-                ch.oob = (ch.x > m.b1 || ch.x < m.b0 || ch.y > m.b3 || ch.y < m.b2) ? 1 : 0;
-                ch.found = pl_hash_find(w, dims.hashCap, ch.x, ch.y, ch.th);
-                ch.found_state = ch.found >= 0 ? w.nodes[ch.found].state : 0;
-                ch.id = avp_pos_to_index(m, ch.x, ch.y);
-                ch.first_coll = 0x7fffffff;
-                ch.rs_err = 0;
-                ch.L = 0;
-                s.frame[lane + 1] = rs_frame(ch.x, ch.y, ch.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            } else if (lane == nchild) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-            wave_sync();
-            // ---- sub-step collision checks of every child (:185-204), PL_WPOSE poses per pass ----------------
-            for (int base = 0; base < nsubs; base += PL_WPOSE) {
-                const int cnt = min(PL_WPOSE, nsubs - base);
-                pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
-                    const int t = base + k;
-                    const int ci = c.sub_child[t], j = c.sub_j[t], si = c.sub_steer[t];
-                    const double td = ci < p.n_steer ? c.k_travel_ddt[j] : -c.k_travel_ddt[j];
-                    th = avp_pi_2_pi(cn.th + c.k_dth_ddt[si][j]);
-                    avp_sincos(th, sn, cs);
-                    x = cn.x + td * cs;
-                    y = cn.y + td * sn;
-                }, &s.chk_hit[base]);
-            }
-            for (int t = lane; t < nsubs; t += 64)
-                if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
-            const bool can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
-            wave_sync();
-
-            // ---- Reeds-Shepp: query 0 = the shot from the popped node (:326-332), 1.. = children (:286-294) ----
-            pw_rs_eval(s, c, p, nq);
-            if (lane >= 1 && lane <= nchild) {
-                RsPath rp;
-                const int st = pw_rs_result(s, lane, rp);
-                s.child[lane - 1].rs_err = (int8_t)st; s.child[lane - 1].L = st ? 0.0 : rp.L / p.maxc;
-            }
-            if (lane == 0) {
-                RsPath rp;
-                const int st = pw_rs_result(s, 0, rp);
-                s.rs_status = in_radius ? st : 0;
-                if (!st) s.rs = rp;
-                if (in_radius && !st) { s.n_rs += 1; pl_rs_sample_book(s, p); }
-            }
-            wave_sync();
-            if (in_radius && s.rs_status) { if (lane == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? AVP_PLAN_RETRY : 3; wave_sync(); break; }
-
-            // ---- the shot: sample in path order, check, stop at the first colliding sample (:335-345) --------------
-            if (in_radius) {
-                pl_rs_sample_origins(s, p);
-                wave_sync();
-                const int total = s.smp_hi + 1;
-                double cm, sm;
-                avp_sincos(-cn.th, sm, cm);
-                for (int base = 0; base < total; base += PL_WPOSE) {
-                    const int cnt = min(PL_WPOSE, total - base);
-                    double tx = 0.0, ty = 0.0, tth = 0.0;
-                    const int mine = base + lane;
-                    if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
-                    uint32_t* hits = &s.wave_chk().hit[0];
-                    pl_check_wave(m, mt, p, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
-                        x = __shfl(tx, k, 64); y = __shfl(ty, k, 64); th = avp_pi_2_pi(__shfl(tth, k, 64)); /* :339 */
-                        avp_sincos(th, sn, cs);
-                    }, hits);
-                    if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
-                    wave_sync();
-                    // stop at the first colliding sample -- unless it may lie in the trailing px == 0.0 tail the reference pops
-                    // (rs_curve.py:588-592): that is only known once every sample has been produced, so keep going then
-                    if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll < s.rs_npts) break;
-                }
-                if (lane == 0) {
-                    // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
-                    if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
-                    if (s.rs_first_coll == 0x7fffffff) { s.n_checks += s.rs_npts; s.done = 1; }
-                    else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
-                }
-                wave_sync();
-            }
+            PW_T(PW_PH_POP);
+            pw_ph_children(sp, cp);
+            PW_T(PW_PH_CHILD);
+            pw_ph_substeps<STAGE>(sp, cp);
+            if constexpr (PROFILE) { if (lane == 0) s.phase[PW_PH_NPASS] += (c.nsubs + PL_WPOSE - 1) / PL_WPOSE; }
+            PW_T(PW_PH_SUB);
+            pw_ph_rs(sp, cp);
+            if constexpr (PROFILE) { if (lane == 0) s.phase[PW_PH_NROUND] += s.nq; }
+            PW_T(PW_PH_RS);
+            if (s.status != 0) break;
+            if (s.in_radius) pw_ph_shot<STAGE, PROFILE>(sp, cp);
+            PW_T(PW_PH_SHOT);
             if (s.status != 0 || s.done) break;
-
-            // ---- child resolution in child order (:153-232) ------------------------------------------------------------
-            if (lane == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = can_fast ? 1 : 0; }
-            if (!can_fast && lane < nchild) s.child[lane].pre_d = pl_id_in_range(m, s.child[lane].id) ? w.dist[s.child[lane].id] : PL_UNSEEN;
+            if (lane == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = s.can_fast; }
+            if (!s.can_fast && lane < c.nchild) s.child[lane].pre_d = pl_id_in_range(c.m, s.child[lane].id) ? s.w.dist[s.child[lane].id] : PL_UNSEEN;
             wave_sync();
-            if (can_fast) pl_resolve_fast_wave<false>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
-            wave_sync();
-            if (!s.fast) {
-                for (;;) {
-                    if (lane == 0) {
-                        s.need_sweep = 0;
-                        int i = s.next_child;
-                        for (; i < nchild && s.status == 0; i++) {
-                            const PlChild ch = s.child[i];
-                            const int si = i % p.n_steer;
-                            const int is_forward = i < p.n_steer ? 1 : 0;
-                            const bool found_closed = ch.found >= 0 && ch.found_state == 2;
-                            if (s.closed_nonempty && (found_closed || ch.oob)) continue;          // :155-165
-                            const bool found_open = ch.found >= 0 && ch.found_state == 1;
-                            if (!found_open && ch.first_coll != 0x7fffffff) {
-                                s.n_checks += ch.first_coll + 1;
-                                if (s.nnodes >= maxNodes) { s.status = 5; break; }
-                                const int32_t pos = s.nnodes++;
-                                PlNode& nd = w.nodes[pos];
-                                nd.x = ch.x; nd.y = ch.y; nd.th = ch.th; nd.g = 0; nd.h = 0; nd.f = 0;
-                                nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
-                                nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
-                                pl_hash_put(w, dims.hashCap, pos);
-                                s.nclosed++; s.closed_nonempty = 1;
-                                continue;
-                            }
-                            uint32_t hd;
-                            if (s.have_d) { hd = s.hq_d; s.have_d = 0; }
-                            else if (!pl_hquery_hit(m, s, ch.id, ch.pre_d, hd)) { s.pending_id = ch.id; s.need_sweep = 1; break; }
-                            if (hd == PL_UNSEEN) { if (!found_open) s.n_checks += p.n_sub; s.status = s.qover ? 5 : 2; break; }
-                            s.n_rs += 1;
-                            if (ch.rs_err) { s.status = ch.rs_err == 4 ? 5 : 3; break; }
-                            const double hv1 = (double)hd / 100, hv2 = ch.L;
-                            const double hval = hv2 > hv1 ? hv2 : hv1;
-                            if (!found_open) {
-                                s.n_checks += p.n_sub;
-                                if (s.nnodes >= maxNodes) { s.status = 5; break; }
-                                const double g = pl_node_cost(p, is_forward, ch.th, cn.th, cn.forward);
-                                const int32_t pos = s.nnodes++;
-                                PlNode& nd = w.nodes[pos];
-                                nd.x = ch.x; nd.y = ch.y; nd.th = ch.th; nd.g = g; nd.h = hval; nd.f = g + hval;
-                                nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
-                                nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
-                                pl_heap_push(w, s, (uint32_t)pos, g + hval);
-                                pl_hash_put(w, dims.hashCap, pos);
-                            } else {
-                                PlNode& chn = w.nodes[ch.found];
-                                const double new_g = pl_node_cost(p, chn.forward, chn.th, cn.th, cn.forward);
-                                const double new_f = hval + new_g;
-                                if (new_f < chn.f) {
-                                    chn.f = new_f; chn.g = new_g; chn.h = hval;
-                                    pl_heap_set_key(w, s, chn.heap_pos, new_f);
-                                    chn.parent_index = cn.index; chn.parent_pos = s.cur;
-                                    chn.forward = (int8_t)is_forward; chn.steer_i = (int8_t)si;
-                                }
-                            }
-                        }
-                        s.next_child = i;
-                    }
-                    CoopWave::sync();
-                    if (!s.need_sweep) break;
-                    pl_hquery_miss<false, CoopWave>(m, w, s, s.pending_id);
-                    if (lane == 0) s.have_d = 1;
-                    if (lane < nchild) s.child[lane].pre_d = pl_id_in_range(m, s.child[lane].id) ? w.dist[s.child[lane].id] : PL_UNSEEN;
-                    CoopWave::sync();
-                }
-            }
+            if (s.can_fast) pw_ph_resolve_fast(sp, cp);
+            PW_T(PW_PH_RESOLVE);
+            if (!s.fast) pw_ph_resolve_slow(sp, cp);
             if (lane == 0 && s.status == 0) {
-                w.nodes[s.cur].state = 2;
+                s.w.nodes[s.cur].state = 2;
                 s.nclosed++; s.closed_nonempty = 1;
-                s.global_index += nchild;
+                s.global_index += c.nchild;
             }
             CoopWave::sync();
+            PW_T(PW_PH_SLOW);
         }
-        CoopWave::sync();
-        if (s.status == 1 && s.cur >= 0 && s.in_radius && s.rs.n > 0 && s.rs_status == 0 && s.collision) {
-            // the reference hands back the last (colliding) shot when the open list runs empty (path_planner.py:100-108):
-            // the early exit above may have left samples unproduced
-            const PlNode cl = w.nodes[s.cur];
-            double cm, sm;
-            avp_sincos(-cl.th, sm, cm);
-            for (int i = lane; i <= s.smp_hi; i += 64) { double a, b, cc; pl_rs_sample_world(w, s, p, cl, cm, sm, i, a, b, cc); }
-            CoopWave::sync();
-        }
-        if (lane == 0) {
-            if (s.status == AVP_PLAN_RETRY) { results[pid].status = AVP_PLAN_RETRY; }
-            else pl_write_result<false>(p, w, s, c.k_travel_ddt, c.k_dth_ddt, results, paths, max_path, pid, n_pops, slot, 0ll);
-        }
+        if constexpr (PROFILE) t_ph = clock64();
+        pw_ph_finish(sp, cp);
+        if constexpr (PROFILE) { if (lane == 0 && s.status != AVP_PLAN_RETRY) { s.phase[PW_PH_FINISH] += (uint32_t)(clock64() - t_ph); for (int k = 0; k < PW_PH_COUNT; k++) results[s.pid].phase_cycles[k] = s.phase[k]; } }
         CoopWave::sync();
     }
 }

@@ -131,10 +131,11 @@ class BatchPlanner:
         self.dm.use_current_stream()
         n = starts_t.shape[0]
         L = _native.lib()
-        mode = 1 if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode)))
+        mode = (2 if self.mode == 2 else 1) if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode)))
         cap = self.n_slots if self.n_slots else int(L.avp_plan_slots(self.dm.h, C.c_int32(mode)))
-        slots = max(1, min(cap, n if mode == 1 else 8 * ((n + 7) // 8)))
-        if mode == 2 and slots < 8:
+        wg = int(L.avp_plan_wave_group())                   # problems per workgroup of the wave form
+        slots = max(1, min(cap, n if mode == 1 else wg * ((n + wg - 1) // wg)))
+        if mode == 2 and slots < wg:
             mode = 1                                        # fewer than one workgroup of slots: the workgroup form
         ws = self._workspace(slots)
         res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
@@ -150,7 +151,7 @@ class BatchPlanner:
         if self.longest_first and n > slots:
             d = ((starts_t[:, :2] - goals_t[:, :2]) ** 2).sum(1)
             order = torch.argsort(d, descending=True, stable=True).to(torch.int32)
-        if profile and look is None:
+        if profile and look is None and mode == 1:
             _native.chk(L.avp_plan_batch_profile(*args), "avp_plan_batch_profile")
         else:
             _native.chk(L.avp_plan_batch_ex(*args, C.c_int32(mode | (0x100 if profile else 0)),

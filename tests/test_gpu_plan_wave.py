@@ -64,7 +64,7 @@ def test_wave_form_auto_mode_and_slots(vehicle, cfg):
     dm = _native.DeviceMap(m, vehicle, cfg, max_pops=40)
     L = _native.lib()
     ncu = int(L.avp_plan_slots(dm.h, C.c_int32(1)))
-    assert int(L.avp_plan_slots(dm.h, C.c_int32(2))) == 8 * ncu
+    assert int(L.avp_plan_slots(dm.h, C.c_int32(2))) == int(L.avp_plan_wave_group()) * ncu
     assert int(L.avp_plan_pick_mode(dm.h, C.c_int64(32 * ncu), C.c_int32(0))) == 2 and int(L.avp_plan_pick_mode(dm.h, C.c_int64(16 * ncu), C.c_int32(0))) == 1
     rng = np.random.default_rng(8)
     b = m.boundary
