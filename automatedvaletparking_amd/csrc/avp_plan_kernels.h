@@ -623,7 +623,12 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, S& s, int col, int row, ui
     }
 }
 
-// Expand bucket s.E (all threads). Each thread handles (entry, neighbour) pairs.
+// Expand bucket s.E (all threads). The relaxations of a bucket commute (atomicMin on distances and alias keys, queue
+// order is irrelevant), so how the (entry, neighbour) pairs are dealt to the threads changes nothing but the time:
+//   workgroup: one thread per pair (a bucket is a few hundred entries: 2 .. 5 rounds of 512 pairs);
+//   wave / pair of waves: one lane per ENTRY, its eight relaxations unrolled -- the lane's loads and atomics are independent and in
+//   flight together, 8 x fewer rounds of the latency-bound loop (the sweep from the goal to the start was 9 .. 26 M
+//   cycles per problem in the wave form, an eighth of a capped search).
 template <bool PROFILE, class Coop = CoopWG, class S>
 AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
 {
@@ -634,6 +639,23 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
     const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
     const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };      // y up = row down
     const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
+    if constexpr (Coop::N <= 128) {
+        for (uint32_t e = Coop::tid(); e < cnt; e += Coop::N) {
+            const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + e];
+            const uint32_t d = (uint32_t)(ent >> 32);
+            const int64_t id = (int64_t)(ent & 0xffffffffull);
+            if (w.dist[id] != d) continue;                    // stale entry (distance was lowered later)
+            if (w.flags[id] & PL_FLAG_T) continue;            // terminator: closed but never expanded
+            const uint32_t id32 = (uint32_t)id, row_u = id32 / (uint32_t)m.S;
+            int col = (int)(id32 - row_u * (uint32_t)m.S), row = (int)row_u;
+            if (s.alias && col == 0) {
+                if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
+            }
+            atomicAdd((unsigned long long*)&s.h_cells, 1ull);
+#pragma unroll
+            for (int nbr = 0; nbr < 8; nbr++) pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
+        }
+    } else {
     for (uint32_t p = Coop::tid(); p < cnt * 8u; p += Coop::N) {
         const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + (p >> 3)];
         const int nbr = (int)(p & 7);
@@ -649,6 +671,7 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
         }
         if (nbr == 0) atomicAdd((unsigned long long*)&s.h_cells, 1ull);
         pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
+    }
     }
     Coop::sync();
     if (Coop::tid() == 0) { s.qcount[q] = 0; s.E += 1; if constexpr (PROFILE) s.phase[PH_SWEEP] += clock64() - t_sw; }

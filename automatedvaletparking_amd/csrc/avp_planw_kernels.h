@@ -1,5 +1,6 @@
-// avp_planw_kernels.h -- batched hybrid-A* planner, THROUGHPUT form: one WAVE = one (start, goal) problem, eight
-// independent problems per workgroup, persistent waves pull problems from a global counter.
+// avp_planw_kernels.h -- batched hybrid-A* planner, THROUGHPUT forms: NW waves = one (start, goal) problem (NW = 1: the
+// wave form, NW = 2: the pair form), PW_WAVES / NW independent problems per workgroup, persistent groups of waves pull
+// problems from a global counter.
 //
 // plan_kernel (avp_plan_kernels.h) spends a whole 512-thread workgroup on one problem to shorten a pop's critical
 // path; measured, its eight waves are busy 40 % of the time (the pop is a chain of dependent scalar fp64 code, every
@@ -18,6 +19,11 @@
 //     adjacent lanes: set_path's duplicate test (rs_curve.py:137-156) is a few shuffles inside the group and the
 //     running arg-min per query (:103-108, "<=": the later word wins a tie) lives in 17 x 3 LDS words -- no table of
 //     all 46 x 11 word results (the 28 KB that keep plan_kernel at one problem per CU).
+// The PAIR form (NW = 2) is the same code with the independent pieces of a pop dealt to two waves -- the collision
+// passes and the Reeds-Shepp solver rounds alternate between them, the sampler's bookkeeping runs beside the segment
+// origins -- behind a two-wave software barrier: a pop takes ~0.6 x the time of the wave form at half the problems in
+// flight, which is what a batch of a few problems per CU needs (its capped searches all run at once: their latency is
+// the launch time).
 // A shot with more than PW_RS_CAP samples (128 m of path) or a configuration with more than PW_MAXCHILD children is
 // handed back (status AVP_PLAN_RETRY, internal) and planned by plan_kernel in a second launch: results never depend
 // on the kernel that produced them.
@@ -42,7 +48,7 @@
 // evaluation, the shot (origins, samples, collision passes), the wave-parallel resolution, the serial resolution with
 // its sweep extensions, the result record; [9] the number of collision passes, [10] of RS rounds
 enum { PW_PH_INIT = 0, PW_PH_POP, PW_PH_CHILD, PW_PH_SUB, PW_PH_RS, PW_PH_SHOT, PW_PH_RESOLVE, PW_PH_SLOW, PW_PH_FINISH, PW_PH_NPASS, PW_PH_NROUND, PW_PH_COUNT = 12 };
-#define PW_T(k) do { if constexpr (PROFILE) { if (lane == 0) { const long long t_ = clock64(); s.phase[k] += (uint32_t)(t_ - t_ph); t_ph = t_; } } } while (0)
+#define PW_T(k) do { if constexpr (PROFILE) { if (gtid == 0) { const long long t_ = clock64(); s.phase[k] += (uint32_t)(t_ - t_ph); t_ph = t_; } } } while (0)
 
 // Words of one solver group in lane order: the members of a set_path type group are adjacent and aligned to the group
 // size (1, 2 or 4), the groups of a query are adjacent, queries follow each other: item = query * L + j.
@@ -84,8 +90,45 @@ struct PwCommon {
     int64_t max_pops;
 };
 
-// State of one problem = one wave (LDS). Field names follow PlShared where the shared device functions read them.
-struct PwShared {
+// The waves that cooperate on one problem. NW = 1: one wave (wave-level syncs only). NW > 1: NW adjacent waves of the
+// workgroup behind a software barrier -- a monotonic arrival counter per group and a generation count per wave in
+// static LDS (s_barrier would stop the whole workgroup: the groups are independent searches).
+__shared__ uint32_t PW_BAR_CNT[PW_WAVES];
+__shared__ uint32_t PW_BAR_GEN[PW_WAVES];
+template <int NW>
+struct PwGroup {
+    static constexpr int N = 64 * NW;
+    static __device__ __forceinline__ int tid() { return threadIdx.x & (N - 1); }
+    static __device__ __forceinline__ int wv() { return (threadIdx.x >> 6) & (NW - 1); }
+    // lanes of the group hand data to each other through LDS and through global memory (queues, arena): both must have landed
+    static __device__ __forceinline__ void sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if constexpr (NW > 1) {
+            if ((threadIdx.x & 63) == 0) {
+                const int wave = threadIdx.x >> 6, grp = wave & ~(NW - 1);
+                const uint32_t g = PW_BAR_GEN[wave] + 1u;
+                PW_BAR_GEN[wave] = g;
+                atomicAdd(&PW_BAR_CNT[grp], 1u);
+                while (*(volatile uint32_t*)&PW_BAR_CNT[grp] < g * (uint32_t)NW) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        wave_sync();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+// Reeds-Shepp evaluation scratch of one wave: running best per query (indexed by position in rsq), round scratch
+struct PwRsBest {
+    unsigned long long bestL[PW_RSQ], tmpL[PW_RSQ];
+    int32_t bestW[PW_RSQ], tmpW[PW_RSQ];
+    double best_l[PW_RSQ][AVP_RS_MAXSEG];
+    uint8_t w_err[PW_RSQ];
+};
+
+// State of one problem = one group of NW waves (LDS). Field names follow PlShared where the shared device functions read them.
+template <int NW>
+struct PwSharedT {
     // lattice / id space and sweep (pl_sweep_init, pl_relax, pl_expand_bucket, pl_hquery_*)
     int32_t col0, row0, colMin, colMax, rowMin, rowMax, orow0, alias;
     int64_t goal_id;
@@ -111,9 +154,9 @@ struct PwShared {
     int32_t next_child, need_sweep, have_d, fast;
     int64_t pending_id;
     int32_t next_cur, have_next;
-    // per wave, set once / per pop
-    PlanWs w;                                  // this wave's workspace slot
-    int32_t slot, can_fast;
+    // per group, set once / per pop
+    PlanWs w;                                  // this group's workspace slot
+    int32_t slot, can_fast, n_passes, n_todo;
     int64_t n_pops;
     PlNode cn;                                 // the node being expanded (copy of its arena record)
     int32_t nq, rsq[PW_RSQ];                   // the Reeds-Shepp queries of this pop: 0 = the shot, 1 + i = child i
@@ -123,51 +166,54 @@ struct PwShared {
     double smp_l[PW_RS_CAP];
     int8_t smp_seg[PW_RS_CAP];
     double seg_o[AVP_RS_MAXSEG][3];
-    uint32_t chk_hit[PW_MAXCHILD * 4];
+    int8_t sub_t[PW_MAXCHILD * 4];             // the sub-step poses to check this pop (pose index = child * n_sub + step)
     // Scratch of the two kinds of phases that never overlap in a pop: the Reeds-Shepp evaluation (pw_ph_rs: its results
-    // are copied to child[].L / rs before it returns) and the collision passes (their results go to chk_hit / rs_first_coll).
+    // are copied to child[].L / rs before it returns) and the collision passes (their results go to first_coll / rs_first_coll).
     union {
         struct {
-            RsFrame frame[PW_RSQ];                       // frames, running best per query, round scratch (indexed by position in rsq)
-            unsigned long long bestL[PW_RSQ], tmpL[PW_RSQ];
-            int32_t bestW[PW_RSQ], tmpW[PW_RSQ];
-            double best_l[PW_RSQ][AVP_RS_MAXSEG];
-            uint8_t w_err[PW_RSQ];
+            RsFrame frame[PW_RSQ];
+            PwRsBest rb[NW];
         };
-        PlWaveChkT<PW_WQCAP> wchk1;
+        PlWaveChkT<PW_WQCAP> wchk[NW];
     };
     static constexpr int RS_CAP = PW_RS_CAP;
     int32_t fetch_go, fetch_nheap;             // (written by the shared pl_resolve_fast_wave; read by plan_kernel's lookahead only)
     int32_t wr_go, wr_done;
     static constexpr bool HEAP_POS = true;
-    static constexpr int HEAP_LDS = 0;         // (no LDS heap top in the wave form: the whole open list stays in the workspace)
+    static constexpr int HEAP_LDS = 0;         // (no LDS heap top in these forms: the whole open list stays in the workspace)
     uint32_t phase[PW_PH_COUNT];               // instrumented instantiation only: shader cycles per phase (lane 0)
-    __device__ __forceinline__ PlWaveChkT<PW_WQCAP>& wave_chk() { return wchk1; }
+    __device__ __forceinline__ PlWaveChkT<PW_WQCAP>& wave_chk() { return wchk[PwGroup<NW>::wv()]; }
 };
 
 static inline __host__ __device__ size_t pw_lds_waves_offset() { return (sizeof(PwCommon) + 15) & ~(size_t)15; }
-static inline __host__ __device__ size_t pw_lds_wave_stride() { return (sizeof(PwShared) + 15) & ~(size_t)15; }
-static inline __host__ __device__ size_t pw_lds_tables_offset() { return pw_lds_waves_offset() + PW_WAVES * pw_lds_wave_stride(); }
+template <int NW> static inline __host__ __device__ size_t pw_lds_group_stride() { return (sizeof(PwSharedT<NW>) + 15) & ~(size_t)15; }
+template <int NW> static inline __host__ __device__ size_t pw_lds_tables_offset() { return pw_lds_waves_offset() + (PW_WAVES / NW) * pw_lds_group_stride<NW>(); }
 
-// Every phase of a pop is a CALLED function on (this wave's state, the workgroup's constants), both in LDS: the
+// Every phase of a pop is a CALLED function on (this group's state, the workgroup's constants), both in LDS: the
 // register demand of a phase is its own (fully inlined, the pop loop held the union of all of them: 256 VGPRs plus
-// spills, two waves per SIMD), and nothing but two LDS addresses crosses a call.
-#define PW_PHASE_ARGS AVP_LDS PwShared* sp, AVP_LDS const PwCommon* cp
-#define PW_PHASE_REFS PwShared& s = *(PwShared*)sp; const PwCommon& c = *(const PwCommon*)cp; const int lane = threadIdx.x & 63; (void)lane
+// spills, two waves per SIMD), and nothing but two LDS addresses crosses a call. Every phase ends with the group in step.
+#define PW_PHASE_ARGS AVP_LDS PwSharedT<NW>* sp, AVP_LDS const PwCommon* cp
+#define PW_PHASE_REFS typedef PwGroup<NW> G; PwSharedT<NW>& s = *(PwSharedT<NW>*)sp; const PwCommon& c = *(const PwCommon*)cp; \
+                      const int lane = threadIdx.x & 63, wv = G::wv(), gtid = G::tid(); (void)lane; (void)wv; (void)gtid
 
-// Reeds-Shepp optimal paths of the queries s.rsq[0 .. s.nq) of this wave (s.frame[k] set): calc_optimal_path's result
-// per query in s.bestW / s.best_l / s.w_err. Whole wave.
+// Reeds-Shepp optimal paths of the queries s.rsq[0 .. s.nq) of this group (s.frame[k] set): calc_optimal_path's result
+// per query in rb[0].bestW / best_l / w_err. The rounds (solver group x 64 items) alternate between the group's waves,
+// each with a running best of its own; wave 0 merges them with the same rule.
+template <int NW>
 __device__ __noinline__ void pw_rs_eval(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
     const int nq = s.nq;
     const double maxc = c.p.maxc;
-    if (lane < nq) { s.bestL[lane] = ~0ull; s.bestW[lane] = -1; s.w_err[lane] = 0; }
+    PwRsBest& rb = s.rb[wv];
+    if (lane < nq) { rb.bestL[lane] = ~0ull; rb.bestW[lane] = -1; rb.w_err[lane] = 0; }
     wave_sync();
+    int round = 0;
     for (int sg = 0; sg < 8; sg++) {
         const int L = c.sg_l[sg], sh = c.sg_shift[sg], off = c.sg_off[sg], gmax = c.sg_gmax[sg];
         const int items = nq << sh;
-        for (int base = 0; base < items; base += 64) {
+        for (int base = 0; base < items; base += 64, round++) {
+            if (NW > 1 && (round & (NW - 1)) != wv) continue;
             const int it = base + lane;
             const bool active = it < items;
             const int q = active ? it >> sh : 0, j = it & (L - 1);
@@ -200,32 +246,51 @@ __device__ __noinline__ void pw_rs_eval(PW_PHASE_ARGS)
             // later word (calc_optimal_path's "<=" keeps the last of equal minima in word order)
             const double Lm = Lsum / maxc;
             const unsigned long long lb = (unsigned long long)__double_as_longlong(Lm);
-            if (lane < nq) { s.tmpL[lane] = ~0ull; s.tmpW[lane] = -1; }
+            if (lane < nq) { rb.tmpL[lane] = ~0ull; rb.tmpW[lane] = -1; }
             wave_sync();
-            if (acc) atomicMin(&s.tmpL[q], lb);
-            if (err) s.w_err[q] = 1;
+            if (acc) atomicMin(&rb.tmpL[q], lb);
+            if (err) rb.w_err[q] = 1;
             wave_sync();
-            if (acc && lb == s.tmpL[q]) atomicMax(&s.tmpW[q], word);
+            if (acc && lb == rb.tmpL[q]) atomicMax(&rb.tmpW[q], word);
             wave_sync();
-            if (acc && lb == s.tmpL[q] && word == s.tmpW[q]) {
-                const unsigned long long bl = s.bestL[q];
-                if (lb < bl || (lb == bl && word > s.bestW[q])) {
-                    s.bestL[q] = lb; s.bestW[q] = word;
+            if (acc && lb == rb.tmpL[q] && word == rb.tmpW[q]) {
+                const unsigned long long bl = rb.bestL[q];
+                if (lb < bl || (lb == bl && word > rb.bestW[q])) {
+                    rb.bestL[q] = lb; rb.bestW[q] = word;
 #pragma unroll
-                    for (int i = 0; i < 5; i++) s.best_l[q][i] = l[i];
+                    for (int i = 0; i < 5; i++) rb.best_l[q][i] = l[i];
                 }
             }
             wave_sync();
         }
     }
+    if constexpr (NW > 1) {
+        G::sync();
+        if (wv == 0 && lane < nq) {
+            PwRsBest& r0 = s.rb[0];
+#pragma unroll
+            for (int k = 1; k < NW; k++) {
+                const PwRsBest& rk = s.rb[k];
+                const unsigned long long lb = rk.bestL[lane];
+                const int word = rk.bestW[lane];
+                if (rk.w_err[lane]) r0.w_err[lane] = 1;
+                if (word >= 0 && (lb < r0.bestL[lane] || (lb == r0.bestL[lane] && word > r0.bestW[lane]))) {
+                    r0.bestL[lane] = lb; r0.bestW[lane] = word;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) r0.best_l[lane][i] = rk.best_l[lane][i];
+                }
+            }
+        }
+        wave_sync();
+    }
 }
 
 // Result of query slot q as pl_rs_fold_wave returns it: 0 path in `out` (normalised lengths), 1 no candidate, 2 assertion.
-AVP_D int pw_rs_result(const PwShared& s, int q, RsPath& out)
+AVP_D int pw_rs_result(const PwRsBest& rb, int q, RsPath& out)
 {
     out.n = 0; out.L = 0;
-    if (s.w_err[q]) return 2;
-    const int wd = s.bestW[q];
+    if (rb.w_err[q]) return 2;
+    const int wd = rb.bestW[q];
     if (wd < 0) return 1;
     const RsWord W = RS_WORDS[wd];
     out.n = W.n;
@@ -233,12 +298,13 @@ AVP_D int pw_rs_result(const PwShared& s, int q, RsPath& out)
     out.t[3] = 3 < W.n ? W.d : (int8_t)-1; out.t[4] = 4 < W.n ? W.e : (int8_t)-1;
     double Ln = 0;
 #pragma unroll
-    for (int i = 0; i < AVP_RS_MAXSEG; i++) { out.l[i] = s.best_l[q][i]; Ln = Ln + fabs(out.l[i]); }
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) { out.l[i] = rb.best_l[q][i]; Ln = Ln + fabs(out.l[i]); }
     out.L = Ln;
     return 0;
 }
 
 // ---- per-problem set-up: hybrid_a_star.__init__ (hybrid_a_star.py:72-124) ------------------------------------------
+template <int NW>
 __device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
@@ -247,8 +313,8 @@ __device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
     const int64_t pid = s.pid;
     const double sx = c.starts[3 * pid], sy = c.starts[3 * pid + 1], sth = c.starts[3 * pid + 2];
     const double gx = c.goals[3 * pid], gy = c.goals[3 * pid + 1], gth = c.goals[3 * pid + 2];
-    for (int64_t i = lane; i < c.dims.hashCap; i += 64) w.hash[i] = 0;
-    if (lane == 0) {
+    for (int64_t i = gtid; i < c.dims.hashCap; i += G::N) w.hash[i] = 0;
+    if (gtid == 0) {
         s.status = (c.nchild > PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;
         s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
         s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0; s.n_pops = 0;
@@ -256,13 +322,13 @@ __device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
         s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
         s.E = 0; s.h_cells = 0; s.h_misses = 0;
     }
-    CoopWave::sync();
-    if (s.status == 0) pl_sweep_init<CoopWave>(m, w, s, c.dims, gx, gy);
+    G::sync();
+    if (s.status == 0) pl_sweep_init<G>(m, w, s, c.dims, gx, gy);
     if (s.status == 0) {
         // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
         const int64_t sid = avp_pos_to_index(m, sx, sy);
-        pl_hquery_miss<false, CoopWave>(m, w, s, sid);
-        if (lane == 0) {
+        pl_hquery_miss<false, G>(m, w, s, sid);
+        if (gtid == 0) {
             if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
             else {
                 PlNode& nd = w.nodes[0];
@@ -273,17 +339,18 @@ __device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
                 pl_hash_put(w, c.dims.hashCap, 0);
             }
         }
-        CoopWave::sync();
+        G::sync();
     }
 }
 
 // ---- the next node (path_planner.py:68-76): popped ahead by the previous resolution, or popped now ----------------------
+template <int NW>
 __device__ __noinline__ void pw_ph_pop(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
     const PlanWs& w = s.w;
-    CoopWave::sync();
-    if (lane == 0) {
+    G::sync();
+    if (gtid == 0) {
         if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }
         else if (s.nheap == 0) { s.status = 1; }
         else if (s.n_pops >= c.max_pops) { s.status = 4; }
@@ -292,25 +359,24 @@ __device__ __noinline__ void pw_ph_pop(PW_PHASE_ARGS)
             s.cur = (int32_t)cc;
             w.nodes[cc].state = 3;
         }
-    }
-    CoopWave::sync();
-    if (s.status != 0) return;
-    const PlNode cn = w.nodes[s.cur];
-    if (lane == 0) {
-        s.cn = cn;
-        const int64_t n_pops = s.n_pops;
-        if (c.trace && n_pops < c.max_trace) {
-            double* t = c.trace + ((size_t)s.pid * c.max_trace + n_pops) * PL_TRACE_W;
-            t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(c.m, cn.x, cn.y);
-            t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
-            t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : c.k_steer[cn.steer_i];
+        if (s.status == 0) {
+            const PlNode cn = w.nodes[s.cur];
+            s.cn = cn;
+            const int64_t n_pops = s.n_pops;
+            if (c.trace && n_pops < c.max_trace) {
+                double* t = c.trace + ((size_t)s.pid * c.max_trace + n_pops) * PL_TRACE_W;
+                t[0] = (double)cn.index; t[1] = (double)cn.parent_index; t[2] = (double)avp_pos_to_index(c.m, cn.x, cn.y);
+                t[3] = cn.x; t[4] = cn.y; t[5] = cn.th; t[6] = cn.g; t[7] = cn.h; t[8] = cn.f;
+                t[9] = cn.forward; t[10] = cn.steer_i < 0 ? NAN : c.k_steer[cn.steer_i];
+            }
+            s.n_pops = n_pops + 1;
         }
-        s.n_pops = n_pops + 1;
     }
-    wave_sync();
+    G::sync();
 }
 
 // ---- children poses (expand_node :134-151), their exact-equality look-ups, try_reach_goal's radius test (:308-312) ----
+template <int NW>
 __device__ __noinline__ void pw_ph_children(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
@@ -318,63 +384,80 @@ __device__ __noinline__ void pw_ph_children(PW_PHASE_ARGS)
     const avp_params& p = c.p;
     const PlanWs& w = s.w;
     const int nchild = c.nchild;
-    const double cnx = s.cn.x, cny = s.cn.y, cnth = s.cn.th;
-    const double ddx = cnx - s.goal[0], ddy = cny - s.goal[1];
-    const double distance = sqrt(ddx * ddx + ddy * ddy);
-    const bool in_radius = distance < p.flag_radius;
-    if (lane == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
-    if (lane < nchild) {
-        PlChild& ch = s.child[lane];
-        const int si = lane % p.n_steer;
-        const bool fwd = lane < p.n_steer;
-        const double travel = fwd ? p.travel_dt : -p.travel_dt;
-        const double th_ = avp_pi_2_pi(cnth + c.k_dth_dt[si]);
-        ch.th = th_;
-        double sth_, cth_;
-        avp_sincos(th_, sth_, cth_);
-        ch.x = cnx + travel * cth_;
-        ch.y = cny + travel * sth_;
-        ch.oob = (ch.x > m.b1 || ch.x < m.b0 || ch.y > m.b3 || ch.y < m.b2) ? 1 : 0;
-        ch.found = pl_hash_find(w, c.dims.hashCap, ch.x, ch.y, ch.th);
-        ch.found_state = ch.found >= 0 ? w.nodes[ch.found].state : 0;
-        ch.id = avp_pos_to_index(m, ch.x, ch.y);
-        ch.first_coll = 0x7fffffff;
-        ch.rs_err = 0;
-        ch.L = 0;
+    if (wv == 0) {
+        const double cnx = s.cn.x, cny = s.cn.y, cnth = s.cn.th;
+        const double ddx = cnx - s.goal[0], ddy = cny - s.goal[1];
+        const double distance = sqrt(ddx * ddx + ddy * ddy);
+        const bool in_radius = distance < p.flag_radius;
+        if (lane == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
+        if (lane < nchild) {
+            PlChild& ch = s.child[lane];
+            const int si = lane % p.n_steer;
+            const bool fwd = lane < p.n_steer;
+            const double travel = fwd ? p.travel_dt : -p.travel_dt;
+            const double th_ = avp_pi_2_pi(cnth + c.k_dth_dt[si]);
+            ch.th = th_;
+            double sth_, cth_;
+            avp_sincos(th_, sth_, cth_);
+            ch.x = cnx + travel * cth_;
+            ch.y = cny + travel * sth_;
+            ch.oob = (ch.x > m.b1 || ch.x < m.b0 || ch.y > m.b3 || ch.y < m.b2) ? 1 : 0;
+            ch.found = pl_hash_find(w, c.dims.hashCap, ch.x, ch.y, ch.th);
+            ch.found_state = ch.found >= 0 ? w.nodes[ch.found].state : 0;
+            ch.id = avp_pos_to_index(m, ch.x, ch.y);
+            ch.first_coll = 0x7fffffff;
+            ch.rs_err = 0;
+            ch.L = 0;
+        }
+        wave_sync();
+        // compact list of the sub-step poses to check: sub_t[k] = pose index t = child * n_sub + step. Only the children
+        // expand_node checks: a child equal to a closed node or out of bounds is dropped before (:155-165, once the closed
+        // list is non-empty), one equal to an open node is re-costed without a check (:169-172, :219-230).
+        bool need = false;
+        if (lane < c.nsubs) {
+            const PlChild& ch = s.child[c.sub_child[lane]];
+            const bool found_closed = ch.found >= 0 && ch.found_state == 2, found_open = ch.found >= 0 && ch.found_state == 1;
+            need = !(s.closed_nonempty && (found_closed || ch.oob)) && !found_open;
+        }
+        const unsigned long long mk = __ballot(need);
+        if (need) s.sub_t[__popcll(mk & ((1ull << lane) - 1ull))] = (int8_t)lane;
+        if (lane == 0) { s.n_todo = __popcll(mk); s.n_passes = (__popcll(mk) + PL_WPOSE - 1) / PL_WPOSE; }
     }
-    wave_sync();
+    G::sync();
 }
 
-// ---- sub-step collision checks of every child (:185-204), PL_WPOSE poses per pass ------------------------------------
-template <bool STAGE>
+// ---- sub-step collision checks (:185-204), PL_WPOSE poses per pass, the passes dealt to the group's waves ------------
+template <bool STAGE, int NW>
 __device__ __noinline__ void pw_ph_substeps(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
     const avp_params& p = c.p;
-    const int nsubs = c.nsubs;
     const double cnx = s.cn.x, cny = s.cn.y, cnth = s.cn.th;
-    for (int base = 0; base < nsubs; base += PL_WPOSE) {
-        const int cnt = min(PL_WPOSE, nsubs - base);
+    const int ntodo = s.n_todo;
+    for (int base = wv * PL_WPOSE; base < ntodo; base += NW * PL_WPOSE) {
+        const int cnt = min(PL_WPOSE, ntodo - base);
+        uint32_t* hits = &s.wave_chk().hit[0];
         pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
-            const int t = base + k;
+            const int t = s.sub_t[base + k];
             const int ci = c.sub_child[t], j = c.sub_j[t], si = c.sub_steer[t];
             const double td = ci < p.n_steer ? c.k_travel_ddt[j] : -c.k_travel_ddt[j];
             th = avp_pi_2_pi(cnth + c.k_dth_ddt[si][j]);
             avp_sincos(th, sn, cs);
             x = cnx + td * cs;
             y = cny + td * sn;
-        }, &s.chk_hit[base]);
+        }, hits);
+        if (lane < cnt && hits[lane]) { const int t = s.sub_t[base + lane]; atomicMin(&s.child[c.sub_child[t]].first_coll, (int)c.sub_j[t]); }
+        wave_sync();
     }
-    for (int t = lane; t < nsubs; t += 64)
-        if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
-    if (lane == 0) s.can_fast = (s.closed_nonempty && (s.nnodes + c.nchild <= c.maxNodes)) ? 1 : 0;
-    wave_sync();
+    if (gtid == 0) s.can_fast = (s.closed_nonempty && (s.nnodes + c.nchild <= c.maxNodes)) ? 1 : 0;
+    G::sync();
 }
 
 // ---- Reeds-Shepp: the shot from the popped node (:326-332) and the children's lengths (:286-294) ----------------------
 // Only the queries whose result the pop can use are evaluated: the shot inside flag_radius; a child unless expand_node
 // drops it before it reaches calc_node_heuristic -- equal to a closed node or out of bounds (:155-165, once the closed
 // list is non-empty), or new and colliding (:197-204). The reference does not solve those either.
+template <int NW>
 __device__ __noinline__ void pw_ph_rs(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
@@ -382,53 +465,64 @@ __device__ __noinline__ void pw_ph_rs(PW_PHASE_ARGS)
     const int nchild = c.nchild;
     const bool in_radius = s.in_radius != 0;
     bool need = false;
-    if (lane == 0) need = in_radius;
-    else if (lane <= nchild) {
-        const PlChild& ch = s.child[lane - 1];
-        const bool found_closed = ch.found >= 0 && ch.found_state == 2, found_open = ch.found >= 0 && ch.found_state == 1;
-        need = !(s.closed_nonempty && (found_closed || ch.oob)) && !(!found_open && ch.first_coll != 0x7fffffff);
+    int k = 0;
+    if (wv == 0) {
+        if (lane == 0) need = in_radius;
+        else if (lane <= nchild) {
+            const PlChild& ch = s.child[lane - 1];
+            const bool found_closed = ch.found >= 0 && ch.found_state == 2, found_open = ch.found >= 0 && ch.found_state == 1;
+            need = !(s.closed_nonempty && (found_closed || ch.oob)) && !(!found_open && ch.first_coll != 0x7fffffff);
+        }
+        const unsigned long long mk = __ballot(need);
+        k = __popcll(mk & ((1ull << lane) - 1ull));
+        if (need) {
+            s.rsq[k] = lane;
+            if (lane == 0) s.frame[k] = rs_frame(s.cn.x, s.cn.y, s.cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
+            else { const PlChild& ch = s.child[lane - 1]; s.frame[k] = rs_frame(ch.x, ch.y, ch.th, s.goal[0], s.goal[1], s.goal[2], p.maxc); }
+        }
+        if (lane == 0) s.nq = __popcll(mk);
     }
-    const unsigned long long mk = __ballot(need);
-    const int k = __popcll(mk & ((1ull << lane) - 1ull));
-    if (need) {
-        s.rsq[k] = lane;
-        if (lane == 0) s.frame[k] = rs_frame(s.cn.x, s.cn.y, s.cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
-        else { const PlChild& ch = s.child[lane - 1]; s.frame[k] = rs_frame(ch.x, ch.y, ch.th, s.goal[0], s.goal[1], s.goal[2], p.maxc); }
+    G::sync();
+    pw_rs_eval<NW>(sp, cp);
+    if (wv == 0) {
+        if (need && lane >= 1) {
+            RsPath rp;
+            const int st = pw_rs_result(s.rb[0], k, rp);
+            s.child[lane - 1].rs_err = (int8_t)st; s.child[lane - 1].L = st ? 0.0 : rp.L / p.maxc;
+        }
+        if (lane == 0 && in_radius) {
+            RsPath rp;
+            const int st = pw_rs_result(s.rb[0], 0, rp);
+            s.rs_status = st;
+            if (!st) { s.rs = rp; s.n_rs += 1; }
+        }
     }
-    if (lane == 0) s.nq = __popcll(mk);
-    wave_sync();
-    pw_rs_eval(sp, cp);
-    if (need && lane >= 1) {
-        RsPath rp;
-        const int st = pw_rs_result(s, k, rp);
-        s.child[lane - 1].rs_err = (int8_t)st; s.child[lane - 1].L = st ? 0.0 : rp.L / p.maxc;
-    }
-    if (lane == 0 && in_radius) {
-        RsPath rp;
-        const int st = pw_rs_result(s, 0, rp);
-        s.rs_status = st;
-        if (!st) { s.rs = rp; s.n_rs += 1; pl_rs_sample_book(s, p); }
-    }
-    wave_sync();
-    if (in_radius && s.rs_status) { if (lane == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? AVP_PLAN_RETRY : 3; wave_sync(); }
+    G::sync();
 }
 
 // ---- the shot: sample in path order, check, stop at the first colliding sample (:335-345) ------------------------------
-template <bool STAGE, bool PROFILE>
+template <bool STAGE, bool PROFILE, int NW>
 __device__ __noinline__ void pw_ph_shot(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
     const avp_params& p = c.p;
     const PlanWs& w = s.w;
+    if (s.rs_status) { if (gtid == 0) s.status = 3; G::sync(); return; }       // (no Reeds-Shepp path / the reference's assertion)
+    // the sampler's index bookkeeping (one lane) beside the chain of segment origins (a wave)
+    if (gtid == 0) pl_rs_sample_book(s, p);
+    if (wv == (NW > 1 ? 1 : 0)) pl_rs_sample_origins(s, p);
+    G::sync();
+    if (s.rs_status) { if (gtid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? AVP_PLAN_RETRY : 3; G::sync(); return; }
     const PlNode cn = s.cn;
-    pl_rs_sample_origins(s, p);
-    wave_sync();
     const int total = s.smp_hi + 1;
     double cm, sm;
     avp_sincos(-cn.th, sm, cm);
-    for (int base = 0; base < total; base += PL_WPOSE) {
+    for (int base = wv * PL_WPOSE; base < total; base += NW * PL_WPOSE) {
+        // stop at the first colliding sample -- unless it may lie in the trailing px == 0.0 tail the reference pops
+        // (rs_curve.py:588-592): that is only known once every sample has been produced, so keep going then
+        { const int fc = *(volatile int32_t*)&s.rs_first_coll; if (fc != 0x7fffffff && fc < *(volatile int32_t*)&s.rs_npts) break; }
         const int cnt = min(PL_WPOSE, total - base);
-        if constexpr (PROFILE) { if (lane == 0) s.phase[PW_PH_NPASS] += 1; }
+        if constexpr (PROFILE) { if (lane == 0) atomicAdd(&s.phase[PW_PH_NPASS], 1u); }
         double tx = 0.0, ty = 0.0, tth = 0.0;
         const int mine = base + lane;
         if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
@@ -439,28 +533,35 @@ __device__ __noinline__ void pw_ph_shot(PW_PHASE_ARGS)
         }, hits);
         if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
         wave_sync();
-        // stop at the first colliding sample -- unless it may lie in the trailing px == 0.0 tail the reference pops
-        // (rs_curve.py:588-592): that is only known once every sample has been produced, so keep going then
-        if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll < s.rs_npts) break;
     }
-    if (lane == 0) {
+    G::sync();
+    if (gtid == 0) {
         // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
         if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
         if (s.rs_first_coll == 0x7fffffff) { s.n_checks += s.rs_npts; s.done = 1; }
         else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
     }
-    wave_sync();
+    G::sync();
 }
 
 // ---- child resolution in child order (:153-232): wave-parallel when every heuristic query hits the closed frontier ------
+template <int NW>
 __device__ __noinline__ void pw_ph_resolve_fast(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
-    const PlNode cn = s.cn;
-    pl_resolve_fast_wave<false>(c.m, c.p, s.w, s, c.dims, cn, c.nchild, s.n_pops < c.max_pops);
-    wave_sync();
+    if (gtid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = s.can_fast; }
+    if (wv == 0) {
+        if (!s.can_fast && lane < c.nchild) s.child[lane].pre_d = pl_id_in_range(c.m, s.child[lane].id) ? s.w.dist[s.child[lane].id] : PL_UNSEEN;
+        wave_sync();
+        if (s.can_fast) {
+            const PlNode cn = s.cn;
+            pl_resolve_fast_wave<false>(c.m, c.p, s.w, s, c.dims, cn, c.nchild, s.n_pops < c.max_pops);
+        }
+    }
+    G::sync();
 }
-// ... else lane 0 in child order, the wave extending the heuristic sweep at every miss
+// ... else lane 0 in child order, the group extending the heuristic sweep at every miss; then the node is closed (:235-239)
+template <int NW>
 __device__ __noinline__ void pw_ph_resolve_slow(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
@@ -468,8 +569,8 @@ __device__ __noinline__ void pw_ph_resolve_slow(PW_PHASE_ARGS)
     const avp_params& p = c.p;
     const PlanWs& w = s.w;
     const int nchild = c.nchild, maxNodes = c.maxNodes;
-    for (;;) {
-        if (lane == 0) {
+    while (!s.fast) {
+        if (gtid == 0) {
             const PlNode cn = s.cn;
             s.need_sweep = 0;
             int i = s.next_child;
@@ -525,39 +626,46 @@ __device__ __noinline__ void pw_ph_resolve_slow(PW_PHASE_ARGS)
             }
             s.next_child = i;
         }
-        CoopWave::sync();
+        G::sync();
         if (!s.need_sweep) break;
-        pl_hquery_miss<false, CoopWave>(m, w, s, s.pending_id);
-        if (lane == 0) s.have_d = 1;
-        if (lane < nchild) s.child[lane].pre_d = pl_id_in_range(m, s.child[lane].id) ? w.dist[s.child[lane].id] : PL_UNSEEN;
-        CoopWave::sync();
+        pl_hquery_miss<false, G>(m, w, s, s.pending_id);
+        if (gtid == 0) s.have_d = 1;
+        if (gtid < nchild) s.child[gtid].pre_d = pl_id_in_range(m, s.child[gtid].id) ? w.dist[s.child[gtid].id] : PL_UNSEEN;
+        G::sync();
     }
+    if (gtid == 0 && s.status == 0) {
+        w.nodes[s.cur].state = 2;
+        s.nclosed++; s.closed_nonempty = 1;
+        s.global_index += nchild;
+    }
+    G::sync();
 }
 
 // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) ------------------------------------------------------------
+template <int NW>
 __device__ __noinline__ void pw_ph_finish(PW_PHASE_ARGS)
 {
     PW_PHASE_REFS;
     const avp_params& p = c.p;
     const PlanWs& w = s.w;
-    CoopWave::sync();
+    G::sync();
     if (s.status == 1 && s.cur >= 0 && s.in_radius && s.rs.n > 0 && s.rs_status == 0 && s.collision) {
         // the reference hands back the last (colliding) shot when the open list runs empty (path_planner.py:100-108):
         // the early exit of the shot's checks may have left samples unproduced
         const PlNode cl = w.nodes[s.cur];
         double cm, sm;
         avp_sincos(-cl.th, sm, cm);
-        for (int i = lane; i <= s.smp_hi; i += 64) { double a, b, cc; pl_rs_sample_world(w, s, p, cl, cm, sm, i, a, b, cc); }
-        CoopWave::sync();
+        for (int i = gtid; i <= s.smp_hi; i += G::N) { double a, b, cc; pl_rs_sample_world(w, s, p, cl, cm, sm, i, a, b, cc); }
+        G::sync();
     }
-    if (lane == 0) {
+    if (gtid == 0) {
         if (s.status == AVP_PLAN_RETRY) { c.results[s.pid].status = AVP_PLAN_RETRY; }
         else pl_write_result<false>(p, w, s, c.k_travel_ddt, c.k_dth_ddt, c.results, c.paths, c.max_path, s.pid, s.n_pops, s.slot, 0ll);
     }
-    CoopWave::sync();
+    G::sync();
 }
 
-template <bool STAGE, bool PROFILE = false>
+template <bool STAGE, bool PROFILE = false, int NW = 1>
 __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                                const double* __restrict__ goals, int64_t n, int32_t maxNodes,
                                                                char* __restrict__ workspace, unsigned int* __restrict__ counter,
@@ -566,24 +674,27 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
                                                                double* __restrict__ trace, int32_t max_trace,
                                                                const int32_t* __restrict__ order)
 {
+    typedef PwGroup<NW> G;
+    static_assert(PW_WAVES % NW == 0, "groups of NW adjacent waves");
     avp_lds_tables_fill<true>();
     rs_lds_tables_fill();
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
     PwCommon& c = *reinterpret_cast<PwCommon*>(pw_smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    PwShared& s = *reinterpret_cast<PwShared*>(pw_smem + pw_lds_waves_offset() + (size_t)wave * pw_lds_wave_stride());
-    AVP_LDS PwShared* const sp = (AVP_LDS PwShared*)&s;
+    const int tid = threadIdx.x, grp = tid / G::N, lane = tid & 63, gtid = G::tid();
+    PwSharedT<NW>& s = *reinterpret_cast<PwSharedT<NW>*>(pw_smem + pw_lds_waves_offset() + (size_t)grp * pw_lds_group_stride<NW>());
+    AVP_LDS PwSharedT<NW>* const sp = (AVP_LDS PwSharedT<NW>*)&s;
     AVP_LDS const PwCommon* const cp = (AVP_LDS const PwCommon*)&c;
     {
         const PlanDims dims = plan_dims(m.S, m.Sy, maxNodes);
-        const int32_t slot = (int32_t)blockIdx.x * PW_WAVES + wave;
-        if (lane == 0) { s.w = plan_carve(workspace + (size_t)slot * dims.bytes, dims); s.slot = slot; }
+        const int32_t slot = (int32_t)blockIdx.x * (PW_WAVES / NW) + grp;
+        if (gtid == 0) { s.w = plan_carve(workspace + (size_t)slot * dims.bytes, dims); s.slot = slot; }
         if (tid == 0) {
             c.m = m; c.p = p; c.dims = dims;
             c.starts = starts; c.goals = goals; c.results = results; c.paths = paths; c.trace = trace;
             c.max_path = max_path; c.max_trace = max_trace; c.maxNodes = maxNodes; c.nchild = 2 * p.n_steer; c.nsubs = 2 * p.n_steer * p.n_sub; c.pad = 0;
             c.max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
         }
+        if (tid < PW_WAVES) { PW_BAR_CNT[tid] = 0; PW_BAR_GEN[tid] = 0; }
     }
 #pragma unroll
     for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
@@ -598,7 +709,7 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
     if (tid < 8) { c.sg_l[tid] = PW_SG_L[tid]; c.sg_shift[tid] = PW_SG_SHIFT[tid]; c.sg_off[tid] = PW_SG_OFF[tid]; c.sg_gmax[tid] = PW_SG_GMAX[tid]; }
     MapTabs mt;
     if (STAGE) {
-        uint64_t* lb = reinterpret_cast<uint64_t*>(pw_smem + pw_lds_tables_offset());
+        uint64_t* lb = reinterpret_cast<uint64_t*>(pw_smem + pw_lds_tables_offset<NW>());
         double* lx = reinterpret_cast<double*>(lb + (size_t)m.nx * m.wpc);
         double* ly = lx + m.nx;
         for (int i = tid; i < m.nx * m.wpc; i += PW_THREADS) lb[i] = m.colBits[i];
@@ -606,53 +717,43 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
         for (int i = tid; i < m.ny; i += PW_THREADS) ly[i] = m.Y[i];
         mt.X = lx; mt.Y = ly; mt.bits = lb;
     } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
-    if (lane == 0) s.mt = mt;
+    if (gtid == 0) s.mt = mt;
     if (tid == 0) pl_chk_env_fill(c.env, m, p, STAGE ? mt.X : nullptr, STAGE ? mt.Y : nullptr, STAGE ? mt.bits : nullptr);
-    __syncthreads();                                   // the last workgroup barrier: from here on every wave is on its own
+    __syncthreads();                                   // the last workgroup barrier: from here on every group is on its own
 
     for (;;) {
-        CoopWave::sync();
-        if (lane == 0) { const uint32_t t = atomicAdd(counter, 1u); s.pid = (int64_t)t < n ? (order ? order[t] : (int32_t)t) : 0x7fffffff; }
-        CoopWave::sync();
+        G::sync();
+        if (gtid == 0) { const uint32_t t = atomicAdd(counter, 1u); s.pid = (int64_t)t < n ? (order ? order[t] : (int32_t)t) : 0x7fffffff; }
+        G::sync();
         if (s.pid >= n) break;
         long long t_ph = PROFILE ? clock64() : 0ll;
-        if constexpr (PROFILE) { if (lane == 0) for (int k = 0; k < PW_PH_COUNT; k++) s.phase[k] = 0; }
-        pw_ph_init(sp, cp);
+        if constexpr (PROFILE) { if (gtid == 0) for (int k = 0; k < PW_PH_COUNT; k++) s.phase[k] = 0; }
+        pw_ph_init<NW>(sp, cp);
         PW_T(PW_PH_INIT);
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
         while (s.status == 0 && !s.done) {
-            pw_ph_pop(sp, cp);
+            pw_ph_pop<NW>(sp, cp);
             if (s.status != 0) break;
             PW_T(PW_PH_POP);
-            pw_ph_children(sp, cp);
+            pw_ph_children<NW>(sp, cp);
             PW_T(PW_PH_CHILD);
-            pw_ph_substeps<STAGE>(sp, cp);
-            if constexpr (PROFILE) { if (lane == 0) s.phase[PW_PH_NPASS] += (c.nsubs + PL_WPOSE - 1) / PL_WPOSE; }
+            pw_ph_substeps<STAGE, NW>(sp, cp);
+            if constexpr (PROFILE) { if (gtid == 0) atomicAdd(&s.phase[PW_PH_NPASS], (uint32_t)s.n_passes); }
             PW_T(PW_PH_SUB);
-            pw_ph_rs(sp, cp);
-            if constexpr (PROFILE) { if (lane == 0) s.phase[PW_PH_NROUND] += s.nq; }
+            pw_ph_rs<NW>(sp, cp);
+            if constexpr (PROFILE) { if (gtid == 0) s.phase[PW_PH_NROUND] += s.nq; }
             PW_T(PW_PH_RS);
-            if (s.status != 0) break;
-            if (s.in_radius) pw_ph_shot<STAGE, PROFILE>(sp, cp);
+            if (s.in_radius) pw_ph_shot<STAGE, PROFILE, NW>(sp, cp);
             PW_T(PW_PH_SHOT);
             if (s.status != 0 || s.done) break;
-            if (lane == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = s.can_fast; }
-            if (!s.can_fast && lane < c.nchild) s.child[lane].pre_d = pl_id_in_range(c.m, s.child[lane].id) ? s.w.dist[s.child[lane].id] : PL_UNSEEN;
-            wave_sync();
-            if (s.can_fast) pw_ph_resolve_fast(sp, cp);
+            pw_ph_resolve_fast<NW>(sp, cp);
             PW_T(PW_PH_RESOLVE);
-            if (!s.fast) pw_ph_resolve_slow(sp, cp);
-            if (lane == 0 && s.status == 0) {
-                s.w.nodes[s.cur].state = 2;
-                s.nclosed++; s.closed_nonempty = 1;
-                s.global_index += c.nchild;
-            }
-            CoopWave::sync();
+            pw_ph_resolve_slow<NW>(sp, cp);
             PW_T(PW_PH_SLOW);
         }
         if constexpr (PROFILE) t_ph = clock64();
-        pw_ph_finish(sp, cp);
-        if constexpr (PROFILE) { if (lane == 0 && s.status != AVP_PLAN_RETRY) { s.phase[PW_PH_FINISH] += (uint32_t)(clock64() - t_ph); for (int k = 0; k < PW_PH_COUNT; k++) results[s.pid].phase_cycles[k] = s.phase[k]; } }
-        CoopWave::sync();
+        pw_ph_finish<NW>(sp, cp);
+        if constexpr (PROFILE) { if (gtid == 0 && s.status != AVP_PLAN_RETRY) { s.phase[PW_PH_FINISH] += (uint32_t)(clock64() - t_ph); for (int k = 0; k < PW_PH_COUNT; k++) results[s.pid].phase_cycles[k] = s.phase[k]; } }
+        G::sync();
     }
 }

@@ -131,11 +131,11 @@ class BatchPlanner:
         self.dm.use_current_stream()
         n = starts_t.shape[0]
         L = _native.lib()
-        mode = (2 if self.mode == 2 else 1) if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode)))
+        mode = (self.mode if self.mode in (2, 3) else 1) if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode)))
         cap = self.n_slots if self.n_slots else int(L.avp_plan_slots(self.dm.h, C.c_int32(mode)))
-        wg = int(L.avp_plan_wave_group())                   # problems per workgroup of the wave form
-        slots = max(1, min(cap, n if mode == 1 else wg * ((n + wg - 1) // wg)))
-        if mode == 2 and slots < wg:
+        wg = int(L.avp_plan_group(C.c_int32(mode)))         # problems per workgroup of the kernel form
+        slots = max(1, min(cap, wg * ((n + wg - 1) // wg)))
+        if mode >= 2 and slots < wg:
             mode = 1                                        # fewer than one workgroup of slots: the workgroup form
         ws = self._workspace(slots)
         res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)

@@ -191,7 +191,7 @@ int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, 
  *           larger than the chip (north_star's 4 096-pose batch). Problems it cannot hold (a Reeds-Shepp shot of more
  *           than 256 samples, more than 16 children) are planned by the mode-1 kernel in a second launch of the same call;
  *   mode 0: avp_plan_batch's choice: mode 2 when n >= 32 x the number of CUs (4 problems per wave slot), else mode 1.
- * n_slots counts problem slots in either form (avp_plan_slots(map, mode): CUs, or avp_plan_wave_group() x CUs); the workspace is
+ * n_slots counts problem slots in either form (avp_plan_slots(map, mode) = avp_plan_group(mode) x CUs); the workspace is
  * avp_plan_workspace_bytes(map, n_slots, max_nodes) as before. avp_plan_pick_mode returns the form mode 0 would use.
  */
 int32_t avp_plan_batch_mode(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
@@ -199,7 +199,7 @@ int32_t avp_plan_batch_mode(avp_map* map, const double* starts, const double* go
                             double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t mode);
 int32_t avp_plan_pick_mode(avp_map* map, int64_t n, int32_t mode);
 int32_t avp_plan_slots(avp_map* map, int32_t mode);
-int32_t avp_plan_wave_group(void);          /* problems (waves) per workgroup of the mode-2 kernel: mode-2 slot counts are multiples of it */
+int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the kernel form: slot counts are multiples of it (mode 1: 1) */
 
 /*
  * Expansion lookahead (mode 1 only). A batch no larger than the chip leaves compute units without a problem of their

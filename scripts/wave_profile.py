@@ -13,6 +13,7 @@ import sys
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--mode", type=int, default=2, help="2 = one wave per problem, 3 = a pair of waves per problem")
 a = ap.parse_args()
 if a.lib:
     os.environ["AVP_HIP_LIB"] = os.path.abspath(a.lib)
@@ -38,7 +39,7 @@ rep = max(1, a.n // 256)
 bs = torch.cat([st] * rep).contiguous()
 bg = torch.cat([go.roll(k, 0) for k in range(rep)]).contiguous()
 n = bs.shape[0]
-bp = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=2)
+bp = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=a.mode)
 
 
 def timed(profile):
@@ -58,7 +59,7 @@ names = ["init", "pop", "children", "substeps", "rs", "shot", "resolve_fast", "r
 cap = rp["status"] == 4
 ph = rp["phase_cycles"].astype(np.float64)
 pops = rp["n_pops"].astype(np.float64)
-out = {"lib": os.path.basename(_native.LIB_PATH), "wave_group": int(_native.lib().avp_plan_wave_group()), "n": int(n), "ms": round(ms, 2),
+out = {"lib": os.path.basename(_native.LIB_PATH), "mode": a.mode, "problems_per_wg": int(_native.lib().avp_plan_group(a.mode)), "n": int(n), "ms": round(ms, 2),
        "ms_instrumented": round(msp, 2), "capped": int(cap.sum()), "expansions_per_s": round(float(rec["n_pops"].sum()) / ms * 1e3),
        "same_pops": bool(np.array_equal(rec["n_pops"], rp["n_pops"]))}
 if cap.any():

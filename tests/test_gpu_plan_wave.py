@@ -1,4 +1,5 @@
-"""plan_wave_kernel (one wave per problem, 8 problems per workgroup; avp_plan_batch_mode mode 2) against the CPU oracle in
+"""plan_wave_kernel in both its forms -- one wave per problem (avp_plan_batch_mode mode 2) and a pair of waves per problem
+(mode 3) -- against the CPU oracle in
 device arithmetic and against plan_kernel (mode 1): every record field, pop trace, counter and way-point identical --
 the result never depends on the kernel form that produced it, including the problems the wave form hands back to the
 workgroup form (Reeds-Shepp shots longer than its sample buffer)."""
@@ -27,7 +28,11 @@ def _same_results(a, b):
             assert np.array_equal(x.trace, y.trace, equal_nan=True)
 
 
-def test_wave_form_case1_batch_vs_oracle_and_workgroup_form(vehicle, cfg):
+FORMS = [2, 3]          # one wave / a pair of waves per problem
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_wave_form_case1_batch_vs_oracle_and_workgroup_form(form, vehicle, cfg):
     from automatedvaletparking_amd import sampling, _native, path_planner
     from oracle import oracle
     m = case_map_from_gold(1)
@@ -39,7 +44,7 @@ def test_wave_form_case1_batch_vs_oracle_and_workgroup_form(vehicle, cfg):
     starts = np.concatenate([poses[0::2], poses[0::2]])
     goals = np.concatenate([poses[1::2], np.roll(poses[1::2], 7, axis=0)])
     dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
-    wave = path_planner.BatchPlanner(dm, max_nodes=8192, mode=2).plan(starts, goals, max_trace=cap)
+    wave = path_planner.BatchPlanner(dm, max_nodes=8192, mode=form).plan(starts, goals, max_trace=cap)
     wg = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1).plan(starts, goals, max_trace=cap)
     _same_results(wave, wg)
     assert len({r.counters["n_nodes"] for r in wave}) > 20 and sum(r.status == 0 for r in wave) > 300
@@ -51,7 +56,7 @@ def test_wave_form_case1_batch_vs_oracle_and_workgroup_form(vehicle, cfg):
         _assert_same_as_oracle(r, w)
     # a batch smaller than one workgroup of slots, and odd sizes (ragged last workgroup)
     for n in (1, 7, 9, 65):
-        _same_results(path_planner.BatchPlanner(dm, max_nodes=8192, mode=2).plan(starts[:n], goals[:n]),
+        _same_results(path_planner.BatchPlanner(dm, max_nodes=8192, mode=form).plan(starts[:n], goals[:n]),
                       path_planner.BatchPlanner(dm, max_nodes=8192, mode=1).plan(starts[:n], goals[:n]))
 
 
@@ -64,7 +69,7 @@ def test_wave_form_auto_mode_and_slots(vehicle, cfg):
     dm = _native.DeviceMap(m, vehicle, cfg, max_pops=40)
     L = _native.lib()
     ncu = int(L.avp_plan_slots(dm.h, C.c_int32(1)))
-    assert int(L.avp_plan_slots(dm.h, C.c_int32(2))) == int(L.avp_plan_wave_group()) * ncu
+    assert int(L.avp_plan_slots(dm.h, C.c_int32(2))) == int(L.avp_plan_group(C.c_int32(2))) * ncu
     assert int(L.avp_plan_pick_mode(dm.h, C.c_int64(32 * ncu), C.c_int32(0))) == 2 and int(L.avp_plan_pick_mode(dm.h, C.c_int64(16 * ncu), C.c_int32(0))) == 1
     rng = np.random.default_rng(8)
     b = m.boundary
@@ -74,8 +79,11 @@ def test_wave_form_auto_mode_and_slots(vehicle, cfg):
     assert len(free) >= 2 * n
     st, go = free[0:2 * n:2], free[1:2 * n:2]
     ref = path_planner.BatchPlanner(dm, max_nodes=4096, mode=1).plan(st, go)
-    _same_results(path_planner.BatchPlanner(dm, max_nodes=4096, mode=2).plan(st, go), ref)
-    _same_results(path_planner.BatchPlanner(dm, max_nodes=4096, mode=2, n_slots=24).plan(st, go), ref)   # 3 workgroups of 8 waves
+    for form in FORMS:
+        grp = int(L.avp_plan_group(C.c_int32(form)))
+        assert int(L.avp_plan_slots(dm.h, C.c_int32(form))) == grp * ncu
+        _same_results(path_planner.BatchPlanner(dm, max_nodes=4096, mode=form).plan(st, go), ref)
+        _same_results(path_planner.BatchPlanner(dm, max_nodes=4096, mode=form, n_slots=3 * grp).plan(st, go), ref)   # 3 workgroups
     big = 32 * ncu                                                                                       # auto -> wave form
     sb, gb = np.tile(st, (big // n + 1, 1))[:big], np.tile(go, (big // n + 1, 1))[:big]
     auto = path_planner.BatchPlanner(dm, max_nodes=4096).plan(sb, gb)
@@ -86,7 +94,8 @@ def test_wave_form_auto_mode_and_slots(vehicle, cfg):
 @pytest.mark.parametrize("name", ["g6_trace_case1.npz", "g6_trace_case13.npz", "g6_trace_case5.npz", "g6_trace_case20.npz", "g8_synth_c5_plan0.npz",
                                   "g10_variant_circle_case4_0.npz", "g10_variant_steer7_r6_case4_1.npz", "g10_variant_dt08_case4_0.npz",
                                   "g10_variant_margins_rsall_case4_2.npz"])
-def test_wave_form_golden_problems(name, vehicle, cfg):
+@pytest.mark.parametrize("form", FORMS)
+def test_wave_form_golden_problems(form, name, vehicle, cfg):
     """Single golden problems through the wave form (8 slots, 7 idle): long searches (Case13: 5 681 pops), NO_PATH
     (Case20), the two-circle checker, 7 steering angles (14 children), other time steps, RS shot at every pop."""
     import json
@@ -101,13 +110,14 @@ def test_wave_form_golden_problems(name, vehicle, cfg):
         cfgp.update(json.loads(str(g["cfg_json"])))
     cap = 30000
     dm = _native.DeviceMap(m, vehicle, cfgp, max_pops=cap)
-    res = path_planner.BatchPlanner(dm, n_slots=8, max_nodes=1 << 19, mode=2).plan(st[None, :], go[None, :], max_trace=cap)[0]
+    res = path_planner.BatchPlanner(dm, n_slots=16, max_nodes=1 << 19, mode=form).plan(st[None, :], go[None, :], max_trace=cap)[0]
     with oracle.device_arithmetic():
         w = oracle.Oracle(m, vehicle, cfgp, max_pops=cap).plan(st, go, max_trace=cap)
     _assert_same_as_oracle(res, w)
 
 
-def test_wave_form_hands_long_shots_back(vehicle, cfg, tmp_path):
+@pytest.mark.parametrize("form", FORMS)
+def test_wave_form_hands_long_shots_back(form, vehicle, cfg, tmp_path):
     """A Reeds-Shepp shot of more than 256 samples (> 128 m) does not fit the wave form's sample buffer: the problem is
     planned by the workgroup form inside the same call, with the same result; 16 children (8 steering angles) too."""
     from automatedvaletparking_amd import costmap, sampling, _native, path_planner
@@ -121,12 +131,12 @@ def test_wave_form_hands_long_shots_back(vehicle, cfg, tmp_path):
     goals = np.array([[190.0 - 0.3 * k, 30.0, 0.0] for k in range(16)])
     goals[8:] = starts[8:] + np.array([6.0, 1.0, 0.3])          # short ones stay in the wave form
     dm = _native.DeviceMap(m, vehicle, c2, max_pops=50)
-    wave = path_planner.BatchPlanner(dm, max_nodes=4096, mode=2, max_path=1024).plan(starts, goals, max_trace=50)
+    wave = path_planner.BatchPlanner(dm, max_nodes=4096, mode=form, max_path=1024).plan(starts, goals, max_trace=50)
     wg = path_planner.BatchPlanner(dm, max_nodes=4096, mode=1, max_path=1024).plan(starts, goals, max_trace=50)
     _same_results(wave, wg)
     assert all(r.status == 0 for r in wave) and max(r.n_rs_pts for r in wave) > 256
     c3 = dict(cfg)
     c3["steering_angle_num"] = 8                                   # 16 children: the wave form's maximum
     dm3 = _native.DeviceMap(m, vehicle, c3, max_pops=40)
-    _same_results(path_planner.BatchPlanner(dm3, max_nodes=4096, mode=2).plan(starts[8:], goals[8:], max_trace=40),
+    _same_results(path_planner.BatchPlanner(dm3, max_nodes=4096, mode=form).plan(starts[8:], goals[8:], max_trace=40),
                   path_planner.BatchPlanner(dm3, max_nodes=4096, mode=1).plan(starts[8:], goals[8:], max_trace=40))
