@@ -180,6 +180,9 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 #ifndef PL_LOOK_BACKLOG
 #define PL_LOOK_BACKLOG 16             // child jobs are posted only while at most this many jobs wait in a ring
 #endif
+#ifndef PL_LOOK_FAULT
+#define PL_LOOK_FAULT 0               // test builds (scripts/look_soak.py): > 0 = a helper publishes the records of the nodes divisible by it with ONE
+#endif                                // key word flipped behind the ready bit's back -- the owner must turn them down (same results, fewer records used)
 #ifndef PL_LOOK_WAIT
 #define PL_LOOK_WAIT 10000            // cycles an owner waits for a record that is posted but not finished (0 / 10 k / 20 k: 21.4 / 20.7 / 20.7 ms)
 #endif
@@ -212,13 +215,34 @@ __device__ __forceinline__ size_t pl_look_idx(int64_t pid, int32_t maxNodes, int
 #define PL_JOB_PID(w0) ((int64_t)(((w0) >> 32) & 0xfffffull))
 #define PL_JOB_SLOT(w0) ((int)(((w0) >> 52) & 15ull))
 // agent-scope relaxed accesses (sc1): payload stores, s_waitcnt vmcnt(0), flag store on the producer side; flag load,
-// then payload loads on the consumer side
+// then payload loads on the consumer side -- the "sc1 payload -> drained -> sc1 flag" hand-off of MI355X_MICROARCH.md
+// (every access of both sides bypasses the non-coherent L1). PL_LOOK_ATOMICS = 1 builds the same protocol from
+// release stores / acquire loads at agent scope instead (buffer_wbl2 / buffer_inv around every flag): measured
+// (profiles/r03_lookahead_soak.json) it changes no result and costs time, so the default stays 0.
+#ifndef PL_LOOK_ATOMICS
+#define PL_LOOK_ATOMICS 0
+#endif
+#if PL_LOOK_ATOMICS
+#define PL_LOOK_DRAIN() do { } while (0)
+#define PL_FLAG_ST64(q, v) __hip_atomic_store((q), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#define PL_FLAG_LD64(q) __hip_atomic_load((q), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+#define PL_FLAG_LD32(q) __hip_atomic_load((q), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+#define PL_FLAG_OR32(q, v) __hip_atomic_fetch_or((q), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define PL_LOOK_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PL_FLAG_ST64(q, v) pl_st64((q), (v))
+#define PL_FLAG_LD64(q) pl_ld64(q)
+#define PL_FLAG_LD32(q) pl_ld32(q)
+#define PL_FLAG_OR32(q, v) atomicOr((q), (v))
+#endif
 __device__ __forceinline__ unsigned long long pl_ld64(const unsigned long long* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pl_st64(unsigned long long* q, unsigned long long v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t pl_ld32(const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pl_st32(uint32_t* q, uint32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long pl_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ double pl_unbits(unsigned long long v) { return __longlong_as_double((long long)v); }
+// key word 83 of a record: the problem and the goal heading (the goal position has words of its own)
+__device__ __forceinline__ unsigned long long pl_look_key3(int64_t pid, double goal_th) { return (unsigned long long)pid ^ (pl_bits(goal_th) * 0x9E3779B97F4A7C15ULL); }
 
 // ---- what a collision pass reads of the map and the vehicle: one copy per workgroup in LDS ------------
 // The passes are CALLED functions (pl_check_pass below): everything they need travels as three LDS addresses, so no
@@ -226,7 +250,7 @@ __device__ __forceinline__ double pl_unbits(unsigned long long v) { return __lon
 #define AVP_LDS __attribute__((address_space(3)))
 // register budget of plan_wave_kernel and of the functions it calls (the attribute propagates): 512 / PW_WAVES_PER_EU per lane
 #ifndef PW_WAVES_PER_EU
-#define PW_WAVES_PER_EU 2
+#define PW_WAVES_PER_EU 4
 #endif
 #define PW_OCC __attribute__((amdgpu_waves_per_eu(PW_WAVES_PER_EU, PW_WAVES_PER_EU)))
 struct PlChkEnv {
@@ -623,12 +647,9 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, S& s, int col, int row, ui
     }
 }
 
-// Expand bucket s.E (all threads). The relaxations of a bucket commute (atomicMin on distances and alias keys, queue
-// order is irrelevant), so how the (entry, neighbour) pairs are dealt to the threads changes nothing but the time:
-//   workgroup: one thread per pair (a bucket is a few hundred entries: 2 .. 5 rounds of 512 pairs);
-//   wave / pair of waves: one lane per ENTRY, its eight relaxations unrolled -- the lane's loads and atomics are independent and in
-//   flight together, 8 x fewer rounds of the latency-bound loop (the sweep from the goal to the start was 9 .. 26 M
-//   cycles per problem in the wave form, an eighth of a capped search).
+// Expand bucket s.E (all threads). Each thread handles (entry, neighbour) pairs.
+// (One lane per ENTRY with its eight relaxations unrolled -- 8 x fewer rounds of the loop for a single wave -- was
+// measured in the wave form: no gain at 8 waves per CU, 15 % slower at 16, where the unrolled body spills.)
 template <bool PROFILE, class Coop = CoopWG, class S>
 AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
 {
@@ -639,23 +660,6 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
     const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
     const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };      // y up = row down
     const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
-    if constexpr (Coop::N <= 128) {
-        for (uint32_t e = Coop::tid(); e < cnt; e += Coop::N) {
-            const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + e];
-            const uint32_t d = (uint32_t)(ent >> 32);
-            const int64_t id = (int64_t)(ent & 0xffffffffull);
-            if (w.dist[id] != d) continue;                    // stale entry (distance was lowered later)
-            if (w.flags[id] & PL_FLAG_T) continue;            // terminator: closed but never expanded
-            const uint32_t id32 = (uint32_t)id, row_u = id32 / (uint32_t)m.S;
-            int col = (int)(id32 - row_u * (uint32_t)m.S), row = (int)row_u;
-            if (s.alias && col == 0) {
-                if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
-            }
-            atomicAdd((unsigned long long*)&s.h_cells, 1ull);
-#pragma unroll
-            for (int nbr = 0; nbr < 8; nbr++) pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
-        }
-    } else {
     for (uint32_t p = Coop::tid(); p < cnt * 8u; p += Coop::N) {
         const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + (p >> 3)];
         const int nbr = (int)(p & 7);
@@ -671,7 +675,6 @@ AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
         }
         if (nbr == 0) atomicAdd((unsigned long long*)&s.h_cells, 1ull);
         pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
-    }
     }
     Coop::sync();
     if (Coop::tid() == 0) { s.qcount[q] = 0; s.E += 1; if constexpr (PROFILE) s.phase[PH_SWEEP] += clock64() - t_sw; }
@@ -981,8 +984,10 @@ AVP_D int pl_rs_fold_wave(PlShared& s, int q, RsPath& out)
 //   pl_rs_sample_book    -- the index bookkeeping: which sample lies at which arc length of which segment;
 //   pl_rs_sample_origins -- the chain of segment origins (end pose of the previous segment).
 // They touch disjoint state, so two waves run them side by side.
+// Returns 0, or 5 when the shot has more samples than the form's buffers hold (the caller stores it: in the pair form
+// another wave may be reading s.rs_status meanwhile).
 template <class S>
-AVP_D void pl_rs_sample_book(S& s, const avp_params& p)
+AVP_D int pl_rs_sample_book(S& s, const avp_params& p)
 {
     const double maxc = p.maxc;
     const RsPath& rp = s.rs;
@@ -990,7 +995,7 @@ AVP_D void pl_rs_sample_book(S& s, const avp_params& p)
     const int point_num = (int)(rp.L / step) + rp.n + 3;
     s.smp_point_num = point_num;
     s.smp_hi = 0;
-    if (point_num > S::RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) { s.rs_status = 5; return; }
+    if (point_num > S::RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) return 5;
     int ind = 1, hi = 0;
     double d = rp.l[0] > 0.0 ? step : -step;
     double pd = d, ll = 0.0;
@@ -1010,6 +1015,7 @@ AVP_D void pl_rs_sample_book(S& s, const avp_params& p)
         if (ind > hi) hi = ind;
     }
     s.smp_hi = hi;
+    return 0;
 }
 template <class S>
 AVP_D void pl_rs_sample_origins(S& s, const avp_params& p)
@@ -1492,7 +1498,7 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
         size_t ri = pl_look_idx(pid, maxNodes, node, 0);
         uint32_t st = 0;
         if (lane == 0) {
-            st = pl_ld32(look.state + ri);
+            st = PL_FLAG_LD32(look.state + ri);
             if ((st & 6u) != 6u && !(st & 1u)) {
                 const PlNode& nn = w.nodes[node];
                 if (nn.parent_pos >= 0) {
@@ -1500,14 +1506,14 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
                     const int d = (int)nn.steer_i - (int)pp.steer_i;
                     if (pp.steer_i >= 0 && nn.forward == pp.forward && d >= -PL_LOOK_KSPAN && d <= PL_LOOK_KSPAN) {
                         ri = pl_look_idx(pid, maxNodes, nn.parent_pos, 1 + PL_LOOK_KSPAN + d);
-                        st = pl_ld32(look.state + ri);
+                        st = PL_FLAG_LD32(look.state + ri);
                         s.n_sec[(st & 6u) == 6u ? 2 : (st & 1u)] += 1;
                     }
                 }
             }
             if (PL_LOOK_WAIT > 0 && wait && s.look_calm && (st & 1u) && (st & 6u) != 6u) {
                 const long long t0 = clock64();
-                while ((st & 6u) != 6u && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = pl_ld32(look.state + ri); }
+                while ((st & 6u) != 6u && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = PL_FLAG_LD32(look.state + ri); }
                 s.n_sec[3] += 1;
             }
         }
@@ -1524,7 +1530,7 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
             const bool r_in = fl & 1ull, r_err = (fl >> 8) & 0xffull, r_hit = (fl >> 1) & 1ull;
             // (a record whose shot failed to solve or came out collision free is not used: that pop takes the long way)
             ok = rec[80] == pl_bits(nn.x) && rec[81] == pl_bits(nn.y) && rec[82] == pl_bits(nn.th) &&
-                 rec[83] == (unsigned long long)pid && rec[86] == pl_bits(s.goal[0]) && rec[87] == pl_bits(s.goal[1]) &&
+                 rec[83] == pl_look_key3(pid, s.goal[2]) && rec[86] == pl_bits(s.goal[0]) && rec[87] == pl_bits(s.goal[1]) &&
                  !(r_in && (r_err || !r_hit));
         }
     }
@@ -1593,9 +1599,9 @@ __device__ __forceinline__ void pl_ring_post2(const PlLook& look, int lane, bool
         const unsigned long long bx = pl_bits(x), by = pl_bits(y), bt = pl_bits(th), g0 = pl_bits(goal[0]), g1 = pl_bits(goal[1]), g2 = pl_bits(goal[2]);
         pl_st64(e0 + 0, w0); pl_st64(e0 + 1, bx); pl_st64(e0 + 2, by); pl_st64(e0 + 3, bt); pl_st64(e0 + 4, g0); pl_st64(e0 + 5, g1); pl_st64(e0 + 6, g2);
         pl_st64(e1 + 0, w0); pl_st64(e1 + 1, bx); pl_st64(e1 + 2, by); pl_st64(e1 + 3, bt); pl_st64(e1 + 4, g0); pl_st64(e1 + 5, g1); pl_st64(e1 + 6, g2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pl_st64(e0 + 7, t0 + k + 1ull);
-        pl_st64(e1 + 7, t1 + k + 1ull);
+        PL_LOOK_DRAIN();
+        PL_FLAG_ST64(e0 + 7, t0 + k + 1ull);
+        PL_FLAG_ST64(e1 + 7, t1 + k + 1ull);
     }
 }
 // Owner side of the lookahead: one wave posts, in ONE round (one look at the ring counters, one ticket range per ring,
@@ -1631,7 +1637,9 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     const unsigned long long helpers = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
     const long long backlog = max((long long)(ta - ha), (long long)(tb - hb));
     if (lane == 0) { s.look_calm = (helpers != 0 && backlog <= PL_LOOK_BACKLOG) ? 1 : 0; s.look_live = helpers != 0 ? 1 : 0; }   // (calm: the helpers keep up, a pending record is worth a short wait)
-    if (helpers == 0 || backlog > PL_JCAP - 4096) return;       // nobody to serve / a ring is full
+    // nobody to serve / a ring is nearly full: every owner may post up to PL_LOOK_TOP + PL_LOOK_KIDS jobs from the same (stale)
+    // reading of the counters, so the margin is several times owners x jobs (256 x 19 = 4 864) -- an unread entry is never overwritten
+    if (helpers == 0 || backlog > PL_JCAP - 16384) return;
     if (backlog > PL_LOOK_BACKLOG && lane >= 32) want = false;
     double x = 0.0, y = 0.0, th = 0.0;
     unsigned long long w0 = 0;
@@ -1792,7 +1800,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         const unsigned long long* e = look.jobs + ((size_t)hk * PL_JCAP + (size_t)(ticket & (PL_JCAP - 1))) * PL_JOB_WORDS;
                         int got = 0;
                         for (int spin = 0; spin < (1 << 23); spin++) {
-                            const unsigned long long seq = pl_ld64(e + 7);
+                            const unsigned long long seq = PL_FLAG_LD64(e + 7);
                             if (seq == ticket + 1ull) { got = 1; break; }
                             if (seq > ticket + 1ull) { got = 2; break; }
                             if (pl_ld64(look.ctrl + 32) >= (unsigned long long)n) break;
@@ -1977,7 +1985,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                                 if (!st) s.rs = rp;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 *(volatile int32_t*)&s.shot_ready = shot ? 1 : 2;
-                                if (shot) { s.n_rs += 1; pl_rs_sample_book(s, p); }
+                                if (shot) { s.n_rs += 1; const int bs = pl_rs_sample_book(s, p); if (bs) s.rs_status = bs; }
                                 if (PROFILE) PH_X(5, t_a0);
                             }
                         }
@@ -2112,16 +2120,17 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     }
                     if (lane == 63) {
                         // (the key words are written by both halves, with the same values)
-                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, (unsigned long long)PL_JOB_PID(j0));
+                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, pl_look_key3(PL_JOB_PID(j0), pl_unbits(s.job[6])));
                         pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
                         if (hS) {
                             pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
                             pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
                         }
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PL_LOOK_DRAIN();
                     wave_sync();
-                    if (lane == 0) { atomicOr(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
+                    if (lane == 0) { PL_FLAG_OR32(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
+                    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % PL_LOOK_FAULT == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
                 }
                 continue;
             }

@@ -1,5 +1,5 @@
 // avp_planw_kernels.h -- batched hybrid-A* planner, THROUGHPUT forms: NW waves = one (start, goal) problem (NW = 1: the
-// wave form, NW = 2: the pair form), PW_WAVES / NW independent problems per workgroup, persistent groups of waves pull
+// wave form, NW = 2: the pair form, NW = 4: the quad form), PW_WAVES / NW independent problems per workgroup, persistent groups of waves pull
 // problems from a global counter.
 //
 // plan_kernel (avp_plan_kernels.h) spends a whole 512-thread workgroup on one problem to shorten a pop's critical
@@ -31,14 +31,14 @@
 #include "avp_plan_kernels.h"
 
 #ifndef PW_WAVES
-#define PW_WAVES 8                    // problems (waves) per workgroup = per CU
+#define PW_WAVES 16                   // waves per workgroup = per CU: 16 / NW problems in flight per CU (4 waves per SIMD: 128 VGPRs each)
 #endif
 #define PW_THREADS (64 * PW_WAVES)
 #ifndef PW_RS_CAP
-#define PW_RS_CAP 256                 // samples of one RS shot held per wave
+#define PW_RS_CAP 192                 // samples of one RS shot held per group (96 m of path; longer shots go to plan_kernel)
 #endif
 #ifndef PW_WQCAP
-#define PW_WQCAP 1024                 // (pose, point) candidates of one collision pass; more fall back to the lane-per-pose walk
+#define PW_WQCAP 512                  // (pose, point) candidates of one collision range; a range that overflows is halved
 #endif
 #define PW_MAXCHILD 16
 #define PW_RSQ (PW_MAXCHILD + 1)      // RS queries per pop: the shot + the children
@@ -86,8 +86,10 @@ struct PwCommon {
     const double* starts; const double* goals;
     avp_plan_result_dev* results;
     double* paths; double* trace;
-    int32_t max_path, max_trace, maxNodes, nchild, nsubs, pad;
-    int64_t max_pops;
+    int32_t max_path, max_trace, maxNodes, nchild, nsubs, retry_only;
+    int64_t max_pops;                 // the caller's pop cap (status ITER_LIMIT)
+    int64_t stage_pops;               // > 0: a search still running after this many pops is handed back (AVP_PLAN_RETRY)
+    unsigned int* deferred;           // ... and counted here
 };
 
 // The waves that cooperate on one problem. NW = 1: one wave (wave-level syncs only). NW > 1: NW adjacent waves of the
@@ -156,7 +158,7 @@ struct PwSharedT {
     int32_t next_cur, have_next;
     // per group, set once / per pop
     PlanWs w;                                  // this group's workspace slot
-    int32_t slot, can_fast, n_passes, n_todo;
+    int32_t slot, can_fast, n_passes, n_todo, book_status, pad2;
     int64_t n_pops;
     PlNode cn;                                 // the node being expanded (copy of its arena record)
     int32_t nq, rsq[PW_RSQ];                   // the Reeds-Shepp queries of this pop: 0 = the shot, 1 + i = child i
@@ -323,7 +325,9 @@ __device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
         s.E = 0; s.h_cells = 0; s.h_misses = 0;
     }
     G::sync();
-    if (s.status == 0) pl_sweep_init<G>(m, w, s, c.dims, gx, gy);
+    const bool go = s.status == 0;
+    G::sync();                      // (pl_sweep_init's first lane may set the status: every wave has read it by now)
+    if (go) pl_sweep_init<G>(m, w, s, c.dims, gx, gy);
     if (s.status == 0) {
         // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
         const int64_t sid = avp_pos_to_index(m, sx, sy);
@@ -354,6 +358,7 @@ __device__ __noinline__ void pw_ph_pop(PW_PHASE_ARGS)
         if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }
         else if (s.nheap == 0) { s.status = 1; }
         else if (s.n_pops >= c.max_pops) { s.status = 4; }
+        else if (c.stage_pops > 0 && s.n_pops >= c.stage_pops) { s.status = AVP_PLAN_RETRY; }
         else {
             const uint32_t cc = pl_heap_pop(w, s);
             s.cur = (int32_t)cc;
@@ -507,20 +512,22 @@ __device__ __noinline__ void pw_ph_shot(PW_PHASE_ARGS)
     PW_PHASE_REFS;
     const avp_params& p = c.p;
     const PlanWs& w = s.w;
-    if (s.rs_status) { if (gtid == 0) s.status = 3; G::sync(); return; }       // (no Reeds-Shepp path / the reference's assertion)
+    // (s.rs_status was set by the previous phase and is not written in this one: every wave of the group reads the same value)
+    if (s.rs_status) { if (gtid == 0) s.status = 3; G::sync(); return; }       // no Reeds-Shepp path / the reference's assertion
     // the sampler's index bookkeeping (one lane) beside the chain of segment origins (a wave)
-    if (gtid == 0) pl_rs_sample_book(s, p);
+    if (gtid == 0) s.book_status = pl_rs_sample_book(s, p);
     if (wv == (NW > 1 ? 1 : 0)) pl_rs_sample_origins(s, p);
     G::sync();
-    if (s.rs_status) { if (gtid == 0) s.status = (s.rs_status == 4 || s.rs_status == 5) ? AVP_PLAN_RETRY : 3; G::sync(); return; }
+    if (s.book_status) { if (gtid == 0) s.status = AVP_PLAN_RETRY; G::sync(); return; }      // more samples than this form holds
     const PlNode cn = s.cn;
     const int total = s.smp_hi + 1;
     double cm, sm;
     avp_sincos(-cn.th, sm, cm);
     for (int base = wv * PL_WPOSE; base < total; base += NW * PL_WPOSE) {
-        // stop at the first colliding sample -- unless it may lie in the trailing px == 0.0 tail the reference pops
+        // stop once a colliding sample BEFORE this chunk is known (the chunks of the other waves included: a hit in a later
+        // chunk does not excuse this one) -- unless it may lie in the trailing px == 0.0 tail the reference pops
         // (rs_curve.py:588-592): that is only known once every sample has been produced, so keep going then
-        { const int fc = *(volatile int32_t*)&s.rs_first_coll; if (fc != 0x7fffffff && fc < *(volatile int32_t*)&s.rs_npts) break; }
+        { const int fc = *(volatile int32_t*)&s.rs_first_coll; if (fc < base && fc < *(volatile int32_t*)&s.rs_npts) break; }
         const int cnt = min(PL_WPOSE, total - base);
         if constexpr (PROFILE) { if (lane == 0) atomicAdd(&s.phase[PW_PH_NPASS], 1u); }
         double tx = 0.0, ty = 0.0, tth = 0.0;
@@ -555,7 +562,7 @@ __device__ __noinline__ void pw_ph_resolve_fast(PW_PHASE_ARGS)
         wave_sync();
         if (s.can_fast) {
             const PlNode cn = s.cn;
-            pl_resolve_fast_wave<false>(c.m, c.p, s.w, s, c.dims, cn, c.nchild, s.n_pops < c.max_pops);
+            pl_resolve_fast_wave<false>(c.m, c.p, s.w, s, c.dims, cn, c.nchild, s.n_pops < c.max_pops && !(c.stage_pops > 0 && s.n_pops >= c.stage_pops));
         }
     }
     G::sync();
@@ -659,7 +666,7 @@ __device__ __noinline__ void pw_ph_finish(PW_PHASE_ARGS)
         G::sync();
     }
     if (gtid == 0) {
-        if (s.status == AVP_PLAN_RETRY) { c.results[s.pid].status = AVP_PLAN_RETRY; }
+        if (s.status == AVP_PLAN_RETRY) { c.results[s.pid].status = AVP_PLAN_RETRY; if (c.deferred) atomicAdd(c.deferred, 1u); }
         else pl_write_result<false>(p, w, s, c.k_travel_ddt, c.k_dth_ddt, c.results, c.paths, c.max_path, s.pid, s.n_pops, s.slot, 0ll);
     }
     G::sync();
@@ -672,9 +679,13 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
                                                                avp_plan_result_dev* __restrict__ results,
                                                                double* __restrict__ paths, int32_t max_path,
                                                                double* __restrict__ trace, int32_t max_trace,
-                                                               const int32_t* __restrict__ order)
+                                                               const int32_t* __restrict__ order, int32_t stage_pops, int32_t retry_only,
+                                                               unsigned int* __restrict__ deferred, int32_t gate_lo, int32_t gate_hi)
 {
     typedef PwGroup<NW> G;
+    // second stage of a staged call (retry_only with a gate): the host launches every form, the one whose range
+    // (gate_lo, gate_hi] holds the number of searches the first stage handed back plans them, the others end here
+    if (retry_only && gate_hi > 0) { const unsigned int d = *(volatile unsigned int*)deferred; if (d <= (unsigned int)gate_lo || d > (unsigned int)gate_hi) return; }
     static_assert(PW_WAVES % NW == 0, "groups of NW adjacent waves");
     avp_lds_tables_fill<true>();
     rs_lds_tables_fill();
@@ -691,8 +702,9 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
         if (tid == 0) {
             c.m = m; c.p = p; c.dims = dims;
             c.starts = starts; c.goals = goals; c.results = results; c.paths = paths; c.trace = trace;
-            c.max_path = max_path; c.max_trace = max_trace; c.maxNodes = maxNodes; c.nchild = 2 * p.n_steer; c.nsubs = 2 * p.n_steer * p.n_sub; c.pad = 0;
+            c.max_path = max_path; c.max_trace = max_trace; c.maxNodes = maxNodes; c.nchild = 2 * p.n_steer; c.nsubs = 2 * p.n_steer * p.n_sub; c.retry_only = retry_only;
             c.max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
+            c.stage_pops = stage_pops; c.deferred = retry_only ? nullptr : deferred;
         }
         if (tid < PW_WAVES) { PW_BAR_CNT[tid] = 0; PW_BAR_GEN[tid] = 0; }
     }
@@ -726,6 +738,7 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
         if (gtid == 0) { const uint32_t t = atomicAdd(counter, 1u); s.pid = (int64_t)t < n ? (order ? order[t] : (int32_t)t) : 0x7fffffff; }
         G::sync();
         if (s.pid >= n) break;
+        if (retry_only && results[s.pid].status != AVP_PLAN_RETRY) continue;      // (second stage: only what the first handed back)
         long long t_ph = PROFILE ? clock64() : 0ll;
         if constexpr (PROFILE) { if (gtid == 0) for (int k = 0; k < PW_PH_COUNT; k++) s.phase[k] = 0; }
         pw_ph_init<NW>(sp, cp);

@@ -157,6 +157,87 @@ def all_gather_rows(local, out=None):
     return out
 
 
+# ---- the two-stage deal (bench.py --gpus N) ------------------------------------------------------------------
+# The start-goal distance does not predict the length of a search (measured: DESIGN.md), and a fifth of the random pose
+# pairs hold 95 % of a batch's expansions, so a static deal by distance leaves the slowest rank ~15 % above the mean at
+# 8 ranks. The staged planner already separates the two kinds of searches; across GPUs its stages become:
+#   stage 1  every rank runs the first stage (wave form, stage_pops pops) on the index slice [rank::world];
+#            one all-gather of the fixed-stride records and paths -- four searches out of five are final here;
+#   stage 2  the searches still running (status AVP_PLAN_DEFERRED), in index order, are dealt round-robin -- they are
+#            the long ones, every rank gets the same number of them --, planned from scratch, and all-gathered.
+# Row (w, j) of a gathered block is problem j * world + w of the dealt list, so the merge is a permute + one index_copy.
+DEFERRED = 100
+
+
+def deal_slice(n: int, rank: int, world: int):
+    """Indices [rank::world] of a list of n, padded with -1 to per = ceil(n / world)."""
+    per = (n + world - 1) // world
+    idx = np.arange(rank, n, world, dtype=np.int64)
+    return np.concatenate([idx, -np.ones(per - len(idx), np.int64)]), per
+
+
+def take_padded(starts, goals, idx):
+    """Problems idx (−1 = padding: a start == goal problem, which ends at once with status RS_ERROR)."""
+    safe = np.where(idx >= 0, idx, 0)
+    s_l, g_l = np.array(starts[safe], dtype=np.float64), np.array(goals[safe], dtype=np.float64)
+    s_l[idx < 0] = g_l[idx < 0] = goals[0]
+    return np.ascontiguousarray(s_l), np.ascontiguousarray(g_l)
+
+
+def gathered_in_list_order(g, count: int):
+    """(world, per, ...) gathered block -> the first `count` rows in dealt-list order (row (w, j) = item j * world + w)."""
+    return g.transpose(0, 1).reshape((-1,) + tuple(g.shape[2:]))[:count]
+
+
+def record_status(rec_t):
+    """int32 status column of a (k, stride) uint8 record tensor (avp_plan_result.status is the first field)."""
+    import torch
+    return rec_t[:, :4].contiguous().view(torch.int32).reshape(-1)
+
+
+def two_stage_plan(stage1, stage2, starts, goals, rank: int, world: int):
+    """One step of the two-stage deal. stage1 / stage2: callables (starts (k,3), goals (k,3)) -> (records (k, stride)
+    uint8 tensor, paths (k, max_path, 4) float64 tensor) on the communication device; stage1 leaves the searches it does
+    not finish with status DEFERRED. Returns (records (n, stride), paths (n, max_path, 4), deferred indices (numpy)) on
+    every rank, in problem order."""
+    import torch
+    starts = np.asarray(starts, dtype=np.float64).reshape(-1, 3)
+    goals = np.asarray(goals, dtype=np.float64).reshape(-1, 3)
+    n = len(starts)
+    idx1, _ = deal_slice(n, rank, world)
+    r1, p1 = stage1(*take_padded(starts, goals, idx1))
+    rec = gathered_in_list_order(all_gather_rows(r1), n).contiguous()
+    paths = gathered_in_list_order(all_gather_rows(p1), n).contiguous()
+    deferred_t = (record_status(rec) == DEFERRED).nonzero().reshape(-1)
+    deferred = deferred_t.cpu().numpy()                       # (the one host synchronisation of the step: stage 2's shape)
+    nd = len(deferred)
+    if nd:
+        idx2, _ = deal_slice(nd, rank, world)
+        share = np.where(idx2 >= 0, deferred[np.where(idx2 >= 0, idx2, 0)], -1)
+        r2, p2 = stage2(*take_padded(starts, goals, share))
+        rec.index_copy_(0, deferred_t, gathered_in_list_order(all_gather_rows(r2), nd))
+        paths.index_copy_(0, deferred_t, gathered_in_list_order(all_gather_rows(p2), nd))
+    return rec, paths, deferred
+
+
+def simulate_deals(n_pops, status, starts, goals, stage_pops: int, worlds=(2, 4, 8)):
+    """Predicted load of the busiest rank relative to the mean (max / mean - 1) from the per-problem pop counts of a
+    finished run, for the deal by decreasing start-goal distance (`shard_indices`) and for the two-stage deal."""
+    n_pops = np.asarray(n_pops, dtype=np.float64)
+    out = {}
+    n = len(n_pops)
+    for w in worlds:
+        by_dist = [n_pops[shard_indices(starts, goals, r, w)].sum() for r in range(w)]
+        deferred = np.where(n_pops > stage_pops)[0]
+        s1 = [np.minimum(n_pops[np.arange(r, n, w)], stage_pops).sum() for r in range(w)]
+        s2 = [n_pops[deferred[r::w]].sum() for r in range(w)]
+        two = [a + b for a, b in zip(s1, s2)]
+        out[str(w)] = {"by_distance_imbalance": float(max(by_dist) / np.mean(by_dist) - 1.0),
+                       "two_stage_imbalance": float(max(two) / np.mean(two) - 1.0),
+                       "two_stage_extra_pops_frac": float((sum(two) - n_pops.sum()) / n_pops.sum())}
+    return out
+
+
 def plan_sharded(plan_fn: Callable[[np.ndarray, np.ndarray], np.ndarray], starts, goals, dst: int = 0, device=None):
     """Run `plan_fn(starts_shard, goals_shard) -> (k, stride) float64 records` on this rank's shard
     and gather to rank dst. The result is identical for every world size (shard invariance)."""

@@ -22,7 +22,9 @@ from . import collision_check
 from .costmap import Map, Vehicle
 from .rs_curve import PATH, path_from_arrays
 
-STATUS_NAMES = {0: "OK", 1: "NO_PATH", 2: "H_UNREACHABLE", 3: "RS_ERROR", 4: "ITER_LIMIT", 5: "CAPACITY", 6: "LATTICE"}
+STATUS_NAMES = {0: "OK", 1: "NO_PATH", 2: "H_UNREACHABLE", 3: "RS_ERROR", 4: "ITER_LIMIT", 5: "CAPACITY", 6: "LATTICE",
+                100: "DEFERRED"}       # (DEFERRED: only from the first stage of a staged call run on its own, BatchPlanner.plan_dev(first_stage_only=True))
+STAGED = 16                           # BatchPlanner mode: avp_plan_batch_staged
 
 
 class AvpPlanResult(C.Structure):
@@ -76,9 +78,12 @@ class BatchPlanner:
 
     def __init__(self, device_map: _native.DeviceMap, max_nodes: int = 65536, n_slots: Optional[int] = None,
                  max_path: int = 512, mode: int = 0, lookahead: Optional[bool] = None,
-                 longest_first: bool = False):
-        """mode: 0 = the library's choice by batch size, 1 = one workgroup per problem, 2 = one wave per problem
-        (include/avp.h: avp_plan_batch_mode). n_slots: problem slots (default: what the chosen form can keep busy).
+                 longest_first: bool = False, stage_pops: int = 16):
+        """mode: 0 = the library's choice by batch size, 1 = one workgroup per problem, 2 = one wave, 3 = a pair of waves,
+        4 = four waves per problem (include/avp.h: avp_plan_batch_mode), STAGED = avp_plan_batch_staged: every problem in
+        the wave form for stage_pops pops, the searches still running then planned again in the form that suits their
+        number (same results, the shortest time for batches of a few to a few dozen problems per CU).
+        n_slots: problem slots (default: what the chosen form can keep busy).
         lookahead: let the compute units without a problem of their own pre-compute node expansions for the running
         searches (avp_plan_batch_ex; results are identical either way). None = when the library wants it for the batch
         and its record store fits LOOK_BYTES_MAX, True = whenever the library supports it, False = never.
@@ -97,20 +102,40 @@ class BatchPlanner:
         self._ws_slots = 0
         self.lookahead = lookahead
         self.longest_first = bool(longest_first)
+        self.stage_pops = int(stage_pops)
         self._look = None
         self.last_lookahead = False
 
     LOOK_BYTES_MAX = 24 << 30          # (512 problems x 16 384 nodes x 4 x 708 B = 23.8 GB of MI355X's 288)
+    LOOK_FREE_FRAC = 0.25              # ... and at most this share of the device memory that is free right now
 
     def _look_workspace(self, n):
+        """The lookahead's record store, or None. lookahead=None (the default) is conservative: never for a single problem
+        (a lone a_star_plan() leaves the other compute units to whoever else uses the device: the helpers would park a
+        spinning workgroup on each), never when the store would take more than LOOK_BYTES_MAX or LOOK_FREE_FRAC of the
+        free device memory, and an allocation failure falls back to planning without it. lookahead=True asks for it
+        whenever the library supports it for the batch (and raises if the store cannot be allocated)."""
         if self.lookahead is False:
             return None
         nbytes = int(_native.lib().avp_plan_look_bytes(self.dm.h, C.c_int64(n), C.c_int32(self.max_nodes)))
-        if nbytes <= 0 or (self.lookahead is None and nbytes > self.LOOK_BYTES_MAX):
+        if nbytes <= 0:
             return None
-        if self._look is None or self._look.numel() < nbytes:
+        have = self._look is not None and self._look.numel() >= nbytes
+        if self.lookahead is None:
+            if n < 2 or nbytes > self.LOOK_BYTES_MAX:
+                return None
+            if not have:
+                free, _ = self.dm.torch.cuda.mem_get_info(self.dm.device)
+                if nbytes > self.LOOK_FREE_FRAC * free:
+                    return None
+        if not have:
             self._look = None
-            self._look = self.dm.empty(nbytes, self.dm.torch.uint8)
+            try:
+                self._look = self.dm.empty(nbytes, self.dm.torch.uint8)
+            except self.dm.torch.cuda.OutOfMemoryError:
+                if self.lookahead is True:
+                    raise
+                return None
         return self._look
 
     def _workspace(self, slots):
@@ -123,15 +148,31 @@ class BatchPlanner:
             self._ws_slots = slots
         return self._ws
 
-    def plan_dev(self, starts_t, goals_t, want_paths=True, max_trace: int = 0, profile: bool = False):
+    def plan_dev(self, starts_t, goals_t, want_paths=True, max_trace: int = 0, profile: bool = False, first_stage_only: bool = False):
         """starts_t/goals_t: (n,3) float64 CUDA tensors. Asynchronous; returns device tensors
         (results as uint8 (n, sizeof result), paths (n, max_path, 3) or None, trace or None).
-        profile=True runs the instrumented kernel (phase_cycles filled)."""
+        profile=True runs the instrumented kernel (phase_cycles filled). first_stage_only (STAGED mode): stop after the
+        first stage; unfinished searches carry status 100 (DEFERRED)."""
         torch = self.dm.torch
         self.dm.use_current_stream()
         n = starts_t.shape[0]
         L = _native.lib()
-        mode = (self.mode if self.mode in (2, 3) else 1) if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode)))
+        if self.mode == STAGED and not profile:
+            grp = int(L.avp_plan_group(C.c_int32(2)))
+            cap = self.n_slots if self.n_slots else int(L.avp_plan_slots(self.dm.h, C.c_int32(2)))
+            slots = max(grp, min(cap, grp * ((n + grp - 1) // grp)))
+            ws = self._workspace(slots)
+            res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
+            paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
+            trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
+            self.last_lookahead = False
+            _native.chk(L.avp_plan_batch_staged(self.dm.h, C.c_void_p(starts_t.data_ptr()), C.c_void_p(goals_t.data_ptr()), C.c_int64(n), C.c_int32(slots),
+                                                C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
+                                                C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
+                                                C.c_void_p(trace.data_ptr()) if trace is not None else None, C.c_int32(max_trace),
+                                                C.c_int32(self.stage_pops), C.c_int32(1 if first_stage_only else 0), None), "avp_plan_batch_staged")
+            return res, paths, trace
+        mode = (self.mode if self.mode in (2, 3, 4) else 1) if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode if self.mode != STAGED else 0)))
         cap = self.n_slots if self.n_slots else int(L.avp_plan_slots(self.dm.h, C.c_int32(mode)))
         wg = int(L.avp_plan_group(C.c_int32(mode)))         # problems per workgroup of the kernel form
         slots = max(1, min(cap, wg * ((n + wg - 1) // wg)))
@@ -279,7 +320,7 @@ class PathPlanner:
         max_nodes, max_path = bp.max_nodes, bp.max_path
         while r.status == 5 and max_nodes < (1 << 22):
             max_nodes, max_path = 2 * max_nodes, 2 * max_path
-            big = BatchPlanner(bp.dm, max_nodes=max_nodes, n_slots=1, max_path=max_path)
+            big = BatchPlanner(bp.dm, max_nodes=max_nodes, n_slots=1, max_path=max_path, lookahead=False)
             r = big.plan([[c.x0, c.y0, c.theta0]], [[c.xf, c.yf, c.thetaf]])[0]
         self.planner.open_list._n = int(r.counters.get("n_open", 0))
         if r.status in (0, 1):
@@ -297,7 +338,12 @@ class PathPlanner:
         return final_path, astar_path, rs_path
 
     def split_path(self, final_path: List[List]) -> Tuple[List[List[List]], int]:
-        return split_path(final_path, self.config, self.vehicle, self.collision_checker)
+        # (through the batch form: every extension pose of the path in ONE check launch instead of a synchronous
+        # upload + launch + download per pose; same segments -- tests/test_gpu_split.py runs both against the goldens)
+        out = split_path_batch([final_path], self.config, self.vehicle, self.collision_checker)[0]
+        if isinstance(out, Exception):
+            raise out
+        return out
 
     def path_planning(self) -> Tuple[List[List], Dict, List[List[List]]]:
         final_path, astar_path, rs_path = self.a_star_plan()

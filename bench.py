@@ -4,15 +4,19 @@
 A "step" = one pass of the hot path over one batch of problems, inputs resident in HBM.
 
   N = 1 : headline = BASELINE config[1] (Case1 map, 256 random start/goal pairs, pop cap 1000); extras on the same GPU:
-          `batch4096` (north_star's 4 096-pose target workload), `c3` (20 BenchmarkCases x 128), `c5` (dense clutter, RS
-          shot at every pop), the footprint kernel alone, and the CPU port timed on the host.
-  N > 1 : SURVEY 8(e), strong scaling of ONE fixed 4 096-problem set on the Case1 map: rank 0 samples the problems,
-          the map blob and the problems are broadcast (RCCL, untimed set-up), every rank plans the shard that
-          `shard_indices` deals it, and the timed step ends with the all-gather of the result records AND the solved
-          paths (fixed stride max_path x 4 doubles) -- the only data-path collectives. Rank 0 then checks the gathered
-          result against its own single-GPU run of the whole set (shard invariance).
-          AVP_BENCH_FORCE_DIST=1 runs exactly this code path with world size 1 (through RCCL).
-  --workload c3 with N > 1: every rank holds all 20 maps, each map's 128 problems are dealt the same way.
+          `batch4096` (north_star's 4 096-pose target workload, every kernel form and the staged call), `scale_point` (the
+          same 4 096 set as the N > 1 runs plan it, with the predicted rank loads of both deals), `c3` (20 BenchmarkCases x
+          128), `c5` (dense clutter, RS shot at every pop), `saturating_batch`, `cap_sweep`, `cases20` (the 20
+          BenchmarkCases' own problems, run to termination), `single_plan_latency_ms`, the footprint kernel alone, and
+          the CPU port timed on the host.
+  N > 1 : SURVEY 8(e), strong scaling of the SAME 4 096-problem set on the Case1 map: rank 0 samples the problems, the
+          map blob and the problems are broadcast (RCCL, untimed set-up), and the timed step is the two-stage deal of
+          automatedvaletparking_amd.distributed.two_stage_plan -- every rank runs the first stage (wave form, 16 pops) on
+          its index slice, one all-gather of the records and paths, the searches still running are dealt round-robin
+          (they are the long ones), planned, and all-gathered: the only data-path collectives. After the timed steps
+          rank 0 plans the whole set alone, timed: `speedup_vs_1gpu`, `parallel_efficiency`, and the shard-invariance
+          check (`shard_invariant`). AVP_BENCH_FORCE_DIST=1 runs exactly this code path with world size 1 (through RCCL).
+  --workload c3 with N > 1: every rank holds all 20 maps, each map's 128 problems are dealt by index slice.
 
 `value` counts COMPLETED searches only (status OK / NO_PATH); problems stopped by the pop cap (ITER_LIMIT; the reference
 has no cap and needs hours on them, DESIGN.md "Workload") are excluded from the numerator and reported separately.
@@ -36,10 +40,19 @@ sys.path.insert(0, ROOT)
 POP_CAP = 1000
 MAX_NODES = 16384
 MAX_PATH = 256
+STAGE_POPS = 16                 # first-stage budget of the staged call / the two-stage deal
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 N_SIMD = 256 * 4                # SIMDs on the chip
 CLOCK_GHZ = 2.4                 # max shader clock
+FP64_PEAK_TFLOPS = 78.6         # vector fp64: 256 CUs x 128 flop/clk x 2.4 GHz
+PMC_FILE = "r03_pmc_summary.json"
 CASES = os.path.join(ROOT, "data", "BenchmarkCases")
+# the reference's own wall-clock per case (unmodified reference imported in the build container,
+# one Python thread): seconds for PathPlanner() + a_star_plan(); None = did not finish / raises
+REFERENCE_SECONDS = {1: 52.3, 2: 198.4, 3: 81.7, 4: 70.0, 5: 267.9, 6: 170.9, 7: None, 8: None, 9: 544.7, 10: 1266.6, 11: 1191.7, 12: 728.2, 13: 805.1,
+                     14: 110.7, 15: 105.7, 16: 47.6, 17: 12.45, 18: 205.4, 19: None, 20: None}
+FORM_NAMES = {1: "one workgroup per problem", 2: "one wave per problem", 3: "a pair of waves per problem", 4: "four waves per problem",
+              16: "staged (wave form for %d pops, then the form that suits the number of searches left)" % STAGE_POPS}
 
 
 def source_hash():
@@ -53,24 +66,38 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 class Group:
     """One map + its problems on this rank's GPU."""
 
-    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP, mode=0):
+    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP, mode=0, lookahead=None):
         import ctypes as C
         from automatedvaletparking_amd import _native, path_planner
         self.m = m
         self.dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=cap)
-        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=mode)
+        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=mode, lookahead=lookahead, stage_pops=STAGE_POPS)
         self.set_problems(starts, goals)
         L = _native.lib()
-        self.mode = int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(self.n), C.c_int32(mode)))      # 1 workgroup / 2 wave per problem
-        self.slots = int(L.avp_plan_slots(self.dm.h, C.c_int32(self.mode)))
+        # the kernel form that runs: 1 workgroup / 2 wave / 3 pair of waves / 4 four waves per problem, STAGED
+        self.mode = mode if mode == path_planner.STAGED else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(self.n), C.c_int32(mode)))
+        self.slots = int(L.avp_plan_slots(self.dm.h, C.c_int32(2 if self.mode == path_planner.STAGED else self.mode)))
 
     def set_problems(self, starts, goals):
         self.starts, self.goals = np.ascontiguousarray(starts), np.ascontiguousarray(goals)
         self.n = len(starts)
         self.st_t, self.go_t = self.dm.dev_tensor(self.starts), self.dm.dev_tensor(self.goals)
+
+    def plan(self, **kw):
+        return self.bp.plan_dev(self.st_t, self.go_t, want_paths=True, **kw)
 
 
 def plan_groups(groups):
@@ -78,8 +105,7 @@ def plan_groups(groups):
     chip each: every group gets its own HIP stream so that the launches overlap; the caller's stream waits for all."""
     import torch
     if len(groups) == 1:
-        g = groups[0]
-        return [g.bp.plan_dev(g.st_t, g.go_t, want_paths=True)]
+        return [groups[0].plan()]
     cur = torch.cuda.current_stream()
     outs = []
     for g in groups:
@@ -90,22 +116,10 @@ def plan_groups(groups):
             g.bp.lookahead = False
         g.stream.wait_stream(cur)
         with torch.cuda.stream(g.stream):
-            outs.append(g.bp.plan_dev(g.st_t, g.go_t, want_paths=True))
+            outs.append(g.plan())
     for g in groups:
         cur.wait_stream(g.stream)
     return outs
-
-
-def sample_pairs(m, dm, n_pairs, rng):
-    """SURVEY 8(d) sampler: footprint-free (HIP check kernel) poses outside every obstacle polygon, paired up."""
-    from automatedvaletparking_amd import sampling
-    free = []
-    while len(free) < 2 * n_pairs:
-        cand = sampling.sample_free_poses(m.boundary, m.case.obs, 8 * min(n_pairs, 512), rng, margin=6.0, reject=False)
-        hit = dm.check_batch(cand)
-        free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
-    poses = np.array(free[:2 * n_pairs])
-    return poses[0::2], poses[1::2]
 
 
 def records(res_t, n):
@@ -115,7 +129,7 @@ def records(res_t, n):
 
 def summarize(recs, n_slots, elapsed_per_step):
     """Throughput figures of one step over the given record arrays (one per group). n_slots: problem slots of the kernel
-    form that ran (CUs for one workgroup per problem, 8 x CUs for one wave per problem), or a list, one per group."""
+    form that ran, or a list, one per group."""
     if not isinstance(n_slots, (list, tuple)):
         n_slots = [n_slots] * len(recs)
     rec = np.concatenate(recs)
@@ -132,6 +146,13 @@ def summarize(recs, n_slots, elapsed_per_step):
             "expansions_per_s": pops / elapsed_per_step, "problems": int(len(rec)), "completed": int(done.sum()),
             "solved_frac": float((rec["status"] == 0).mean()), "iter_limit_frac": float((rec["status"] == 4).mean()),
             "slot_utilisation": float(util_num / max(util_den, 1)), "ms_per_step": elapsed_per_step * 1e3}
+
+
+def same_results(ra, pa, rb, pb):
+    """Two (records, paths) results of the same problem set are identical: every record field but the slot that ran the
+    problem and the diagnostics, and every way-point."""
+    ok = all(np.array_equal(ra[f], rb[f]) for f in ra.dtype.names if f not in ("slot", "phase_cycles"))
+    return bool(ok and all(np.array_equal(pa[i, :ra["n_final"][i]], pb[i, :ra["n_final"][i]]) for i in range(len(ra))))
 
 
 def main():
@@ -153,7 +174,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from automatedvaletparking_amd import costmap, config, sampling, _native, path_planner, distributed as avd
+    from automatedvaletparking_amd import costmap, config, _native, path_planner, workloads, distributed as avd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,38 +193,24 @@ def main():
     cfg = config.default_config()
     veh = costmap.Vehicle()
 
+    def checker(cap):
+        return lambda m: _native.DeviceMap(m, veh, cfg, device=local, max_pops=cap).check_batch
+
     # ---- problem sets (rank 0 builds and samples; the others receive) ------------------------------------------------
     def build(name):
-        """-> (label, cfg, cap, [(Map, starts, goals)]) on rank 0; maps None elsewhere."""
+        """-> (label, cfg, cap, [(Map, starts, goals)]) (automatedvaletparking_amd/workloads.py holds the definitions)."""
         if name in ("c2", "batch4096"):
             n = 256 if name == "c2" else 4096
-            m = costmap.Map(file=os.path.join(CASES, "Case1.csv"), discrete_size=cfg["map_discrete_size"])
-            dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=POP_CAP)
-            st, go = sample_pairs(m, dm, n, np.random.default_rng(20260927))
+            m, st, go = workloads.case1_pairs(cfg, checker(POP_CAP), n)
             label = ("Case1 map, 256 random start/goal pairs (config[1]), pop cap 1000" if name == "c2" else
                      "Case1 map, 4096 random start/goal pairs (north_star target batch), pop cap 1000")
             return label, cfg, POP_CAP, [(m, st, go)]
         if name == "c3":
-            out = []
-            for k in range(1, 21):
-                m = costmap.Map(file=os.path.join(CASES, f"Case{k}.csv"), discrete_size=cfg["map_discrete_size"], device="cuda")
-                dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=300)
-                st, go = sample_pairs(m, dm, 128, np.random.default_rng(20260927 + k))
-                out.append((m, st, go))
+            out = [workloads.c3_map_pairs(k, cfg, checker(300), 128, device="cuda") for k in range(1, 21)]
             return "all 20 BenchmarkCases x 128 random pairs (config[2]), pop cap 300", cfg, 300, out
         if name == "c5":
-            import tempfile
-            obs, goal, aisle = sampling.parking_lot_map()
-            with tempfile.TemporaryDirectory() as td:
-                pth = os.path.join(td, "c5.csv")
-                sampling.write_tpcap_csv(pth, (aisle[0] + 8.0, 0.5 * (aisle[2] + aisle[3]), 0.0), goal, obs)
-                m = costmap.Map(file=pth, discrete_size=cfg["map_discrete_size"], device="cuda")
-            c5 = dict(cfg)
-            c5["flag_radius"] = 1e9
-            rng = np.random.default_rng(5)
-            starts = np.stack([rng.uniform(m.boundary[0] + 4, m.boundary[1] - 4, 1024), rng.uniform(aisle[2] + 1.2, aisle[3] - 1.2, 1024),
-                               rng.choice([0.0, np.pi], 1024) + rng.normal(0, 0.05, 1024)], 1)
-            return "parking lot, 120 obstacles, 1024 starts, RS shot at every pop (config[4]), pop cap 300", c5, 300, [(m, starts, np.tile(np.array(goal), (1024, 1)))]
+            m, c5, starts, goals, _ = workloads.c5_problems(cfg, 1024, device="cuda")
+            return "parking lot, 120 obstacles, 1024 starts, RS shot at every pop (config[4]), pop cap 300", c5, 300, [(m, starts, goals)]
         raise ValueError(name)
 
     def timed_steps(step_fn, steps, warmup):
@@ -227,6 +234,16 @@ def main():
             el = float(tt.item())
         return el, out
 
+    def time_group(g, reps=2, **kw):
+        """(seconds per pass, last outputs) of one group alone on this GPU."""
+        g.plan(**kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = g.plan(**kw)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, o
+
     # ---- headline -----------------------------------------------------------------------------------------------------
     label, wcfg, cap, sets = build(workload) if rank == 0 else (None, None, None, None)
     if use_dist:
@@ -249,12 +266,12 @@ def main():
 
     ev_k = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps + a.warmup)]
     ev_i = [0]
+    extra_dist = {}
 
     if not use_dist:
         groups = [Group(m, veh, wcfg, st, go, local, cap) for (m, st, go) in groups_full]
 
         def step():
-            outs = []
             e0, e1 = ev_k[ev_i[0] % len(ev_k)]
             ev_i[0] += 1
             e0.record()
@@ -265,59 +282,76 @@ def main():
         elapsed, outs = timed_steps(step, a.steps, a.warmup)
         recs = [records(o[0], g.n) for o, g in zip(outs, groups)]
         shard_invariant = None
-        for g in groups:
-            g.kernel_form = g.mode
+        slots_all = [g.slots for g in groups]
     else:
-        # shard: problems dealt by decreasing start-goal distance; equal shard size (padded with start == goal problems)
-        groups, idxs, pers = [], [], []
+        # ---- the two-stage deal: stage 1 on the index slice, all-gather, the unfinished searches dealt evenly, all-gather --
+        planners = []
         for (m, st, go) in groups_full:
-            s_l, g_l, idx_pad, per = avd.shard_problems(st, go, rank, world)
-            groups.append(Group(m, veh, wcfg, s_l, g_l, local, cap))
-            idxs.append(idx_pad)
-            pers.append(per)
-        rec_stride = path_planner.RESULT_DTYPE.itemsize
-        gat_r = [torch.empty((world, per, rec_stride), dtype=torch.uint8, device=dev) for per in pers]
-        gat_p = [torch.empty((world, per, MAX_PATH, 4), dtype=torch.float64, device=dev) for per in pers]
-        idx_t = [avd.all_gather_rows(torch.as_tensor(ix, device=dev)).cpu().numpy().reshape(-1) for ix in idxs]
+            dm = _native.DeviceMap(m, veh, wcfg, device=local, max_pops=cap)
+            planners.append((dm, path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=path_planner.STAGED, stage_pops=STAGE_POPS),
+                             path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=0)))
+
+        def two_stage(k):
+            dm, bp1, bp2 = planners[k]
+            m, st, go = groups_full[k]
+
+            def stage1(s_l, g_l):
+                r, p, _ = bp1.plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True, first_stage_only=True)
+                return r, p
+
+            def stage2(s_l, g_l):
+                r, p, _ = bp2.plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True)
+                return r, p
+
+            return avd.two_stage_plan(stage1, stage2, st, go, rank, world)
 
         def step():
             e0, e1 = ev_k[ev_i[0] % len(ev_k)]
             ev_i[0] += 1
             e0.record()
-            for k, g in enumerate(groups):
-                res, paths, _ = g.bp.plan_dev(g.st_t, g.go_t, want_paths=True)
-                if k == len(groups) - 1:
-                    e1.record()
-                avd.all_gather_rows(res, out=gat_r[k])       # final gather of the records ...
-                avd.all_gather_rows(paths, out=gat_p[k])     # ... and of the solved paths (RCCL all-gather over xGMI)
-            return None
+            out = [two_stage(k) for k in range(len(groups_full))]
+            e1.record()
+            return out
 
-        elapsed, _ = timed_steps(step, a.steps, a.warmup)
+        elapsed, out = timed_steps(step, a.steps, a.warmup)
         recs, shard_invariant = [], None
-        slots_per_gpu = int(_native.lib().avp_plan_default_slots(groups[0].dm.h))
+        slots_all = []
+        if rank == 0:
+            for (rec_t, path_t, deferred) in out:
+                recs.append(rec_t.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1))
+        # ---- the same set on rank 0's GPU alone (staged call), timed: the in-run single-GPU reference + shard invariance -----
+        t1 = None
         if rank == 0:
             shard_invariant = True
+            t1 = 0.0
             for k, (m, st, go) in enumerate(groups_full):
-                flat_r = gat_r[k].reshape(-1, rec_stride).cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)
-                flat_p = gat_p[k].reshape(-1, MAX_PATH, 4).cpu().numpy()
-                flat_r = flat_r.copy()
-                flat_r["slot"] += (np.arange(len(flat_r)) // pers[k]).astype(np.int32) * slots_per_gpu     # slot ids are per GPU
-                rec_all, path_all = avd.unshard_rows(idx_t[k], flat_r, flat_p)
-                recs.append(rec_all)
-                # the same set on this GPU alone (untimed): the sharded result must be identical
-                ref = Group(m, veh, wcfg, st, go, local, cap)
-                r_res, r_paths, _ = ref.bp.plan_dev(ref.st_t, ref.go_t, want_paths=True)
-                r_rec, r_paths = records(r_res, ref.n), r_paths.cpu().numpy()
-                for name in ("status", "n_pops", "n_astar", "n_final", "n_checks", "n_rs", "n_closed", "n_open", "rs_L"):
-                    shard_invariant &= bool(np.array_equal(rec_all[name], r_rec[name]))
-                for i in range(ref.n):
-                    nf = int(r_rec["n_final"][i])
-                    shard_invariant &= bool(np.array_equal(path_all[i, :nf], r_paths[i, :nf]))
+                ref = Group(m, veh, wcfg, st, go, local, cap, mode=path_planner.STAGED)
+                sec, (r_res, r_paths, _) = time_group(ref, reps=2)
+                t1 += sec
+                shard_invariant &= same_results(recs[k], out[k][1].cpu().numpy(), records(r_res, ref.n), r_paths.cpu().numpy())
+                slots_all.append(ref.slots * world)
+                if k == 0:
+                    rr = records(r_res, ref.n)
+                    extra_dist["deal_simulation"] = avd.simulate_deals(rr["n_pops"], rr["status"], st, go, STAGE_POPS)
+                    extra_dist["deferred_after_stage1"] = int(len(out[k][2]))
             assert shard_invariant, "sharded result differs from the single-GPU result"
+            extra_dist["one_gpu_ms_per_step"] = t1 * 1e3
+            extra_dist["speedup_vs_1gpu"] = t1 / (elapsed / a.steps)
+            extra_dist["parallel_efficiency"] = t1 / (elapsed / a.steps) / world
+            extra_dist["one_gpu_note"] = "the whole set planned by rank 0 alone (staged call) right after the timed steps, same process, same GPU"
+        if use_dist:
+            dist.barrier()
+
+        class _G:          # what the report below reads of a group
+            pass
+        groups = []
+        for k, (m, st, go) in enumerate(groups_full):
+            g = _G()
+            g.dm, g.m, g.mode, g.bp, g.n = planners[k][0], m, path_planner.STAGED, planners[k][2], len(st)
+            groups.append(g)
 
     if rank == 0:
-        n_slots = int(_native.lib().avp_plan_default_slots(groups[0].dm.h))
-        head = summarize(recs, [g.slots * (world if use_dist else 1) for g in groups], elapsed / a.steps)
+        head = summarize(recs, slots_all, elapsed / a.steps)
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_k[a.warmup:a.warmup + a.steps]])) if a.steps else 0.0
         rec = np.concatenate(recs)
         P = groups[0].dm.P
@@ -333,7 +367,7 @@ def main():
         alg = (t_checks + t_scan + t_pop + t_h) * scale
         pmc = None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             pmc = pj if pj.get("source_hash") == source_hash() else {"stale": True}
         except Exception:
             pass
@@ -344,6 +378,9 @@ def main():
               "hbm_algorithmic_GBps": alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None,
               "frac_hbm_algorithmic": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel_ms else None,
               "frac_hbm_without_list_scan": (alg - t_scan * scale) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel_ms else None,
+              "frac_hbm_note": "SURVEY 8(d)'s algorithmic bytes (what the REFERENCE formulation reads) per launch time: a throughput-equivalence figure. "
+                               "The kernel keeps the map in LDS and replaces the list scans by a pose hash; its physical HBM traffic is `traffic`, "
+                               "its bound is fp64 VALU issue (`frac`, `fp64_flops_frac`)",
               "bound": "valu", "unit": "G SIMD-cycles/s", "peak": N_SIMD * CLOCK_GHZ, "achieved": None, "frac": None, "traffic": None}
         if pmc and not pmc.get("stale") and workload == "c2" and "plan_kernel" in pmc:
             pk = pmc["plan_kernel"]
@@ -352,98 +389,142 @@ def main():
             rl["frac"] = rl["achieved"] / rl["peak"]
             rl["traffic"] = pk.get("hbm_bytes_per_launch_corrected")
             rl["wait_frac"] = pk.get("wait_any_frac")
-            try:      # per-pop critical path of the capped problems, from the instrumented kernel (scripts/variant_bench.py)
-                rl["cycles_per_pop"] = json.load(open(os.path.join(ROOT, "profiles", "r02_plan_kernel_phase_cycles.json")))["cyc_per_pop"]
-                rl["cycles_per_pop_note"] = "the long way (no expansion record), instrumented kernel without lookahead"
-            except Exception:
-                rl["cycles_per_pop"] = None
-            try:      # ... and with the expansion lookahead (scripts/look_bench.py): record pops of the capped searches
-                lk = json.load(open(os.path.join(ROOT, "profiles", "r02_lookahead.json")))
-                if lk.get("source_hash") == source_hash():
-                    rp = lk["record_pops_of_capped_problems"]
-                    rl["record_pop_frac"] = rp["record_pop_frac"]
-                    rl["cycles_per_record_pop"] = max(rp["cycles_since_pop_start_per_wave"]["end_of_pop"])
-                    # average over record pops and long pops: the long-way figure scaled by the measured launch-time ratio
-                    if rl["cycles_per_pop"]:
-                        rl["cycles_per_pop_with_lookahead"] = rl["cycles_per_pop"] * lk["with_lookahead"]["ms_best"] / lk["without_lookahead"]["ms_best"]
-            except Exception:
-                pass
-            rl["pmc_source"] = "profiles/r02_pmc_summary.json (source hash %s)" % pmc["source_hash"]
+            if pk.get("f64_valu_wave_insts_per_launch"):
+                # upper bound: every counted f64 VALU wave-instruction as 64 live lanes (x 2 flops for an FMA)
+                fl = pk["f64_valu_wave_insts_per_launch"]
+                rl["fp64_flops_frac"] = 64.0 * (2 * fl.get("fma", 0) + fl.get("mul", 0) + fl.get("add", 0)) / (kernel_ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12)
+                rl["fp64_flops_note"] = "upper bound (64 live lanes per counted wave-instruction) of the fp64 vector peak %.1f TFLOP/s" % FP64_PEAK_TFLOPS
+            if pk.get("valu_lane_utilisation") is not None:
+                rl["valu_lane_utilisation"] = pk["valu_lane_utilisation"]
+            rl["pmc_source"] = "profiles/%s (source hash %s)" % (PMC_FILE, pmc["source_hash"])
         elif pmc and pmc.get("stale"):
-            rl["pmc_source"] = "profiles/r02_pmc_summary.json is STALE (kernel sources changed): PMC-derived fields left null"
+            rl["pmc_source"] = "profiles/%s is STALE (kernel sources changed): PMC-derived fields left null" % PMC_FILE
         out = {
             "metric": "hybrid-A* plans/sec, batched poses", "value": head["plans_per_s"], "unit": "plans/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if use_dist else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "problems": head["problems"], "pop_cap": cap, "obstacle_points": P,
-                       "kernel_form": "one workgroup per problem" if groups[0].mode == 1 else "one wave per problem",
+                       "kernel_form": FORM_NAMES.get(groups[0].mode, str(groups[0].mode)) if not use_dist else
+                       "two-stage deal: wave form for %d pops on the index slice, the rest dealt evenly (library's choice of form)" % STAGE_POPS,
                        "expansion_lookahead": bool(groups[0].bp.last_lookahead),
-                       "parallelism": f"shard{world}" + (" (records + paths all-gathered in the timed step)" if use_dist else "")},
+                       "parallelism": f"shard{world}" + (" (records + paths all-gathered after each stage, inside the timed step)" if use_dist else "")},
             "value_counts": "completed searches (status OK or NO_PATH); ITER_LIMIT problems are excluded",
             "all_problems_per_s": head["all_problems_per_s"], "expansions_per_s": head["expansions_per_s"],
             "solved_frac": head["solved_frac"], "iter_limit_frac": head["iter_limit_frac"],
             "slot_utilisation": head["slot_utilisation"], "shard_invariant": shard_invariant,
             "roofline": rl,
         }
+        out.update(extra_dist)
 
         if world == 1 and not use_dist and not a.no_extras and not a.pmc_mode and groups[0].bp.last_lookahead:
             # ---- the same step without the expansion lookahead (idle CUs stay idle): what the helpers buy -----------------
             g0 = groups[0]
-            bp0 = path_planner.BatchPlanner(g0.dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=1, lookahead=False)
-            o0 = bp0.plan_dev(g0.st_t, g0.go_t, want_paths=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                o0 = bp0.plan_dev(g0.st_t, g0.go_t, want_paths=True)
-            torch.cuda.synchronize()
-            x0 = summarize([records(o0[0], g0.n)], [g0.slots], (time.perf_counter() - t0) / 3)
-            r_on, r_off = recs[0], records(o0[0], g0.n)
-            p_on, p_off = outs[0][1].cpu().numpy(), o0[1].cpu().numpy()
-            x0["identical_results"] = bool(all(np.array_equal(r_on[f], r_off[f]) for f in r_on.dtype.names if f not in ("slot", "phase_cycles"))
-                                           and all(np.array_equal(p_on[i, :r_on["n_final"][i]], p_off[i, :r_on["n_final"][i]]) for i in range(g0.n)))
+            gn = Group(g0.m, veh, wcfg, g0.starts, g0.goals, local, cap, mode=1, lookahead=False)
+            sec, o0 = time_group(gn, reps=3)
+            x0 = summarize([records(o0[0], g0.n)], [g0.slots], sec)
+            x0["identical_results"] = same_results(recs[0], outs[0][1].cpu().numpy(), records(o0[0], g0.n), o0[1].cpu().numpy())
             out["without_lookahead"] = x0
-            del bp0
+            del gn
         if world == 1 and not use_dist and not a.no_extras:
             # ---- extras on the same GPU: the other BASELINE workloads ------------------------------------------------
-            for name in ("batch4096", "c3", "c5"):
+            for name in ("c3", "c5"):
                 if name == workload or a.pmc_mode:
                     continue
                 lab, xcfg, xcap, xsets = build(name)
                 xg = [Group(m, veh, xcfg, st, go, local, xcap) for (m, st, go) in xsets]
-
-                def xstep():
-                    return plan_groups(xg)
-
-                xstep()
+                plan_groups(xg)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(2):
-                    xo = xstep()
+                    xo = plan_groups(xg)
                 torch.cuda.synchronize()
                 xe = (time.perf_counter() - t0) / 2
                 xs = summarize([records(o[0], g.n) for o, g in zip(xo, xg)], [g.slots for g in xg], xe)
                 xs["workload"] = lab
-                xs["kernel_form"] = "one workgroup per problem" if xg[0].mode == 1 else "one wave per problem"
+                xs["kernel_form"] = FORM_NAMES.get(xg[0].mode)
                 out[name] = xs
                 del xg
             if not a.pmc_mode:
-                # ---- a saturating batch (4 x the 4 096 set, goals re-paired): the chip's sustained expansion rate in both
-                # kernel forms (avp_plan_batch_mode): the workgroup form keeps 256 problems in flight, the wave form 2 048
+                # ---- north_star's 4 096-pose batch: every kernel form and the staged call, identical results ------------------
                 lab, xcfg, xcap, xsets = build("batch4096")
                 mm, st4, go4 = xsets[0]
+                forms, ref_rp = {}, None
+                for mode in (1, 2, 3, 4, path_planner.STAGED):
+                    g4 = Group(mm, veh, xcfg, st4, go4, local, xcap, mode=mode)
+                    sec, o4 = time_group(g4, reps=2)
+                    r4, p4 = records(o4[0], g4.n), o4[1].cpu().numpy()
+                    forms[mode] = summarize([r4], [g4.slots], sec)
+                    forms[mode]["kernel_form"] = FORM_NAMES[mode]
+                    if ref_rp is None:
+                        ref_rp = (r4, p4)
+                    else:
+                        forms[mode]["identical_to_workgroup_form"] = same_results(ref_rp[0], ref_rp[1], r4, p4)
+                    del g4
+                best = min(forms, key=lambda k: forms[k]["ms_per_step"])
+                b4 = dict(forms[best])
+                b4["workload"] = lab
+                b4["forms_ms_per_step"] = {FORM_NAMES[k]: forms[k]["ms_per_step"] for k in forms}
+                b4["forms_identical"] = all(forms[k].get("identical_to_workgroup_form", True) for k in forms)
+                out["batch4096"] = b4
+                # the point of the 1 -> 8 curve this GPU contributes: the same set, planned the way `--gpus N` plans it
+                sp = dict(forms[path_planner.STAGED])
+                sp["workload"] = lab
+                sp["note"] = "the set `bench.py --gpus N` shards (strong scaling): at N = 1 the two-stage deal is the staged call"
+                sp["deal_simulation"] = avd.simulate_deals(ref_rp[0]["n_pops"], ref_rp[0]["status"], st4, go4, STAGE_POPS)
+                sp["deal_simulation_note"] = ("predicted load of the busiest rank over the mean, minus 1, from this run's per-problem pop counts: deal by decreasing "
+                                              "start-goal distance (round 2) vs the two-stage deal; two_stage_extra_pops_frac = the first-stage pops of the searches planned again")
+                out["scale_point"] = sp
+                # ---- a saturating batch (4 x the 4 096 set, goals re-paired): the chip's sustained expansion rate per kernel form
                 st16 = np.concatenate([st4] * 4)
                 go16 = np.concatenate([np.roll(go4, 17 * k, axis=0) for k in range(4)])
                 sat = {"workload": "Case1 map, 16384 problems (the 4096 starts against 4 rotations of the goals), pop cap 1000"}
-                for mode, key in ((1, "workgroup_per_problem"), (2, "wave_per_problem")):
+                for mode, key in ((1, "workgroup_per_problem"), (2, "wave_per_problem"), (3, "pair_per_problem"), (4, "quad_per_problem"), (path_planner.STAGED, "staged")):
                     g16 = Group(mm, veh, xcfg, st16, go16, local, xcap, mode=mode)
-                    g16.bp.plan_dev(g16.st_t, g16.go_t, want_paths=True)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    o16 = g16.bp.plan_dev(g16.st_t, g16.go_t, want_paths=True)
-                    torch.cuda.synchronize()
-                    sat[key] = summarize([records(o16[0], g16.n)], [g16.slots], time.perf_counter() - t0)
+                    sec, o16 = time_group(g16, reps=1)
+                    sat[key] = summarize([records(o16[0], g16.n)], [g16.slots], sec)
                     del g16
                 out["saturating_batch"] = sat
+                # ---- cap sensitivity: the headline set and config[4] at pop caps 300 / 1000 / 3000 -----------------------------
+                sweep = {}
+                for wname in ("c2", "c5"):
+                    lab_s, scfg, _, ssets = build(wname)
+                    ms_, st_, go_ = ssets[0]
+                    sweep[wname] = {}
+                    for cap_s in (300, 1000, 3000):
+                        gs = Group(ms_, veh, scfg, st_, go_, local, cap_s)
+                        sec, os_ = time_group(gs, reps=1)
+                        x = summarize([records(os_[0], gs.n)], [gs.slots], sec)
+                        sweep[wname][str(cap_s)] = {k: x[k] for k in ("plans_per_s", "expansions_per_s", "completed", "problems", "iter_limit_frac", "ms_per_step")}
+                        del gs
+                sweep["note"] = ("completed plans/s is a function of the cap only through the searches the cap stops: on Case1 a fifth of the random pairs never "
+                                 "connects (the reference would not terminate); on config[4] most searches need more than 300 pops")
+                out["cap_sweep"] = sweep
+                # ---- the 20 BenchmarkCases' own problems, run to termination (cap 30 000), one problem per launch ----------------
+                c20 = {}
+                for k in range(1, 21):
+                    mk = workloads.case_map(k, cfg, device="cuda")
+                    ck = mk.case
+                    gk = Group(mk, veh, cfg, np.array([[ck.x0, ck.y0, ck.theta0]]), np.array([[ck.xf, ck.yf, ck.thetaf]]), local, 30000, mode=1, lookahead=True)
+                    gk.bp.max_nodes = 1 << 19
+                    sec, ok_ = time_group(gk, reps=1)
+                    rk = records(ok_[0], 1)[0]
+                    c20[f"Case{k}"] = {"status": path_planner.STATUS_NAMES.get(int(rk["status"]), int(rk["status"])), "pops": int(rk["n_pops"]),
+                                       "ms": sec * 1e3, "way_points": int(rk["n_final"]), "reference_s": REFERENCE_SECONDS.get(k)}
+                    del gk
+                tot = sum(v["ms"] for v in c20.values())
+                out["cases20"] = {"cases": c20, "total_ms_one_after_the_other": tot, "plans_per_s": 20.0 / (tot * 1e-3),
+                                  "note": "each BenchmarkCase's own start / goal, pop cap 30 000 (never reached), one problem per launch with the expansion lookahead; "
+                                          "reference_s: the unmodified Python reference on one host thread (BASELINE.md)"}
+                # ---- one plan through the reference's API (config[0]): PathPlanner(...).path_planning() on Case1 ---------------
+                m1 = workloads.case_map(1, cfg)
+                pl = path_planner.PathPlanner(config=cfg, map=m1, vehicle=veh)
+                pl.path_planning()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    pl.path_planning()
+                out["single_plan_latency_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+                out["single_plan_note"] = "PathPlanner.path_planning() on BenchmarkCases/Case1.csv, host call to split path (uploads, launch, download, split_path), mean of 5; reference: 52 s"
             # ---- the footprint-collision kernel alone ----------------------------------------------------------------
             dm = groups[0].dm
             m = groups[0].m
@@ -474,6 +555,9 @@ def main():
                 rc["traffic"] = ck.get("hbm_bytes_per_launch_corrected")
                 rc["lds_busy_frac"] = ck.get("lds_busy_frac")
                 rc["lds_bank_conflict_frac"] = ck.get("lds_bank_conflict_frac")
+                if ck.get("f64_valu_wave_insts_per_launch"):
+                    fl = ck["f64_valu_wave_insts_per_launch"]
+                    rc["fp64_flops_frac"] = 64.0 * (2 * fl.get("fma", 0) + fl.get("mul", 0) + fl.get("add", 0)) / (cms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12)
             out["roofline_check"] = rc
             if not a.no_cpu_baseline and not a.pmc_mode:
                 from oracle import oracle
@@ -487,17 +571,18 @@ def main():
                     pops_cpu += w["n_pops"]
                     done_cpu += w["status"] in (0, 1)
                 tc = time.perf_counter() - t1
-                out["cpu_baseline"] = {"value": done_cpu / tc, "unit": "plans/s", "cores": 1, "kind": "port",
+                out["cpu_baseline"] = {"value": done_cpu / tc, "unit": "plans/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
                                        "sample": f"the first {nb} problems of the headline workload, pop cap {cap}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s; completed searches only, like `value`",
                                        "all_problems_per_s": nb / tc, "expansions_per_s": pops_cpu / tc}
                 from concurrent.futures import ThreadPoolExecutor
                 ncore = os.cpu_count() or 1
                 t2 = time.perf_counter()
+                reps_mc = 8                       # (the set is planned 8 times over: a fraction of a second would time the thread pool)
                 with ThreadPoolExecutor(max_workers=ncore) as ex:
-                    st_all = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=1)["status"], zip(g0.starts[:nb], g0.goals[:nb])))
+                    st_all = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=1)["status"], list(zip(g0.starts[:nb], g0.goals[:nb])) * reps_mc))
                 tm = time.perf_counter() - t2
-                out["cpu_baseline_all_cores"] = {"value": sum(s in (0, 1) for s in st_all) / tm, "unit": "plans/s", "cores": ncore, "kind": "port",
-                                                 "sample": f"the same {nb} problems, one per thread, {tm:.1f} s"}
+                out["cpu_baseline_all_cores"] = {"value": sum(s in (0, 1) for s in st_all) / tm, "unit": "plans/s", "cores": ncore, "kind": "port", "cpu_model": cpu_model(),
+                                                 "sample": f"the same {nb} problems {reps_mc} times over, one problem per thread, {tm:.1f} s"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

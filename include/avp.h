@@ -190,6 +190,9 @@ int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, 
  *   mode 2: one wave per problem, eight problems per workgroup -- the most problems in flight; right for batches much
  *           larger than the chip (north_star's 4 096-pose batch). Problems it cannot hold (a Reeds-Shepp shot of more
  *           than 256 samples, more than 16 children) are planned by the mode-1 kernel in a second launch of the same call;
+ *   mode 3: a pair of waves per problem, half as many problems per workgroup as mode 2 -- a pop takes ~0.6 x the time of
+ *           mode 2: right for a few problems per CU (their long searches all run at once: their latency is the launch time);
+ *   mode 4: four waves per problem, a quarter as many problems per workgroup as mode 2 (a pop takes ~0.45 x the time);
  *   mode 0: avp_plan_batch's choice: mode 2 when n >= 32 x the number of CUs (4 problems per wave slot), else mode 1.
  * n_slots counts problem slots in either form (avp_plan_slots(map, mode) = avp_plan_group(mode) x CUs); the workspace is
  * avp_plan_workspace_bytes(map, n_slots, max_nodes) as before. avp_plan_pick_mode returns the form mode 0 would use.
@@ -198,6 +201,23 @@ int32_t avp_plan_batch_mode(avp_map* map, const double* starts, const double* go
                             int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
                             double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t mode);
 int32_t avp_plan_pick_mode(avp_map* map, int64_t n, int32_t mode);
+/*
+ * The STAGED call (replaces the same reference code as avp_plan_batch: PathPlanner.a_star_plan, path_plan/path_planner.py:58-110,
+ * once per problem). Random pose pairs are bimodal: four searches out of five end within a few pops, the rest run for
+ * hundreds of pops or to the cap and hold 95 % of a batch's expansions. Stage 1 runs every problem in the mode-2 kernel
+ * and hands back, unfinished, every search still running after stage_pops pops; stage 2 plans those from scratch -- in
+ * the mode-4 / 3 / 2 kernel, whichever holds their number in one round, when they outnumber the compute units, else (and
+ * whatever those hand back) in the mode-1 kernel.
+ * A restarted search is the same search: records, traces and paths are those of avp_plan_batch (tests/test_gpu_staged.py).
+ * n_slots / workspace: as for mode 2 (avp_plan_slots(map, 2)). first_stage_only != 0: stop after stage 1; the
+ * unfinished searches then carry status AVP_PLAN_DEFERRED and nothing else -- for callers that deal them to other
+ * devices themselves (automatedvaletparking_amd.distributed).
+ */
+#define AVP_PLAN_DEFERRED 100
+int32_t avp_plan_batch_staged(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
+                              int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
+                              double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t stage_pops,
+                              int32_t first_stage_only, const int32_t* order);
 int32_t avp_plan_slots(avp_map* map, int32_t mode);
 int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the kernel form: slot counts are multiples of it (mode 1: 1) */
 

@@ -1,6 +1,6 @@
 """A/B of the expansion lookahead (avp_plan_batch_ex) on the bench's config[1] workload: identical results, time with and
 without, the helpers' job counters, and the per-wave timeline of the pops that were served from a record (instrumented
-instantiation). Prints one JSON object (committed as profiles/r02_lookahead.json).
+instantiation). Prints one JSON object (committed as profiles/r03_lookahead.json).
 usage: python scripts/look_bench.py [n_problems] [cap]"""
 import json
 import os
@@ -23,7 +23,8 @@ def main():
     cfg, veh = config.default_config(), costmap.Vehicle()
     m = costmap.Map(file=os.path.join(bench.CASES, "Case1.csv"), discrete_size=cfg["map_discrete_size"])
     dm = _native.DeviceMap(m, veh, cfg, device=0, max_pops=cap)
-    st, go = bench.sample_pairs(m, dm, n, np.random.default_rng(20260927))
+    from automatedvaletparking_amd import workloads
+    st, go = workloads.sample_pairs(m, dm.check_batch, n, np.random.default_rng(20260927))
     stt, got = dm.dev_tensor(st), dm.dev_tensor(go)
     out = {"workload": "Case1 map, %d random start/goal pairs, pop cap %d (bench.py's config[1] problem set)" % (n, cap),
            "source_hash": bench.source_hash()}

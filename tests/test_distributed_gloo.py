@@ -72,8 +72,31 @@ def _worker(rank, world, port, q):
     g_path = avd.all_gather_rows(torch.as_tensor(path_l))
     g_idx = avd.all_gather_rows(torch.as_tensor(idx_pad))
     rec13, path13 = avd.unshard_rows(g_idx.numpy().reshape(-1), g_rec.numpy().reshape(-1, 4), g_path.numpy().reshape(-1, max_path, 4))
+    # bench.py --gpus N: the two-stage deal (stage 1 on the index slice with a pop budget, all-gather, the unfinished
+    # searches dealt round-robin, all-gather, merge by permute + index_copy) with the oracle standing in for both stages
+    K = 8
+
+    def stage(cap_pops):
+        oo = oracle.Oracle(m, veh, cfg, max_pops=cap_pops)
+
+        def run(s, g):
+            rec_t = torch.zeros((len(s), 16), dtype=torch.uint8)
+            path_t = torch.zeros((len(s), max_path, 4), dtype=torch.float64)
+            rv = rec_t.view(torch.int32)
+            for i in range(len(s)):
+                r = oo.plan(s[i], g[i], max_trace=1)
+                st_ = r["status"]
+                if cap_pops == K and st_ == 4:
+                    st_ = avd.DEFERRED                     # still running after the first stage's budget
+                k = min(len(r["final_path"]), max_path)
+                rv[i, 0], rv[i, 1], rv[i, 2] = st_, r["n_pops"], k
+                path_t[i, :k, :3] = torch.as_tensor(r["final_path"][:k])
+            return rec_t, path_t
+        return run
+
+    rec2s, path2s, deferred = avd.two_stage_plan(stage(K), stage(200), starts, goals, rank, world)
     if rank == 0:
-        q.put((rec, avd.pack_map_blob(m), rec13, path13))
+        q.put((rec, avd.pack_map_blob(m), rec13, path13, rec2s.view(torch.int32).numpy().copy(), path2s.numpy().copy(), deferred))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,7 +111,7 @@ def test_shard_invariance_world2(vehicle, cfg):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    rec2, blob, rec13, path13 = q.get(timeout=300)
+    rec2, blob, rec13, path13, rec2s, path2s, deferred = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -110,6 +133,14 @@ def test_shard_invariance_world2(vehicle, cfg):
             assert list(rec13[i]) == [r["status"], r["n_pops"], k2, r["rs_L"]]
             assert np.array_equal(path13[i, :k2, :3], r["final_path"][:k2])
     assert len(rec13) == 11
+    # the two-stage deal: every problem's final record and path, in problem order; some searches went through stage 2
+    assert len(rec2s) == len(starts) and 0 < len(deferred) < len(starts)
+    for i in range(len(starts)):
+        r = o.plan(starts[i], goals[i], max_trace=1)
+        k2 = min(len(r["final_path"]), 40)
+        assert list(rec2s[i, :3]) == [r["status"], r["n_pops"], k2], (i, list(rec2s[i, :3]), r["status"], r["n_pops"])
+        assert np.array_equal(path2s[i, :k2, :3], r["final_path"][:k2])
+        assert (i in set(deferred.tolist())) == (r["n_pops"] > 8 or (r["status"] == 4 and r["n_pops"] >= 8))
 
 
 def test_map_blob_roundtrip():

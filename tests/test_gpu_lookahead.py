@@ -79,3 +79,38 @@ def test_problem_order_changes_no_result(vehicle, cfg):
         a = path_planner.BatchPlanner(dm, max_nodes=4096, mode=mode, lookahead=False, n_slots=64).plan(st, go, max_trace=150)
         b = path_planner.BatchPlanner(dm, max_nodes=4096, mode=mode, lookahead=False, n_slots=64, longest_first=True).plan(st, go, max_trace=150)
         _same_results(a, b)
+
+
+def test_lookahead_soak_300_launches(vehicle, cfg):
+    """The inter-workgroup hand-offs (job rings, record store) under repetition: 300 consecutive launches of config[1]'s
+    256 problems with the lookahead on the same workspace -- the record store is never zeroed between launches, records are
+    accepted by key -- every launch's records and way-points equal to the launch without the lookahead. (Builds with other
+    helper sleep / owner wait times, release / acquire atomics and injected wrong keys: scripts/look_soak.py,
+    profiles/r03_lookahead_soak.json.)"""
+    import torch
+    from automatedvaletparking_amd import _native, path_planner, workloads
+    m = case_map_from_gold(1)
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=1000)
+    st, go = workloads.sample_pairs(m, dm.check_batch, 256, np.random.default_rng(workloads.SEED))
+    stt, got = dm.dev_tensor(st), dm.dev_tensor(go)
+
+    def fetch(res, paths):
+        rec = res.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:256]
+        return rec, paths.cpu().numpy()
+
+    off = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=1, lookahead=False)
+    r, p, _ = off.plan_dev(stt, got)
+    torch.cuda.synchronize()
+    r0, p0 = fetch(r, p)
+    on = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=1, lookahead=True)
+    fields = [f for f in r0.dtype.names if f not in ("slot", "phase_cycles")]
+    for k in range(300):
+        r, p, _ = on.plan_dev(stt, got)
+        torch.cuda.synchronize()
+        assert on.last_lookahead
+        rk, pk = fetch(r, p)
+        for f in fields:
+            assert np.array_equal(rk[f], r0[f]), (k, f)
+        assert all(np.array_equal(pk[i, :r0["n_final"][i]], p0[i, :r0["n_final"][i]]) for i in range(256)), k
+    used = int(on._look[:1024].cpu().numpy().view(np.uint64)[8])
+    assert used > 0.5 * r0["n_pops"].sum()          # most pops were served from a record

@@ -1,5 +1,5 @@
 """plan_wave_kernel in both its forms -- one wave per problem (avp_plan_batch_mode mode 2) and a pair of waves per problem
-(mode 3) -- against the CPU oracle in
+(mode 3), four waves per problem (mode 4) -- against the CPU oracle in
 device arithmetic and against plan_kernel (mode 1): every record field, pop trace, counter and way-point identical --
 the result never depends on the kernel form that produced it, including the problems the wave form hands back to the
 workgroup form (Reeds-Shepp shots longer than its sample buffer)."""
@@ -28,7 +28,7 @@ def _same_results(a, b):
             assert np.array_equal(x.trace, y.trace, equal_nan=True)
 
 
-FORMS = [2, 3]          # one wave / a pair of waves per problem
+FORMS = [2, 3, 4]       # one wave / a pair of waves / four waves per problem
 
 
 @pytest.mark.parametrize("form", FORMS)
