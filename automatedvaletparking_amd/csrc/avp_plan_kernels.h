@@ -35,6 +35,9 @@
 #define PL_CHK_MAX 1280               // poses per collision pass (shot samples + sub-steps)
 #define PL_RS_CAP 1024                // samples of one RS shot
 #define PL_UNSEEN 0x7fffffffu
+#ifndef PL_RELAX_PRECHECK
+#define PL_RELAX_PRECHECK 0
+#endif
 #define PL_TRACE_W 11
 #define PL_SCHED_ROUNDS (PL_THREADS >= 512 ? 4 : 8)   // rounds of the RS word schedule: 12 solver chunks of <= 64 lanes over PL_THREADS / 64 waves, with slack
 #define PL_FLAG_T 1
@@ -638,6 +641,11 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, S& s, int col, int row, ui
                                        ((unsigned long long)nbr << 1) | (col == 0 ? 0ull : 1ull);
         atomicMin(&w.aliasKey[slot], key);
     }
+#if PL_RELAX_PRECHECK
+    // (distances only ever decrease: a plain load that already shows a value <= nd settles it without the atomic -- about
+    // half the relaxations of a ring go backwards or sideways; a stale larger value just takes the atomic as before)
+    if (w.dist[nid] <= nd) return;
+#endif
     const uint32_t old = atomicMin(&w.dist[nid], nd);
     if (nd < old) {
         const int q = pl_bucket(nd) & (PL_NQ - 1);

@@ -118,6 +118,22 @@ struct PwGroup {
         wave_sync();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    // The same for hand-overs through LDS only: the wave's outstanding GLOBAL stores (node records, heap entries, shot
+    // samples: a few thousand cycles until acknowledged) are not waited for -- nobody reads them before a full sync().
+    static __device__ __forceinline__ void sync_lds()
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (NW > 1) {
+            if ((threadIdx.x & 63) == 0) {
+                const int wave = threadIdx.x >> 6, grp = wave & ~(NW - 1);
+                const uint32_t g = PW_BAR_GEN[wave] + 1u;
+                PW_BAR_GEN[wave] = g;
+                atomicAdd(&PW_BAR_CNT[grp], 1u);
+                while (*(volatile uint32_t*)&PW_BAR_CNT[grp] < g * (uint32_t)NW) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        wave_sync();
+    }
 };
 
 // Reeds-Shepp evaluation scratch of one wave: running best per query (indexed by position in rsq), round scratch
@@ -162,6 +178,7 @@ struct PwSharedT {
     int64_t n_pops;
     PlNode cn;                                 // the node being expanded (copy of its arena record)
     int32_t nq, rsq[PW_RSQ];                   // the Reeds-Shepp queries of this pop: 0 = the shot, 1 + i = child i
+    uint32_t rs_next, pad3;                    // next unclaimed solver round of this pop (the group's waves draw from it)
     PlChild child[PW_MAXCHILD];
     // shot sampling
     int32_t smp_hi, smp_point_num;
@@ -210,12 +227,28 @@ __device__ __noinline__ void pw_rs_eval(PW_PHASE_ARGS)
     PwRsBest& rb = s.rb[wv];
     if (lane < nq) { rb.bestL[lane] = ~0ull; rb.bestW[lane] = -1; rb.w_err[lane] = 0; }
     wave_sync();
-    int round = 0;
-    for (int sg = 0; sg < 8; sg++) {
-        const int L = c.sg_l[sg], sh = c.sg_shift[sg], off = c.sg_off[sg], gmax = c.sg_gmax[sg];
-        const int items = nq << sh;
-        for (int base = 0; base < items; base += 64, round++) {
-            if (NW > 1 && (round & (NW - 1)) != wv) continue;
+    // The rounds (solver group x 64 items) are drawn by the group's waves from one counter, dearest solver group first
+    // (cycles per round, scripts/microbench/rs_words.hip: LRLRn + LRLRp 19 k, SLS 8 k, LRL / LRSL 6 k, LSR 6 k, LRSR 4.5 k,
+    // LSL 4 k, LRSLR 3 k): list scheduling keeps the waves within one round of each other. Minimum and tie rule are
+    // commutative, so who evaluates which round -- and in which order -- changes no result.
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = NW > 1 ? atomicAdd(&s.rs_next, 1u) : s.rs_next++;
+        r = __shfl(r, 0, 64);
+        int sg = -1, base = 0;
+        {
+            uint32_t left = r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int g_ = (0x40352617 >> (4 * (7 - k))) & 7;               // order 4 0 3 5 2 6 1 7, dearest first
+                const uint32_t nr = (uint32_t)(((nq << c.sg_shift[g_]) + 63) >> 6);
+                if (sg < 0) { if (left < nr) { sg = g_; base = (int)left * 64; } else left -= nr; }
+            }
+        }
+        if (sg < 0) break;
+        {
+            const int L = c.sg_l[sg], sh = c.sg_shift[sg], off = c.sg_off[sg], gmax = c.sg_gmax[sg];
+            const int items = nq << sh;
             const int it = base + lane;
             const bool active = it < items;
             const int q = active ? it >> sh : 0, j = it & (L - 1);
@@ -267,7 +300,7 @@ __device__ __noinline__ void pw_rs_eval(PW_PHASE_ARGS)
         }
     }
     if constexpr (NW > 1) {
-        G::sync();
+        G::sync_lds();
         if (wv == 0 && lane < nq) {
             PwRsBest& r0 = s.rb[0];
 #pragma unroll
@@ -377,7 +410,7 @@ __device__ __noinline__ void pw_ph_pop(PW_PHASE_ARGS)
             s.n_pops = n_pops + 1;
         }
     }
-    G::sync();
+    G::sync_lds();
 }
 
 // ---- children poses (expand_node :134-151), their exact-equality look-ups, try_reach_goal's radius test (:308-312) ----
@@ -428,7 +461,7 @@ __device__ __noinline__ void pw_ph_children(PW_PHASE_ARGS)
         if (need) s.sub_t[__popcll(mk & ((1ull << lane) - 1ull))] = (int8_t)lane;
         if (lane == 0) { s.n_todo = __popcll(mk); s.n_passes = (__popcll(mk) + PL_WPOSE - 1) / PL_WPOSE; }
     }
-    G::sync();
+    G::sync_lds();
 }
 
 // ---- sub-step collision checks (:185-204), PL_WPOSE poses per pass, the passes dealt to the group's waves ------------
@@ -455,7 +488,7 @@ __device__ __noinline__ void pw_ph_substeps(PW_PHASE_ARGS)
         wave_sync();
     }
     if (gtid == 0) s.can_fast = (s.closed_nonempty && (s.nnodes + c.nchild <= c.maxNodes)) ? 1 : 0;
-    G::sync();
+    G::sync_lds();
 }
 
 // ---- Reeds-Shepp: the shot from the popped node (:326-332) and the children's lengths (:286-294) ----------------------
@@ -485,9 +518,9 @@ __device__ __noinline__ void pw_ph_rs(PW_PHASE_ARGS)
             if (lane == 0) s.frame[k] = rs_frame(s.cn.x, s.cn.y, s.cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             else { const PlChild& ch = s.child[lane - 1]; s.frame[k] = rs_frame(ch.x, ch.y, ch.th, s.goal[0], s.goal[1], s.goal[2], p.maxc); }
         }
-        if (lane == 0) s.nq = __popcll(mk);
+        if (lane == 0) { s.nq = __popcll(mk); s.rs_next = 0; }
     }
-    G::sync();
+    G::sync_lds();
     pw_rs_eval<NW>(sp, cp);
     if (wv == 0) {
         if (need && lane >= 1) {
@@ -502,7 +535,7 @@ __device__ __noinline__ void pw_ph_rs(PW_PHASE_ARGS)
             if (!st) { s.rs = rp; s.n_rs += 1; }
         }
     }
-    G::sync();
+    G::sync_lds();
 }
 
 // ---- the shot: sample in path order, check, stop at the first colliding sample (:335-345) ------------------------------
@@ -513,12 +546,12 @@ __device__ __noinline__ void pw_ph_shot(PW_PHASE_ARGS)
     const avp_params& p = c.p;
     const PlanWs& w = s.w;
     // (s.rs_status was set by the previous phase and is not written in this one: every wave of the group reads the same value)
-    if (s.rs_status) { if (gtid == 0) s.status = 3; G::sync(); return; }       // no Reeds-Shepp path / the reference's assertion
+    if (s.rs_status) { if (gtid == 0) s.status = 3; G::sync_lds(); return; }       // no Reeds-Shepp path / the reference's assertion
     // the sampler's index bookkeeping (one lane) beside the chain of segment origins (a wave)
     if (gtid == 0) s.book_status = pl_rs_sample_book(s, p);
     if (wv == (NW > 1 ? 1 : 0)) pl_rs_sample_origins(s, p);
-    G::sync();
-    if (s.book_status) { if (gtid == 0) s.status = AVP_PLAN_RETRY; G::sync(); return; }      // more samples than this form holds
+    G::sync_lds();
+    if (s.book_status) { if (gtid == 0) s.status = AVP_PLAN_RETRY; G::sync_lds(); return; }      // more samples than this form holds
     const PlNode cn = s.cn;
     const int total = s.smp_hi + 1;
     double cm, sm;
@@ -541,14 +574,14 @@ __device__ __noinline__ void pw_ph_shot(PW_PHASE_ARGS)
         if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
         wave_sync();
     }
-    G::sync();
+    G::sync_lds();
     if (gtid == 0) {
         // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
         if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
         if (s.rs_first_coll == 0x7fffffff) { s.n_checks += s.rs_npts; s.done = 1; }
         else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
     }
-    G::sync();
+    G::sync_lds();
 }
 
 // ---- child resolution in child order (:153-232): wave-parallel when every heuristic query hits the closed frontier ------
