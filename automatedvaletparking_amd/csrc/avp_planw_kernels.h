@@ -174,7 +174,7 @@ struct PwSharedT {
     int32_t next_cur, have_next;
     // per group, set once / per pop
     PlanWs w;                                  // this group's workspace slot
-    int32_t slot, can_fast, n_passes, n_todo, book_status, pad2;
+    int32_t slot, can_fast, n_passes, n_todo, book_status, shot_stop;
     int64_t n_pops;
     PlNode cn;                                 // the node being expanded (copy of its arena record)
     int32_t nq, rsq[PW_RSQ];                   // the Reeds-Shepp queries of this pop: 0 = the shot, 1 + i = child i
@@ -556,23 +556,43 @@ __device__ __noinline__ void pw_ph_shot(PW_PHASE_ARGS)
     const int total = s.smp_hi + 1;
     double cm, sm;
     avp_sincos(-cn.th, sm, cm);
-    for (int base = wv * PL_WPOSE; base < total; base += NW * PL_WPOSE) {
-        // stop once a colliding sample BEFORE this chunk is known (the chunks of the other waves included: a hit in a later
-        // chunk does not excuse this one) -- unless it may lie in the trailing px == 0.0 tail the reference pops
-        // (rs_curve.py:588-592): that is only known once every sample has been produced, so keep going then
-        { const int fc = *(volatile int32_t*)&s.rs_first_coll; if (fc < base && fc < *(volatile int32_t*)&s.rs_npts) break; }
-        const int cnt = min(PL_WPOSE, total - base);
-        if constexpr (PROFILE) { if (lane == 0) atomicAdd(&s.phase[PW_PH_NPASS], 1u); }
-        double tx = 0.0, ty = 0.0, tth = 0.0;
-        const int mine = base + lane;
-        if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
-        uint32_t* hits = &s.wave_chk().hit[0];
-        pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
-            x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
-            avp_sincos(th, sn, cs);
-        }, hits);
-        if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
-        wave_sync();
+    // Rounds in path order; a round deals `per` consecutive samples to every wave of the group and ends with the group
+    // in step, so that the decision to stop sees every result of the round: the reference stops at the first colliding
+    // sample, typically 5 .. 10 m down the path. A group of several waves starts with SHORT chunks (8 samples per round
+    // in total, then 16, then 8 per wave): the samples get dearer along the path -- towards the obstacles around the
+    // goal --, and a first round that spreads 32 samples over four waves was measured to cost more than the one or two
+    // 8-sample passes a single wave needs before it may stop.
+    int base0 = 0;
+    for (int r = 0; base0 < total; r++) {
+        const int per = NW == 1 ? PL_WPOSE : min(PL_WPOSE, (PL_WPOSE / NW) << r);
+        const int base = base0 + wv * per;
+        if (base < total) {
+            const int cnt = min(per, total - base);
+            if constexpr (PROFILE) { if (lane == 0) atomicAdd(&s.phase[PW_PH_NPASS], 1u); }
+            double tx = 0.0, ty = 0.0, tth = 0.0;
+            const int mine = base + lane;
+            if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
+            uint32_t* hits = &s.wave_chk().hit[0];
+            pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+                x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
+                avp_sincos(th, sn, cs);
+            }, hits);
+            if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
+        }
+        base0 += NW * per;
+        G::sync_lds();
+        // every sample before base0 has been checked: the smallest colliding index among them is final. Stop -- unless it may
+        // lie in the trailing px == 0.0 tail the reference pops (rs_curve.py:588-592): that is only known once every sample
+        // has been produced (rs_npts grows with them), so keep going then. ONE lane decides and the group meets again: a
+        // wave that read the two words itself could see what a faster wave has already written in the next round.
+        if constexpr (NW > 1) {
+            if (gtid == 0) { const int fc = s.rs_first_coll, np = s.rs_npts; s.shot_stop = (fc != 0x7fffffff && fc < np) ? 1 : 0; }
+            G::sync_lds();
+            if (s.shot_stop) break;
+        } else {
+            const int fc = s.rs_first_coll, np = s.rs_npts;
+            if (fc != 0x7fffffff && fc < np) break;
+        }
     }
     G::sync_lds();
     if (gtid == 0) {
