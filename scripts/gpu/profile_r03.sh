@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-3 evidence run (one GPU box): the whole GPU suite, the bench line (twice: before and after the stamped PMC summary
+# is in place), the N > 1 code path through RCCL with world size 1, rocprofv3 kernel stats of the headline-only form of the
+# command, the PMC passes (each its own run, --kernel-trace --pmc only) on the bench and on the secondary kernels, the SQ
+# counters of the saturating batch per kernel form, the per-phase cycles of every form, the lookahead A/B and its soak
+# builds. Outputs under gpurun_out/r03/; scripts/gpu/collect_r03.sh copies the summaries into profiles/.
+set -x
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R=$PWD; O=$R/gpurun_out/r03; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+V=automatedvaletparking_amd/variants
+timeout -k 10 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log
+for pass in "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS" "lds:SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_SALU" "lane:SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  name=${pass%%:*}; ctr=${pass#*:}
+  (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc/$name --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --pmc-mode > $O/pmc_$name.log 2>&1)
+  (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc/$name --output-format csv -- python $R/scripts/bench_check.py --iters 3 > $O/pmc_check_$name.log 2>&1)
+done
+python scripts/pmc_r03_summary.py $O/pmc > $O/pmc_summary.json; head -c 300 $O/pmc_summary.json
+cp $O/pmc_summary.json profiles/r03_pmc_summary.json       # (on the box only: the bench line below reads the stamped file)
+timeout -k 10 900 python bench.py --steps 5 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err; head -c 600 $O/bench_n1.json; tail -3 $O/bench_n1.err
+AVP_BENCH_FORCE_DIST=1 timeout -k 10 600 python bench.py --steps 3 --warmup 1 > $O/bench_force_dist.json 2> $O/bench_force_dist.err; head -c 400 $O/bench_force_dist.json; tail -3 $O/bench_force_dist.err
+(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/stats_headline --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --pmc-mode > $O/bench_headline_under_rocprof.json 2> $O/stats_headline.err)
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_check --output-format csv -- python $R/scripts/bench_check.py --iters 10 > $O/bench_check.jsonl 2> $O/stats_check.err)
+for mode in 1 2 3 4; do
+  for pass in "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS" "lane:SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA"; do
+    name=${pass%%:*}; ctr=${pass#*:}
+    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_sat/mode$mode/$name --output-format csv -- python $R/scripts/variant_bench.py --big 16384 --big-mode $mode --no-profile --steps 1 > $O/pmc_sat_m${mode}_$name.log 2>&1)
+  done
+done
+python scripts/pmc_sat_summary.py $O/pmc_sat > $O/pmc_saturating_batch.json 2> $O/pmc_sat_summary.err
+python scripts/variant_bench.py --big 2048 > $O/phase_profile.json 2> $O/phase_profile.err
+for mode in 2 3 4; do timeout -k 10 300 python scripts/wave_profile.py --n 4096 --mode $mode > $O/wave_profile_m$mode.json 2> $O/wave_profile_m$mode.err; done
+timeout -k 10 300 python scripts/look_bench.py > $O/lookahead.json 2> $O/lookahead.err; head -c 300 $O/lookahead.json
+for v in default look_atomics look_sleep1 look_sleep127 look_wait0 look_wait50k look_fault5; do
+  L=""; [ $v != default ] && L="--lib $V/libavp_hip_$v.so"
+  [ $v = default -o -f $V/libavp_hip_$v.so ] && timeout -k 10 300 python scripts/look_soak.py $L --launches 300 > $O/soak_$v.json 2> $O/soak_$v.err
+done
+find $O -name "*kernel_stats.csv" | head; du -sh $O
