@@ -411,6 +411,10 @@ struct PlShared {
     int32_t fold_idx[PL_THREADS / 64];
     MapTabs mt;                       // the map tables as the kernel sees them (LDS copies when staged)
     PlChkEnv env;                     // what the called collision passes read of the map and the vehicle
+    // copies of the kernel's arguments for the CALLED parts of plan_kernel (set-up, sweep extension, result record): they
+    // take this struct's LDS address and nothing else, so their registers -- and their code -- stay out of the pop loop
+    DevMap km; avp_params kp; PlanDims kdims; PlanWs kw; PlLook klook;
+    const double* k_starts; const double* k_goals; avp_plan_result_dev* k_results; double* k_paths; int32_t k_max_path, k_pad;
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
@@ -893,11 +897,11 @@ AVP_D void pl_rs_words(PlShared& s, const avp_params& p, int nq, PoseFn pose, bo
         const uint16_t it = s.sched[t];
         if (it == 0xffff) continue;
         const int wd = it >> 4, q = it & 15;
-        double l[5];
         const int slot = q * 46 + wd;
-        s.w_ok[slot] = rs_word(wd, s.frame[q], l) ? 1 : 0;
+        const RsWordOut o = rs_word_fn(wd, s.frame[q]);      // (a called leaf: the nine solvers exist once, outside the pop loop's register budget)
+        s.w_ok[slot] = o.ok ? 1 : 0;
         s.w_acc[slot] = 0;
-        for (int k = 0; k < 5; k++) s.w_l[slot][k] = l[k];
+        s.w_l[slot][0] = o.l0; s.w_l[slot][1] = o.l1; s.w_l[slot][2] = o.l2; s.w_l[slot][3] = o.l3; s.w_l[slot][4] = o.l4;
     }
     if ((int)threadIdx.x < nq) s.w_err[threadIdx.x] = 0;
     // (the caller closes the pass with a workgroup barrier)
@@ -1671,6 +1675,82 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     pl_ring_post2(look, lane, want, w0, x, y, th, s.goal);
 }
 
+// ---- called parts of plan_kernel (whole workgroup; they read the kernel's arguments through PlShared's LDS copies) ------------
+// per-problem set-up: hybrid_a_star.__init__ (hybrid_a_star.py:72-124)
+template <bool PROFILE>
+__device__ __noinline__ void plk_init(AVP_LDS PlShared* sp, int64_t pid)
+{
+    PlShared& s = *(PlShared*)sp;
+    const DevMap& m = s.km;
+    const PlanWs& w = s.kw;
+    const int tid = threadIdx.x;
+    const double sx = s.k_starts[3 * pid], sy = s.k_starts[3 * pid + 1], sth = s.k_starts[3 * pid + 2];
+    const double gx = s.k_goals[3 * pid], gy = s.k_goals[3 * pid + 1], gth = s.k_goals[3 * pid + 2];
+    const long long t_init0 = PH_NOW();
+    for (int64_t i = tid; i < s.kdims.hashCap; i += PL_THREADS) w.hash[i] = 0;
+    if (tid == 0) {
+        s.status = 0; s.done = 0;
+        s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1; s.nf_node = -1;
+        s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
+        for (int k = 0; k < PH_COUNT; k++) s.phase[k] = 0;
+        s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
+        s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
+    }
+    pl_sweep_init(m, w, s, s.kdims, gx, gy);
+    if (s.status == 0) {
+        // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
+        const int64_t sid = avp_pos_to_index(m, sx, sy);
+        pl_hquery_miss<PROFILE>(m, w, s, sid);
+        if (tid == 0) {
+            if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
+            else {
+                PlNode& nd = w.nodes[0];
+                nd.x = sx; nd.y = sy; nd.th = avp_pi_2_pi(sth); nd.g = 0; nd.h = 0; nd.f = 0;
+                nd.index = 0; nd.parent_index = -1; nd.parent_pos = -1; nd.forward = 1; nd.steer_i = -1; nd.state = 1;
+                s.nnodes = 1;
+                pl_heap_push(w, s, 0, 0.0);
+                pl_hash_put(w, s.kdims.hashCap, 0);
+            }
+        }
+        __syncthreads();
+    }
+    PH_ACC(PH_INIT, t_init0);
+}
+// a heuristic query that misses the closed frontier: the workgroup extends the sweep (compute_h.py:198-214)
+template <bool PROFILE>
+__device__ __noinline__ void plk_sweep_extend(AVP_LDS PlShared* sp)
+{
+    PlShared& s = *(PlShared*)sp;
+    pl_hquery_miss<PROFILE>(s.km, s.kw, s, s.pending_id);
+}
+// finish_path + assembly (one thread)
+template <bool PROFILE>
+__device__ __noinline__ void plk_write_result(AVP_LDS PlShared* sp, int64_t pid, int64_t n_pops, int32_t slot, long long t_fin)
+{
+    PlShared& s = *(PlShared*)sp;
+    pl_write_result<PROFILE>(s.kp, s.kw, s, s.k_travel_ddt, s.k_dth_ddt, s.k_results, s.k_paths, s.k_max_path, pid, n_pops, slot, t_fin);
+}
+
+// the owner side of the lookahead (one wave each), as called functions: five call sites in the pop loop
+__device__ __noinline__ void plk_look_post(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, uint32_t node, int kids,
+                                           double cnx, double cny, double cnth, int cn_forward, int cn_steer)
+{
+    PlShared& s = *(PlShared*)sp;
+    PlNode cn;
+    cn.x = cnx; cn.y = cny; cn.th = cnth; cn.forward = (int8_t)cn_forward; cn.steer_i = (int8_t)cn_steer;     // (what pl_look_post reads of the node)
+    pl_look_post(s.klook, s.kw, s, s.kp, cn, pid, maxNodes, threadIdx.x & 63, node, kids != 0);
+}
+__device__ __noinline__ void plk_look_fetch(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node, int32_t nheap_after, int nchild, int lookups)
+{
+    PlShared& s = *(PlShared*)sp;
+    pl_look_fetch(s.klook, s.kw, s, pid, maxNodes, node, threadIdx.x & 63, nheap_after, s.kdims.hashCap, nchild, lookups != 0);
+}
+__device__ __noinline__ void plk_look_prefetch(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node)
+{
+    PlShared& s = *(PlShared*)sp;
+    pl_look_prefetch(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node);
+}
+
 template <bool STAGE, bool PROFILE, bool LOOK = false>
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                           const double* __restrict__ goals, int64_t n, int32_t maxNodes,
@@ -1718,7 +1798,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         mt.X = lx; mt.Y = ly; mt.bits = lb;
         __syncthreads();
     } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
-    if (tid == 0) { s.mt = mt; pl_chk_env_fill(s.env, m, p, STAGE ? mt.X : nullptr, STAGE ? mt.Y : nullptr, STAGE ? mt.bits : nullptr); }
+    if (tid == 0) {
+        s.mt = mt; pl_chk_env_fill(s.env, m, p, STAGE ? mt.X : nullptr, STAGE ? mt.Y : nullptr, STAGE ? mt.bits : nullptr);
+        s.km = m; s.kp = p; s.kdims = dims; s.kw = w; s.klook = look;
+        s.k_starts = starts; s.k_goals = goals; s.k_results = results; s.k_paths = paths; s.k_max_path = max_path; s.k_pad = 0;
+    }
     const int nchild = 2 * p.n_steer;
     const int64_t max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
 
@@ -1746,41 +1830,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             __syncthreads();
         } else {
-        const double sx = starts[3 * pid], sy = starts[3 * pid + 1], sth = starts[3 * pid + 2];
-        const double gx = goals[3 * pid], gy = goals[3 * pid + 1], gth = goals[3 * pid + 2];
-
-        // ---- init ------------------------------------------------------------------------------
-        const long long t_init0 = PH_NOW();
-        for (int64_t i = tid; i < dims.hashCap; i += PL_THREADS) w.hash[i] = 0;
-        if (tid == 0) {
-            s.status = 0; s.done = 0;
-            s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1; s.nf_node = -1;
-            s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
-            for (int k = 0; k < PH_COUNT; k++) s.phase[k] = 0;
-            s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
-            s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
-        }
-        pl_sweep_init(m, w, s, dims, gx, gy);
-
-        if (s.status == 0) {
-            // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
-            const int64_t sid = avp_pos_to_index(m, sx, sy);
-            pl_hquery_miss<PROFILE>(m, w, s, sid);
-            if (tid == 0) {
-                if (s.hq_d == PL_UNSEEN) s.status = s.qover ? 5 : 2;
-                else {
-                    PlNode& nd = w.nodes[0];
-                    nd.x = sx; nd.y = sy; nd.th = avp_pi_2_pi(sth); nd.g = 0; nd.h = 0; nd.f = 0;
-                    nd.index = 0; nd.parent_index = -1; nd.parent_pos = -1; nd.forward = 1; nd.steer_i = -1; nd.state = 1;
-                    s.nnodes = 1;
-                    pl_heap_push(w, s, 0, 0.0);
-                    pl_hash_put(w, dims.hashCap, 0);
-                }
-            }
-            __syncthreads();
-        }
-
-        PH_ACC(PH_INIT, t_init0);
+        plk_init<PROFILE>((AVP_LDS PlShared*)&s, pid);
         }
         const int wave = tid >> 6, lane = tid & 63;
         const int nwave = PL_THREADS / 64;
@@ -1825,7 +1875,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 } else if (look.on && wave == 0 && !ahead) {
                     // (a node popped ahead had its record fetched right behind the resolution that popped it)
                     wave_sync();
-                    pl_look_fetch(look, w, s, pid, maxNodes, s.cur, lane, s.nheap);
+                    plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.cur, s.nheap, 0, 0);
                 }
             }
             PH_ACC(PH_POP, t_pop); }
@@ -1847,7 +1897,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             uint32_t look_node = 0xffffffffu;
             if constexpr (LOOK) if (!helper && look.on && wave == nwave - 1) {
                 look_node = pl_look_candidate(w, s, lane);
-                if (!use_rec) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, true);      // (hidden behind the sub-step checks)
+                if (!use_rec) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, 1, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);      // (hidden behind the sub-step checks)
             }
             if (trace && tid == 0 && !helper && n_pops < max_trace) {
                 double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
@@ -1901,7 +1951,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 __syncthreads();
                 can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
                 t_f = PH_NOW();
-                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, PL_LOOK_KIDS_ON_HIT != 0);
+                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);
             } else {
             if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = hC ? 2 : 0; }
             // a helper runs its half only: queries = the children (hC), the shot (hS), both (an owner)
@@ -1928,7 +1978,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             } else if (one_pass && tid == PL_THREADS - 2 && !hC) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nq_all) pl_rs_build_schedule(s, nq_all);
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
-            if constexpr (LOOK) if (!helper && look.on && wave == 0) pl_look_prefetch(look, w, s, pid, maxNodes, lane, pl_look_prefetch_node(w, s));   // (wave 0 idles until the sub-step checks are done)
+            if constexpr (LOOK) if (!helper && look.on && wave == 0) plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, pl_look_prefetch_node(w, s));   // (wave 0 idles until the sub-step checks are done)
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
             const int nsubs = nchild * p.n_sub;
@@ -2049,7 +2099,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     wave_sync();
                     if (can_fast) {
                         pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
-                        if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.nheap); }
+                        if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0); }
                     }
                 }
                 if (wave >= w0 && wave < w0 + nw) {
@@ -2160,22 +2210,22 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             if (lane == 0 && *(volatile int32_t*)&s.wr_go == 0) *(volatile int32_t*)&s.wr_go = 2;
                             if (lane == 0 && *(volatile int32_t*)&s.fetch_go == 0) *(volatile int32_t*)&s.fetch_go = 2;
                         }
-                        else if (s.have_next) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.nheap);
+                        else if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0);
                     }
                 } else if (LOOK && use_rec && wave == 1) {
                     // record pop: the other waves are idle, so this one fetches the next node's record as soon as wave 0
                     // knows that node (before it sifts the heap), and does the bounded wait for a pending record
                     if constexpr (LOOK) {
-                        pl_look_prefetch(look, w, s, pid, maxNodes, lane, pre_cand);
+                        plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, pre_cand);
                         if (lane == 0) while (*(volatile int32_t*)&s.fetch_go == 0) __builtin_amdgcn_s_sleep(2);
                         wave_sync();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        if (*(volatile int32_t*)&s.fetch_go == 1) pl_look_fetch(look, w, s, pid, maxNodes, s.next_cur, lane, s.fetch_nheap, dims.hashCap, nchild, true);
+                        if (*(volatile int32_t*)&s.fetch_go == 1) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.fetch_nheap, nchild, 1);
                     }
                 } else if (LOOK && use_rec && wave == 2) {
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
                 } else if (LOOK && use_rec && wave == nwave - 1) {
-                    if constexpr (LOOK) pl_look_post(look, w, s, p, cn, pid, maxNodes, lane, look_node, PL_LOOK_KIDS_ON_HIT != 0);    // (beside the resolution on wave 0)
+                    if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
                 }
                 if (LOOK && use_rec) PH_MARK(3);
                 __syncthreads();
@@ -2242,7 +2292,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 }
                 __syncthreads();
                 if (!s.need_sweep) break;
-                pl_hquery_miss<PROFILE>(m, w, s, s.pending_id);
+                plk_sweep_extend<PROFILE>((AVP_LDS PlShared*)&s);
                 if (tid == 0) s.have_d = 1;
                 if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
                 __syncthreads();
@@ -2274,7 +2324,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
 
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
         if (tid == 0) {
-            pl_write_result<PROFILE>(p, w, s, s.k_travel_ddt, s.k_dth_ddt, results, paths, max_path, pid, n_pops, (int32_t)blockIdx.x, t_fin);
+            plk_write_result<PROFILE>((AVP_LDS PlShared*)&s, pid, n_pops, (int32_t)blockIdx.x, t_fin);
             if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } }   // ([8]: records used, a diagnostic)
         }
         __syncthreads();

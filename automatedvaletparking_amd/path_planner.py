@@ -73,6 +73,17 @@ class PlanResult:
         return STATUS_NAMES.get(self.status, str(self.status))
 
 
+def long_search_mode(dm, n: int) -> int:
+    """Kernel form for n searches that are all known to be LONG (the second stage of the two-stage deal,
+    automatedvaletparking_amd.distributed): the form with the shortest pop whose problem slots hold them all at once --
+    one workgroup per search up to the number of compute units, then four waves, a pair of waves, one wave per search."""
+    L = _native.lib()
+    for mode in (1, 4, 3):
+        if n <= int(L.avp_plan_slots(dm.h, C.c_int32(mode))):
+            return mode
+    return 2
+
+
 class BatchPlanner:
     """Device-side batched planner bound to one DeviceMap. Owns the scratch workspace (torch tensor)."""
 

@@ -79,12 +79,12 @@ def cpu_model():
 class Group:
     """One map + its problems on this rank's GPU."""
 
-    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP, mode=0, lookahead=None):
+    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP, mode=0, lookahead=None, max_nodes=MAX_NODES):
         import ctypes as C
         from automatedvaletparking_amd import _native, path_planner
         self.m = m
         self.dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=cap)
-        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=mode, lookahead=lookahead, stage_pops=STAGE_POPS)
+        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=max_nodes, max_path=MAX_PATH, mode=mode, lookahead=lookahead, stage_pops=STAGE_POPS)
         self.set_problems(starts, goals)
         L = _native.lib()
         # the kernel form that runs: 1 workgroup / 2 wave / 3 pair of waves / 4 four waves per problem, STAGED
@@ -145,6 +145,7 @@ def summarize(recs, n_slots, elapsed_per_step):
     return {"plans_per_s": float(done.sum()) / elapsed_per_step, "all_problems_per_s": len(rec) / elapsed_per_step,
             "expansions_per_s": pops / elapsed_per_step, "problems": int(len(rec)), "completed": int(done.sum()),
             "solved_frac": float((rec["status"] == 0).mean()), "iter_limit_frac": float((rec["status"] == 4).mean()),
+            "capacity_frac": float((rec["status"] == 5).mean()),
             "slot_utilisation": float(util_num / max(util_den, 1)), "ms_per_step": elapsed_per_step * 1e3}
 
 
@@ -289,7 +290,7 @@ def main():
         for (m, st, go) in groups_full:
             dm = _native.DeviceMap(m, veh, wcfg, device=local, max_pops=cap)
             planners.append((dm, path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=path_planner.STAGED, stage_pops=STAGE_POPS),
-                             path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=0)))
+                             {}))
 
         def two_stage(k):
             dm, bp1, bp2 = planners[k]
@@ -300,7 +301,11 @@ def main():
                 return r, p
 
             def stage2(s_l, g_l):
-                r, p, _ = bp2.plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True)
+                # every search of the second stage is a long one: the form whose slots hold them all at once
+                mode2 = path_planner.long_search_mode(dm, len(s_l))
+                if mode2 not in bp2:
+                    bp2[mode2] = path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=mode2)
+                r, p, _ = bp2[mode2].plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True)
                 return r, p
 
             return avd.two_stage_plan(stage1, stage2, st, go, rank, world)
@@ -347,7 +352,7 @@ def main():
         groups = []
         for k, (m, st, go) in enumerate(groups_full):
             g = _G()
-            g.dm, g.m, g.mode, g.bp, g.n = planners[k][0], m, path_planner.STAGED, planners[k][2], len(st)
+            g.dm, g.m, g.mode, g.bp, g.n = planners[k][0], m, path_planner.STAGED, planners[k][1], len(st)
             groups.append(g)
 
     if rank == 0:
@@ -486,18 +491,19 @@ def main():
                 out["saturating_batch"] = sat
                 # ---- cap sensitivity: the headline set and config[4] at pop caps 300 / 1000 / 3000 -----------------------------
                 sweep = {}
-                for wname in ("c2", "c5"):
+                for wname, caps in (("c2", (300, 1000, 3000)), ("c5", (300, 1000, 3000, 10000))):
                     lab_s, scfg, _, ssets = build(wname)
                     ms_, st_, go_ = ssets[0]
                     sweep[wname] = {}
-                    for cap_s in (300, 1000, 3000):
-                        gs = Group(ms_, veh, scfg, st_, go_, local, cap_s)
+                    for cap_s in caps:
+                        # (the node arena grows with the cap: a search makes ~7 nodes per pop)
+                        gs = Group(ms_, veh, scfg, st_, go_, local, cap_s, max_nodes=max(MAX_NODES, 8 * cap_s))
                         sec, os_ = time_group(gs, reps=1)
                         x = summarize([records(os_[0], gs.n)], [gs.slots], sec)
-                        sweep[wname][str(cap_s)] = {k: x[k] for k in ("plans_per_s", "expansions_per_s", "completed", "problems", "iter_limit_frac", "ms_per_step")}
+                        sweep[wname][str(cap_s)] = {k: x[k] for k in ("plans_per_s", "expansions_per_s", "completed", "problems", "iter_limit_frac", "capacity_frac", "ms_per_step")}
                         del gs
                 sweep["note"] = ("completed plans/s is a function of the cap only through the searches the cap stops: on Case1 a fifth of the random pairs never "
-                                 "connects (the reference would not terminate); on config[4] most searches need more than 300 pops")
+                                 "connects (the reference would not terminate); on config[4] most searches need thousands of pops")
                 out["cap_sweep"] = sweep
                 # ---- the 20 BenchmarkCases' own problems, run to termination (cap 30 000), one problem per launch ----------------
                 c20 = {}
