@@ -1,5 +1,6 @@
 // avp_plan_kernels.h -- batched hybrid-A* planner: one workgroup = one (start, goal) problem,
-// persistent workgroups pull problems from a global counter.
+// persistent workgroups pull problems from a global counter (plan_kernel), and the device functions it shares with the
+// group forms of avp_planw_kernels.h (one, two or four waves per problem).
 //
 // Replaces, per problem, PathPlanner.a_star_plan (path_plan/path_planner.py:58-110) with
 // hybrid_a_star.{__init__, expand_node, calc_node_cost, calc_node_heuristic, try_reach_goal,

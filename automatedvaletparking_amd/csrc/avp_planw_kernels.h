@@ -1,32 +1,40 @@
-// avp_planw_kernels.h -- batched hybrid-A* planner, THROUGHPUT forms: NW waves = one (start, goal) problem (NW = 1: the
-// wave form, NW = 2: the pair form, NW = 4: the quad form), PW_WAVES / NW independent problems per workgroup, persistent groups of waves pull
-// problems from a global counter.
+// avp_planw_kernels.h -- batched hybrid-A* planner, the GROUP forms: NW waves = one (start, goal) problem (NW = 1 the
+// wave form, 2 the pair form, 4 the quad form), PW_WAVES / NW independent problems per workgroup = per CU, persistent
+// groups of waves pull problems from a global counter.
 //
 // plan_kernel (avp_plan_kernels.h) spends a whole 512-thread workgroup on one problem to shorten a pop's critical
-// path; measured, its eight waves are busy 40 % of the time (the pop is a chain of dependent scalar fp64 code, every
-// phase is as long as its slowest wave). For batches much larger than the chip (north_star's 4 096 poses on 256 CUs)
-// latency per problem does not matter, resident problems per CU do: here every wave runs a complete search on its
-// own -- the same device functions, the same arithmetic in the same order, bit-identical results -- with no
-// workgroup barrier after the map tables have been staged. Replaces the same reference code as plan_kernel:
-// PathPlanner.a_star_plan (path_plan/path_planner.py:58-110), hybrid_a_star (path_plan/hybrid_a_star.py:72-389),
-// Dijkstra (path_plan/compute_h.py), rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-680), heapq order.
+// path: one problem per CU. A pop is a chain of dependent scalar fp64 code, so what a batch larger than the chip needs is
+// problems in flight: here a search runs on one, two or four waves -- the same device functions, the same arithmetic in
+// the same order, bit-identical results -- with no workgroup barrier after the map tables have been staged. Replaces the
+// same reference code as plan_kernel: PathPlanner.a_star_plan (path_plan/path_planner.py:58-110), hybrid_a_star
+// (path_plan/hybrid_a_star.py:72-389), Dijkstra (path_plan/compute_h.py), rs_curve.calc_optimal_path
+// (path_plan/rs_curve.py:99-680), heapq order.
+//
+// Structure: every phase of a pop is a CALLED function (pw_ph_*) on two LDS addresses -- the group's state (PwSharedT)
+// and the workgroup's constants (PwCommon, with copies of the kernel's arguments). Fully inlined, the pop loop held the
+// union of all phases' registers: 256 VGPRs plus spills, two waves per SIMD. Called, each phase has the register demand
+// of its own body; the kernel is compiled for 4 waves per SIMD (amdgpu_waves_per_eu propagates to the callees):
+// 122 .. 128 VGPRs, no VGPR spill in any phase loop (the scratch the compiler reports is the callee-saved registers a
+// phase saves on entry), 16 waves per CU.
 //
 // What differs from plan_kernel is only WHO does the work:
-//   * the sub-step and shot collision passes (pl_check_wave) and the fast child resolution (pl_resolve_fast_wave) were
-//     wave-local already and are used as they are; the heuristic sweep runs with the wave as its cooperating group;
+//   * the collision passes (pl_check_pass), the wave-parallel child resolution (pl_resolve_fast_wave) and the heuristic
+//     sweep (with the group as the cooperating set) are the shared device functions;
 //   * the shot is checked BEFORE the children are resolved, as in the reference (no speculation, no roll-back);
-//   * the Reeds-Shepp words are evaluated solver group by solver group, the words of one set_path type group in
-//     adjacent lanes: set_path's duplicate test (rs_curve.py:137-156) is a few shuffles inside the group and the
-//     running arg-min per query (:103-108, "<=": the later word wins a tie) lives in 17 x 3 LDS words -- no table of
-//     all 46 x 11 word results (the 28 KB that keep plan_kernel at one problem per CU).
-// The PAIR form (NW = 2) is the same code with the independent pieces of a pop dealt to two waves -- the collision
-// passes and the Reeds-Shepp solver rounds alternate between them, the sampler's bookkeeping runs beside the segment
-// origins -- behind a two-wave software barrier: a pop takes ~0.6 x the time of the wave form at half the problems in
-// flight, which is what a batch of a few problems per CU needs (its capped searches all run at once: their latency is
-// the launch time).
-// A shot with more than PW_RS_CAP samples (128 m of path) or a configuration with more than PW_MAXCHILD children is
-// handed back (status AVP_PLAN_RETRY, internal) and planned by plan_kernel in a second launch: results never depend
-// on the kernel that produced them.
+//   * Reeds-Shepp: only the queries the pop can use are solved (the shot inside flag_radius; a child unless expand_node
+//     drops it before calc_node_heuristic), solver group by solver group with the words of one set_path type group in
+//     adjacent lanes: the duplicate test (rs_curve.py:137-156) is a few shuffles inside the group and the running
+//     arg-min per query (:103-108, "<=": the later word wins a tie) a few LDS words -- no table of all 46 x 11 word
+//     results (the 28 KB that keep plan_kernel at one problem per CU);
+//   * NW > 1: the independent pieces of a pop are dealt to the group's waves behind a software barrier (an arrival
+//     counter in LDS; LDS-only where only LDS is handed over): the collision passes, the solver rounds (drawn from one
+//     counter, dearest first), the shot's sample rounds; the sampler's bookkeeping runs beside the segment origins. A pop
+//     takes ~0.75 x (pair) / ~0.6 x (quad) the time of the wave form at a half / a quarter of the problems in flight --
+//     what a batch of a few problems per CU needs: its long searches all run at once, so their latency IS the launch time.
+// A shot with more than PW_RS_CAP samples or a configuration with more than PW_MAXCHILD children is handed back (status
+// AVP_PLAN_RETRY, internal) and planned by plan_kernel in a later launch of the same call; the staged call
+// (avp_plan_batch_staged) uses the same hand-back for searches that outlive its first stage. Results never depend on the
+// kernel that produced them.
 #pragma once
 #include "avp_plan_kernels.h"
 
