@@ -496,8 +496,8 @@ def main():
                     ms_, st_, go_ = ssets[0]
                     sweep[wname] = {}
                     for cap_s in caps:
-                        # (the node arena grows with the cap: a search makes ~7 nodes per pop)
-                        gs = Group(ms_, veh, scfg, st_, go_, local, cap_s, max_nodes=max(MAX_NODES, 8 * cap_s))
+                        # (the node arena grows with the cap: a search makes up to 10 nodes per pop)
+                        gs = Group(ms_, veh, scfg, st_, go_, local, cap_s, max_nodes=max(MAX_NODES, 12 * cap_s))
                         sec, os_ = time_group(gs, reps=1)
                         x = summarize([records(os_[0], gs.n)], [gs.slots], sec)
                         sweep[wname][str(cap_s)] = {k: x[k] for k in ("plans_per_s", "expansions_per_s", "completed", "problems", "iter_limit_frac", "capacity_frac", "ms_per_step")}

@@ -35,14 +35,8 @@ def same(r, w):
 
 def free_pairs(m, dm, n_pairs, rng):
     """SURVEY 8(d) sampler: footprint-free (GPU check) poses outside every obstacle polygon, paired up."""
-    from automatedvaletparking_amd import sampling
-    free = []
-    while len(free) < 2 * n_pairs:
-        cand = sampling.sample_free_poses(m.boundary, m.case.obs, 8 * n_pairs, rng, margin=6.0, reject=False)
-        hit = dm.check_batch(cand)
-        free += [p for p, h in zip(cand, hit) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)]
-    poses = np.array(free[:2 * n_pairs])
-    return poses[0::2], poses[1::2]
+    from automatedvaletparking_amd import workloads
+    return workloads.sample_pairs(m, dm.check_batch, n_pairs, rng, chunk=8 * n_pairs)
 
 
 def plan_and_compare(m, veh, cfg, starts, goals, cap=CAP, threads=THREADS, max_nodes=8192):

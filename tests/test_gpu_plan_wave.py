@@ -141,3 +141,16 @@ def test_wave_form_hands_long_shots_back(form, vehicle, cfg, tmp_path):
     dm3 = _native.DeviceMap(m, vehicle, c3, max_pops=40)
     _same_results(path_planner.BatchPlanner(dm3, max_nodes=4096, mode=form).plan(starts[8:], goals[8:], max_trace=40),
                   path_planner.BatchPlanner(dm3, max_nodes=4096, mode=1).plan(starts[8:], goals[8:], max_trace=40))
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_group_forms_shot_at_every_pop(form, vehicle, cfg):
+    """config[4]'s parking lot (dense clutter, flag_radius 1e9: the Reeds-Shepp shot and its collision passes run at every
+    pop, the collision queue overflows and ranges are halved): 256 starts through every group form == the workgroup form."""
+    from automatedvaletparking_amd import _native, path_planner, workloads
+    m, c5, st, go, _ = workloads.c5_problems(cfg, 256, device="cuda")
+    dm = _native.DeviceMap(m, vehicle, c5, max_pops=150)
+    ref = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1, lookahead=False).plan(st, go, max_trace=150)
+    got = path_planner.BatchPlanner(dm, max_nodes=8192, mode=form).plan(st, go, max_trace=150)
+    _same_results(got, ref)
+    assert all(r.counters["n_rs"] >= r.n_pops for r in ref)

@@ -1,8 +1,9 @@
-"""Repository consistency (no GPU): the committed round-2 evidence was measured on the kernel sources that are committed.
+"""Repository consistency (no GPU): the committed round-3 evidence was measured on the kernel sources that are committed.
 bench.py stamps nothing itself -- it REFUSES a PMC summary whose `source_hash` (sha256 over csrc/ + include/) differs from
 the tree's and then prints null roofline fields; this test makes that situation fail here, before the GPU box sees it."""
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
@@ -16,12 +17,14 @@ def _load(name):
 def test_pmc_and_lookahead_evidence_match_the_sources():
     import bench
     h = bench.source_hash()
-    assert _load("r02_pmc_summary.json")["source_hash"] == h, "re-run scripts/gpu/profile_r02.sh: kernel sources changed after the PMC passes"
-    assert _load("r02_lookahead.json")["source_hash"] == h
+    assert _load(bench.PMC_FILE)["source_hash"] == h, "re-run scripts/gpu/profile_r03.sh: kernel sources changed after the PMC passes"
+    assert _load("r03_lookahead.json")["source_hash"] == h
+    assert _load("r03_pmc_saturating_batch.json")["source_hash"] == h
+    assert open(os.path.join(PROF, "r03_kernel_resource_usage.txt")).readline().strip().endswith("source_hash " + h), "re-run scripts/resource_usage.sh"
 
 
 def test_committed_bench_line_keeps_the_contract():
-    d = _load("r02_bench_n1.json")
+    d = _load("r03_bench_n1.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -30,19 +33,58 @@ def test_committed_bench_line_keeps_the_contract():
         assert r["bound"] in ("valu", "lds", "latency", "hbm", "mfma")
         assert r["frac"] is not None and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
         assert r["traffic"] is not None and r["traffic"] > 0
-    assert d["roofline"]["pmc_source"].endswith(_load("r02_pmc_summary.json")["source_hash"] + ")")
+    assert d["roofline"]["pmc_source"].endswith(_load("r03_pmc_summary.json")["source_hash"] + ")")
+    assert 0.0 < d["roofline"]["valu_lane_utilisation"] <= 1.0 and 0.0 < d["roofline"]["fp64_flops_frac"] < 1.0
     c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["cpu_model"]
     # the lookahead changes the time of a step, never a result
     assert d["config"]["expansion_lookahead"] is True and d["without_lookahead"]["identical_results"] is True
     assert d["without_lookahead"]["ms_per_step"] > d["ms_per_step"]
-    for k in ("batch4096", "c3", "c5", "saturating_batch"):
+    for k in ("batch4096", "scale_point", "c3", "c5", "saturating_batch", "cap_sweep", "cases20", "single_plan_latency_ms"):
         assert k in d, k
+    # every kernel form and the staged call plan the 4 096 set to the same records and paths
+    assert d["batch4096"]["forms_identical"] is True and len(d["batch4096"]["forms_ms_per_step"]) == 5
+    assert d["batch4096"]["ms_per_step"] == min(d["batch4096"]["forms_ms_per_step"].values())
+    # the 20 BenchmarkCases' own problems: every case the reference finishes is finished here
+    solved = {k for k, v in d["cases20"]["cases"].items() if v["status"] == "OK"}
+    assert {f"Case{k}" for k in (1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)} <= solved
+    assert d["cases20"]["cases"]["Case20"]["status"] == "NO_PATH"
+
+
+def test_force_dist_line_carries_the_in_run_reference():
+    d = _load("r03_bench_force_dist_n1.json")
+    assert d["scaling"] == "strong" and d["shard_invariant"] is True and d["config"]["problems"] == 4096
+    for k in ("one_gpu_ms_per_step", "speedup_vs_1gpu", "parallel_efficiency", "deal_simulation", "deferred_after_stage1"):
+        assert k in d, k
+    assert set(d["deal_simulation"]) == {"2", "4", "8"}
 
 
 def test_lookahead_evidence_is_consistent():
-    l = _load("r02_lookahead.json")
+    l = _load("r03_lookahead.json")
     assert l["identical_results"] is True and l["with_lookahead"]["lookahead_used"] and not l["without_lookahead"]["lookahead_used"]
     w = l["with_lookahead"]
     assert w["children_halves_made"] == w["jobs_posted"] == w["shot_halves_made"]          # every posted half-job was served
     assert 0 < w["records_used"] <= w["pops"] and w["pops"] == l["without_lookahead"]["pops"]
+    soak = _load("r03_lookahead_soak.json")
+    assert {"default", "look_atomics", "look_sleep1", "look_sleep127", "look_wait0", "look_wait50k", "look_fault5"} <= set(soak)
+    for name, s in soak.items():
+        assert s["launches"] >= 300 and s["launches_with_a_different_digest"] == 0 and s["lookahead_used"], name
+    # records published under a wrong key are turned down: fewer records used, same results
+    assert soak["look_fault5"]["records_used_min_median_max"][1] < soak["default"]["records_used_min_median_max"][1]
+
+
+def test_compiler_remarks_of_the_planner_kernels():
+    """the group forms fit 4 waves per SIMD without a spilled VGPR; plan_kernel (LDS-staged instantiations:
+    the ones every bench workload runs) spills none either."""
+    rows = {}
+    for line in open(os.path.join(PROF, "r03_kernel_resource_usage.txt")):
+        if line.startswith("#") or "|" not in line:
+            continue
+        name, rest = line.split("|", 1)
+        rows[name.strip()] = {k.strip(): int(v) for k, v in re.findall(r"([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", rest)}
+    waves = [k for k in rows if k.startswith("plan_wave_kernel<")]
+    assert len(waves) == 12
+    for k in waves:
+        assert rows[k]["VGPRs Spill"] == 0 and rows[k]["VGPRs"] <= 128 and rows[k]["Occupancy"] == 4, (k, rows[k])
+    for k in ("plan_kernel<true, false, true>", "plan_kernel<true, false, false>", "plan_kernel<true, true, true>", "plan_kernel<true, true, false>"):
+        assert rows[k]["VGPRs Spill"] == 0, (k, rows[k])
