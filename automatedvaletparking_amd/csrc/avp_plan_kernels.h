@@ -391,7 +391,7 @@ struct PlShared {
     int32_t regular;
     // sweep
     int32_t E;                        // buckets [0, E) are expanded
-    uint32_t qcount[PL_NQ];
+    uint32_t qcount[PL_NQ], qbase[PL_NQ];   // pushes so far / entries consumed so far, per rotating bucket queue
     int32_t qover;
     uint32_t dF; int64_t idF;         // key of the last miss (closed frontier)
     int32_t hasF;
@@ -654,44 +654,10 @@ AVP_D void pl_relax(const DevMap& m, const PlanWs& w, S& s, int col, int row, ui
     const uint32_t old = atomicMin(&w.dist[nid], nd);
     if (nd < old) {
         const int q = pl_bucket(nd) & (PL_NQ - 1);
-        const uint32_t pos = atomicAdd(&s.qcount[q], 1u);
+        const uint32_t pos = atomicAdd(&s.qcount[q], 1u) - s.qbase[q];       // (qcount counts every push ever, qbase what has been consumed)
         if (pos < PL_QCAP) w.queue[(size_t)q * PL_QCAP + pos] = ((unsigned long long)nd << 32) | (unsigned long long)nid;
         else s.qover = 1;
     }
-}
-
-// Expand bucket s.E (all threads). Each thread handles (entry, neighbour) pairs.
-// (One lane per ENTRY with its eight relaxations unrolled -- 8 x fewer rounds of the loop for a single wave -- was
-// measured in the wave form: no gain at 8 waves per CU, 15 % slower at 16, where the unrolled body spills.)
-template <bool PROFILE, class Coop = CoopWG, class S>
-AVP_D void pl_expand_bucket(const DevMap& m, const PlanWs& w, S& s)
-{
-    const long long t_sw = PH_NOW();
-    const int q = s.E & (PL_NQ - 1);
-    const uint32_t cnt = min(s.qcount[q], (uint32_t)PL_QCAP);
-    Coop::sync();
-    const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
-    const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };      // y up = row down
-    const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
-    for (uint32_t p = Coop::tid(); p < cnt * 8u; p += Coop::N) {
-        const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + (p >> 3)];
-        const int nbr = (int)(p & 7);
-        const uint32_t d = (uint32_t)(ent >> 32);
-        const int64_t id = (int64_t)(ent & 0xffffffffull);
-        if (w.dist[id] != d) continue;                    // stale entry (distance was lowered later)
-        if (w.flags[id] & PL_FLAG_T) continue;            // terminator: closed but never expanded
-        // queue ids are in [0, idCap) < 2^31 (the queue entry keeps 32 bits): 32-bit division, not the 64-bit sequence
-        const uint32_t id32 = (uint32_t)id, row_u = id32 / (uint32_t)m.S;
-        int col = (int)(id32 - row_u * (uint32_t)m.S), row = (int)row_u;
-        if (s.alias && col == 0) {
-            if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
-        }
-        if (nbr == 0) atomicAdd((unsigned long long*)&s.h_cells, 1ull);
-        pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, id, nbr);
-    }
-    Coop::sync();
-    if (Coop::tid() == 0) { s.qcount[q] = 0; s.E += 1; if constexpr (PROFILE) s.phase[PH_SWEEP] += clock64() - t_sw; }
-    Coop::sync();
 }
 
 // Heuristic query (hybrid_a_star.py:268-283 + compute_h.py:198-214), split in two:
@@ -709,28 +675,77 @@ AVP_D bool pl_hquery_hit(const DevMap& m, const S& s, int64_t id, uint32_t d, ui
     return false;
 }
 
+// The sweep loop, ONE group barrier per expanded bucket (round 2 and the first half of round 3 spent three per bucket --
+// read the count / expand / reset the count and advance -- and two per EMPTY bucket: ~400 buckets between goal and start,
+// the whole cost of a short search). What makes the single barrier enough:
+//  * the bucket queues are never reset: qcount[q] counts every push, qbase[q] what has been consumed; the entries of the
+//    current use of queue q sit at [0, qcount - qbase). A relaxation out of bucket E pushes into buckets E + 1, E + 2 only
+//    (edges weigh 10 .. 14, a bucket spans 10), never into queue E & 3 itself or into E + 3, so every count a thread reads at
+//    the top of an iteration was final at the barrier before -- no thread needs to be told;
+//  * every thread carries E and the four bases in registers and advances them identically; one thread mirrors the base of
+//    the consumed queue to LDS before the barrier (pl_relax reads it two buckets later) and E at the end;
+//  * the query cell's distance is not read until E reaches its lower bound -- the obstacle-free octile distance from the
+//    goal: the grid distance cannot be smaller -- which saves a dependent global load per bucket for most of the way.
+// Relaxations of a bucket commute (atomicMin on distances and alias keys, queue order is irrelevant), so the field, the
+// closed frontier and every counter are what the three-barrier loop produced (tests/test_gpu_hfield.py, no tolerance).
 template <bool PROFILE = false, class Coop = CoopWG, class S>
 AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, S& s, int64_t id)
 {
     Coop::sync();
     if (!(id >= 0 && id < (int64_t)m.S * (m.Sy + 3))) { if (Coop::tid() == 0) s.hq_d = PL_UNSEEN; Coop::sync(); return; }
-    for (;;) {
-        const uint32_t d = w.dist[id];
-        if (d != PL_UNSEEN && pl_bucket(d) <= s.E) break;
-        const uint32_t pending = s.qcount[0] + s.qcount[1] + s.qcount[2] + s.qcount[3];
-        if (pending == 0 || s.qover) break;
-        if (s.qcount[s.E & (PL_NQ - 1)] == 0) {
-            Coop::sync();
-            if (Coop::tid() == 0) s.E += 1;
-            Coop::sync();
-            continue;
+    const long long t_sw = PH_NOW();
+    int32_t E = s.E;
+    uint32_t b0 = s.qbase[0], b1 = s.qbase[1], b2 = s.qbase[2], b3 = s.qbase[3];
+    int32_t lbE = 0;
+    {
+        const uint32_t id32 = (uint32_t)id, row_u = id32 / (uint32_t)m.S;
+        const int col = (int)(id32 - row_u * (uint32_t)m.S), row = (int)row_u;
+        if (!(s.alias && col == 0)) {                       // (an aliased id may be the last-column cell of the row above: no bound)
+            const int dcl = abs(col - s.col0), drw = abs(row - s.row0);
+            lbE = (10 * max(dcl, drw) + 4 * min(dcl, drw)) / 10;
         }
-        pl_expand_bucket<PROFILE, Coop>(m, w, s);
+    }
+    const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
+    const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };      // y up = row down
+    const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
+    for (;;) {
+        if (E >= lbE) {
+            const uint32_t d = w.dist[id];
+            if (d != PL_UNSEEN && pl_bucket(d) <= E) break;
+        }
+        const uint32_t c0 = s.qcount[0] - b0, c1 = s.qcount[1] - b1, c2 = s.qcount[2] - b2, c3 = s.qcount[3] - b3;
+        if (c0 + c1 + c2 + c3 == 0 || s.qover) break;
+        const int q = E & (PL_NQ - 1);
+        const uint32_t full = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
+        if (full == 0) { E += 1; continue; }              // an empty bucket costs nothing
+        const uint32_t cnt = min(full, (uint32_t)PL_QCAP);
+        for (uint32_t p = Coop::tid(); p < cnt * 8u; p += Coop::N) {
+            const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + (p >> 3)];
+            const int nbr = (int)(p & 7);
+            const uint32_t d = (uint32_t)(ent >> 32);
+            const int64_t eid = (int64_t)(ent & 0xffffffffull);
+            if (w.dist[eid] != d) continue;                   // stale entry (distance was lowered later)
+            if (w.flags[eid] & PL_FLAG_T) continue;           // terminator: closed but never expanded
+            // queue ids are in [0, idCap) < 2^31 (the queue entry keeps 32 bits): 32-bit division, not the 64-bit sequence
+            const uint32_t id32 = (uint32_t)eid, row_u = id32 / (uint32_t)m.S;
+            int col = (int)(id32 - row_u * (uint32_t)m.S), row = (int)row_u;
+            if (s.alias && col == 0) {
+                if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
+            }
+            if (nbr == 0) atomicAdd((unsigned long long*)&s.h_cells, 1ull);
+            pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, eid, nbr);
+        }
+        if (q == 0) b0 += full; else if (q == 1) b1 += full; else if (q == 2) b2 += full; else b3 += full;
+        if (Coop::tid() == 0) s.qbase[q] += full;         // (read by pl_relax when bucket E + 2 pushes into this queue again)
+        E += 1;
+        Coop::sync();
     }
     Coop::sync();
     if (Coop::tid() == 0) {
+        s.E = E;
+        if constexpr (PROFILE) s.phase[PH_SWEEP] += clock64() - t_sw;
         const uint32_t d = w.dist[id];
-        s.hq_d = (d != PL_UNSEEN && pl_bucket(d) <= s.E) ? d : PL_UNSEEN;
+        s.hq_d = (d != PL_UNSEEN && pl_bucket(d) <= E) ? d : PL_UNSEEN;
         s.h_misses += 1;
         if (s.hq_d != PL_UNSEEN) {
             s.dF = d; s.idF = id; s.hasF = 1;
@@ -752,7 +767,7 @@ AVP_D void pl_sweep_init(const DevMap& m, const PlanWs& w, S& s, const PlanDims&
     for (int64_t i = tid; i < dims.rowCap; i += Coop::N) w.aliasKey[i] = ~0ull;
     if (tid == 0) {
         s.E = 0; s.qover = 0; s.hasF = 0; s.dF = 0; s.idF = 0;
-        for (int q = 0; q < PL_NQ; q++) s.qcount[q] = 0;
+        for (int q = 0; q < PL_NQ; q++) { s.qcount[q] = 0; s.qbase[q] = 0; }
         s.h_cells = 0; s.h_misses = 0;
         const int col0 = (int)floor((gx - m.b0) / m.dx);
         const int row0 = (int)floor((m.b3 - gy) / m.dy);

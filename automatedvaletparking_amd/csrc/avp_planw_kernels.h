@@ -160,7 +160,7 @@ struct PwSharedT {
     int64_t goal_id;
     int32_t regular;
     int32_t E;
-    uint32_t qcount[PL_NQ];
+    uint32_t qcount[PL_NQ], qbase[PL_NQ];
     int32_t qover;
     uint32_t dF; int64_t idF;
     int32_t hasF;
