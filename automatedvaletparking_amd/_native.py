@@ -21,7 +21,7 @@ AVP_MAX_STEER = 16
 EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
     "avp_check_batch", "avp_corridor_batch", "avp_corridor_batch_v", "avp_trig_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
-    "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch", "avp_plan_batch_profile", "avp_plan_batch_mode", "avp_plan_batch_ex", "avp_plan_look_bytes", "avp_plan_pick_mode", "avp_plan_slots", "avp_plan_group", "avp_plan_batch_staged",
+    "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch", "avp_plan_batch_profile", "avp_plan_batch_mode", "avp_plan_batch_ex", "avp_plan_look_bytes", "avp_plan_pick_mode", "avp_plan_slots", "avp_plan_group", "avp_plan_batch_staged", "avp_plan_set_slice_pops",
     "avp_hfield_id_capacity", "avp_hfield_queries", "avp_rasterize_edges",
 ]
 
@@ -190,6 +190,22 @@ class DeviceMap:
         and torch.cuda.Event timing sees it."""
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         chk(lib().avp_map_set_stream(self.h, C.c_void_p(s)), "avp_map_set_stream")
+
+    def planner_launch_begin(self):
+        """The planner's ticket counters (and a BatchPlanner's workspace) are one per handle: a planner launch issued on
+        another stream than the previous one waits for it (launches on one stream are ordered anyway)."""
+        cur = self.torch.cuda.current_stream(self.device)
+        ev = getattr(self, "_plan_event", None)
+        if ev is not None and self._plan_stream != cur.cuda_stream:
+            cur.wait_event(ev)
+
+    def planner_launch_end(self):
+        cur = self.torch.cuda.current_stream(self.device)
+        ev = getattr(self, "_plan_event", None)
+        if ev is None:
+            ev = self._plan_event = self.torch.cuda.Event()
+        ev.record(cur)
+        self._plan_stream = cur.cuda_stream
 
     def sync(self):
         chk(lib().avp_sync(self.h), "avp_sync")

@@ -53,6 +53,7 @@ struct avp_map {
     int32_t n_cu;
     // planner scratch owned by the handle (problem queue counter etc.)
     void* counters;
+    int32_t slice_pops;  // time slice of the group forms in pops (0 = never park a search); avp_plan_set_slice_pops
 };
 
 extern "C" {
@@ -151,6 +152,7 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
     d.colBits = (const uint64_t*)(base + oB); d.colStart = (const int32_t*)(base + oC);
     d.occ = (const uint8_t*)(base + oOcc);
     m->counters = base + oCnt;
+    m->slice_pops = PW_SLICE_POPS;
     *out = m;
     return AVP_OK;
 }

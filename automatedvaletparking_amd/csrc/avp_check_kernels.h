@@ -346,7 +346,7 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
 #define COR_QCAP 2048            // queue entries per wave
 #define COR_WAVES 6               // waves per workgroup, at most (the host launches as many as fit the LDS)
 #define COR_COLS 4                // map columns per broad-phase step (up to 3 bitmap words each: the AABB is grown by expand_dis)
-struct CorPose { double ac, as, expand; int32_t cs, pad; unsigned long long mn[4]; };   // |cos|, |sin|, heading case, minima {x_max, y_max, x_min, y_min}
+struct CorPose { double ac, as, expand; int32_t cs, pad; unsigned long long mn[4]; double pad2; };   // |cos|, |sin|, heading case, minima {x_max, y_max, x_min, y_min}; 9 doubles: an ODD record stride, like CHK_FPW
 
 static inline size_t corridor_lds_bytes(const DevMap& m, bool stage, int waves)
 {

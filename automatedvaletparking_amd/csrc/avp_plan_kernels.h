@@ -36,6 +36,9 @@
 #define PL_CHK_MAX 1280               // poses per collision pass (shot samples + sub-steps)
 #define PL_RS_CAP 1024                // samples of one RS shot
 #define PL_UNSEEN 0x7fffffffu
+#ifndef PL_SWEEP_U
+#define PL_SWEEP_U 4          // (entry, neighbour) pairs a lane relaxes per trip of the bucket loop
+#endif
 #ifndef PL_RELAX_PRECHECK
 #define PL_RELAX_PRECHECK 1              // (measured: the heuristic sweep 15 % shorter; 0 = every relaxation goes straight to the atomic)
 #endif
@@ -111,9 +114,11 @@ struct PlanWs {                       // per-slot workspace carve (device pointe
     uint32_t* hash;                   // [hashCap] node position + 1, 0 = empty
     double* rsbuf;                    // [PL_RS_CAP * 3]
     int8_t* rsdir;                    // [PL_RS_CAP]
+    char* park;                       // [PL_PARK_BYTES] a parked search's LDS state + its ring word (time-sliced group forms)
 };
+#define PL_PARK_BYTES 8192
 
-struct PlanDims { int64_t idCap, rowCap, maxNodes, hashCap; size_t bytes; };
+struct PlanDims { int64_t idCap, rowCap, maxNodes, hashCap; size_t bytes, parkOff; };
 
 static inline __host__ __device__ size_t pl_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -136,6 +141,8 @@ static inline __host__ __device__ PlanDims plan_dims(int32_t S, int32_t Sy, int3
     b += pl_al((size_t)d.hashCap * 4);
     b += pl_al((size_t)PL_RS_CAP * 3 * 8);
     b += pl_al((size_t)PL_RS_CAP);
+    d.parkOff = b;
+    b += pl_al((size_t)PL_PARK_BYTES);
     d.bytes = b;
     return d;
 }
@@ -153,6 +160,7 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
     w.hash = (uint32_t*)(base + o); o += pl_al((size_t)d.hashCap * 4);
     w.rsbuf = (double*)(base + o); o += pl_al((size_t)PL_RS_CAP * 3 * 8);
     w.rsdir = (int8_t*)(base + o);
+    w.park = base + d.parkOff;
     return w;
 }
 
@@ -623,6 +631,67 @@ AVP_D uint32_t pl_heap_pop(const PlanWs& w, S& s)
     return lastelt.node;
 }
 
+// heappop by a whole wave (all 64 lanes call it; nheap = the entry count BEFORE the pop, the same in every lane; returns
+// the popped node to every lane; the caller stores the new count). heapq's _siftup walks the hole from the root to a leaf
+// along the smaller children -- a chain of dependent loads, one round trip per level for a single lane. Here the wave
+// fetches six levels of the subtree under the hole at once (lane r - 1 holds relative position r), walks five levels on
+// register values (readlane), and repeats from where it stands: two round trips for 1 000 entries instead of ten. Lane k
+// remembers path position k and the entry that moves up into it. The final _siftdown of the last element compares it with
+// the path's ORIGINAL entries from the leaf upwards (each parent slot holds what was its child on the path) and stops at
+// the first one it does not beat: a ballot; the slots below that point end with their original entries (no store), the
+// ones above take their path child, the element lands in between -- the array the serial code leaves (PL_HEAP_POP_WAVE 0).
+#ifndef PL_HEAP_POP_WAVE
+#define PL_HEAP_POP_WAVE 1
+#endif
+AVP_D double pl_readlane_f64(double v, int l)          // l: the same in every lane (a scalar)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <class S>
+AVP_D uint32_t pl_heap_pop_wave(const PlanWs& w, S& s, int32_t nheap)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t nh = (uint32_t)__builtin_amdgcn_readfirstlane(nheap - 1);     // (scalar: the walk below is uniform control flow)
+    const PlHeapEnt last = pl_heap_get(w, s, (int32_t)nh);
+    if (nh == 0) return last.node;
+    const uint32_t r = (uint32_t)lane + 1u, k = 31u - (uint32_t)__clz(r);
+    uint32_t P = 1, cur1 = 1, root_node = 0;     // 1-based: root of the fetched subtree, the hole
+    int level = 0;
+    int32_t my_pos = 0;
+    PlHeapEnt my_ent; my_ent.f = 0.0; my_ent.node = 0; my_ent.pad = 0;
+    for (;;) {
+        const uint32_t abs1 = (P << k) + (r - (1u << k));
+        PlHeapEnt e; e.f = 0.0; e.node = 0; e.pad = 0;
+        if (r < 64u && abs1 <= nh) e = pl_heap_get(w, s, (int32_t)(abs1 - 1u));
+        if (P == 1) root_node = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.node);
+        uint32_t rr = 1;
+        bool leaf = false;
+        for (int step = 0; step < 5; step++) {
+            const uint32_t left1 = 2u * cur1;
+            if (left1 > nh) { leaf = true; break; }
+            const int cl = (int)(2u * rr) - 1;                                   // lane of the left child; the right one is next to it
+            double cf = pl_readlane_f64(e.f, cl);
+            uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)e.node, cl);
+            uint32_t right = 0;
+            if (left1 + 1u <= nh) {
+                const double rf = pl_readlane_f64(e.f, cl + 1);
+                if (!(cf < rf)) { right = 1; cf = rf; cn = (uint32_t)__builtin_amdgcn_readlane((int)e.node, cl + 1); }
+            }
+            if (lane == level) { my_pos = (int32_t)(cur1 - 1u); my_ent.f = cf; my_ent.node = cn; }
+            level++;
+            cur1 = left1 + right; rr = 2u * rr + right;
+        }
+        if (leaf) break;
+        P = cur1;
+    }
+    // lane t < level holds orig[pos_(t+1)]: the element stops at the lowest path index whose original entry it does not beat
+    const unsigned long long stop = __ballot(lane < level && !(last.f < my_ent.f));
+    const int j = stop ? 64 - __clzll((long long)stop) : 0;
+    if (lane < j) pl_heap_set(w, s, my_pos, my_ent);
+    if (lane == j) pl_heap_set(w, s, j < level ? my_pos : (int32_t)(cur1 - 1u), last);
+    return root_node;
+}
+
 // ---- heuristic sweep ---------------------------------------------------------------------------
 // Relax lattice cell (col, row) with new distance nd, discovered from (srcDist, srcId) via
 // neighbour slot nbr (compute_h.py:216-235 add_grid_to_openlist).
@@ -705,9 +774,10 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, S& s, int64_t id)
             lbE = (10 * max(dcl, drw) + 4 * min(dcl, drw)) / 10;
         }
     }
-    const int dc[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
-    const int dr[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };      // y up = row down
-    const uint32_t cost[8] = { 14, 10, 14, 10, 10, 14, 10, 14 };
+    // this lane's neighbour slot: 0..7 = (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1) in (col, row), y up = row down
+    const int nbr = Coop::tid() & 7, nb9 = nbr < 4 ? nbr : nbr + 1;
+    const int dcn = nb9 % 3 - 1, drn = nb9 / 3 - 1;
+    const uint32_t costn = (dcn != 0 && drn != 0) ? 14u : 10u;
     for (;;) {
         if (E >= lbE) {
             const uint32_t d = w.dist[id];
@@ -719,22 +789,78 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, S& s, int64_t id)
         const uint32_t full = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
         if (full == 0) { E += 1; continue; }              // an empty bucket costs nothing
         const uint32_t cnt = min(full, (uint32_t)PL_QCAP);
-        for (uint32_t p = Coop::tid(); p < cnt * 8u; p += Coop::N) {
-            const unsigned long long ent = w.queue[(size_t)q * PL_QCAP + (p >> 3)];
-            const int nbr = (int)(p & 7);
-            const uint32_t d = (uint32_t)(ent >> 32);
-            const int64_t eid = (int64_t)(ent & 0xffffffffull);
-            if (w.dist[eid] != d) continue;                   // stale entry (distance was lowered later)
-            if (w.flags[eid] & PL_FLAG_T) continue;           // terminator: closed but never expanded
-            // queue ids are in [0, idCap) < 2^31 (the queue entry keeps 32 bits): 32-bit division, not the 64-bit sequence
-            const uint32_t id32 = (uint32_t)eid, row_u = id32 / (uint32_t)m.S;
-            int col = (int)(id32 - row_u * (uint32_t)m.S), row = (int)row_u;
-            if (s.alias && col == 0) {
-                if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
+        // PL_SWEEP_U (entry, neighbour) pairs per lane and trip, stage by stage: the U queue loads, then the U distance/flag
+        // loads, the U pre-check loads and the U atomics are each in flight together -- a trip costs one chain of memory
+        // round trips whatever U is (Coop::N is a multiple of 8: a lane keeps its neighbour slot nbr for the whole sweep)
+        uint32_t cells = 0;
+        for (uint32_t p0 = Coop::tid(); p0 < cnt * 8u; p0 += Coop::N * PL_SWEEP_U) {
+            unsigned long long ent[PL_SWEEP_U];
+            bool v[PL_SWEEP_U];
+#pragma unroll
+            for (int k = 0; k < PL_SWEEP_U; k++) {
+                const uint32_t p = p0 + (uint32_t)k * Coop::N;
+                v[k] = p < cnt * 8u;
+                ent[k] = v[k] ? w.queue[(size_t)q * PL_QCAP + (p >> 3)] : 0ull;
             }
-            if (nbr == 0) atomicAdd((unsigned long long*)&s.h_cells, 1ull);
-            pl_relax(m, w, s, col + dc[nbr], row + dr[nbr], d + cost[nbr], d, eid, nbr);
+            uint32_t cur[PL_SWEEP_U];
+            uint8_t fl[PL_SWEEP_U];
+#pragma unroll
+            for (int k = 0; k < PL_SWEEP_U; k++) {
+                const uint32_t eid = (uint32_t)ent[k];               // (0 for an idle pair: a valid index, result unused)
+                cur[k] = w.dist[eid];
+                fl[k] = w.flags[eid];
+            }
+            uint32_t nd[PL_SWEEP_U], nid[PL_SWEEP_U];
+#pragma unroll
+            for (int k = 0; k < PL_SWEEP_U; k++) {
+                const uint32_t d = (uint32_t)(ent[k] >> 32), eid = (uint32_t)ent[k];
+                // stale entry (distance was lowered later) / terminator: closed but never expanded
+                v[k] = v[k] && cur[k] == d && !(fl[k] & PL_FLAG_T);
+                // queue ids are in [0, idCap) < 2^31 (the queue entry keeps 32 bits): 32-bit division, not the 64-bit sequence
+                const uint32_t row_u = eid / (uint32_t)m.S;
+                int col = (int)(eid - row_u * (uint32_t)m.S), row = (int)row_u;
+                if (s.alias && v[k] && col == 0) {
+                    if (w.aliasKey[row] & 1ull) { col = m.S; row -= 1; }   // owned by the last-column lattice cell
+                }
+                cells += (v[k] && nbr == 0) ? 1u : 0u;
+                // the relaxation of pl_relax, up to its distance load
+                col += dcn; row += drn;
+                nd[k] = d + costn;
+                v[k] = v[k] && !(col < s.colMin || col > s.colMax || row < s.rowMin || row > s.rowMax);
+                int ox = col - 1;
+                if (ox >= m.S) ox = m.S - 1;
+                if (ox < 0) ox += m.nx;
+                int oy = s.orow0 + (s.row0 - row);
+                if (oy >= m.Sy) oy = m.Sy - 1;
+                if (oy < 0) oy += m.ny;
+                if (v[k]) v[k] = !((s.mt.bits[(size_t)ox * m.wpc + (oy >> 6)] >> (oy & 63)) & 1ull);
+                nid[k] = (uint32_t)col + (uint32_t)row * (uint32_t)m.S;
+                if (s.alias && v[k] && (col == 0 || col == m.S)) {
+                    const int slot = col == 0 ? row : row + 1;
+                    const unsigned long long key = ((unsigned long long)d << 44) | ((unsigned long long)eid << 8) |
+                                                   ((unsigned long long)nbr << 1) | (col == 0 ? 0ull : 1ull);
+                    atomicMin(&w.aliasKey[slot], key);
+                }
+            }
+#if PL_RELAX_PRECHECK
+#pragma unroll
+            for (int k = 0; k < PL_SWEEP_U; k++) cur[k] = v[k] ? w.dist[nid[k]] : 0u;
+#pragma unroll
+            for (int k = 0; k < PL_SWEEP_U; k++) v[k] = v[k] && !(cur[k] <= nd[k]);
+#endif
+#pragma unroll
+            for (int k = 0; k < PL_SWEEP_U; k++) if (v[k]) cur[k] = atomicMin(&w.dist[nid[k]], nd[k]);
+#pragma unroll
+            for (int k = 0; k < PL_SWEEP_U; k++) {
+                if (v[k] && nd[k] < cur[k]) {
+                    const int q2 = pl_bucket(nd[k]) & (PL_NQ - 1);
+                    const uint32_t pos = atomicAdd(&s.qcount[q2], 1u) - s.qbase[q2];   // (qcount counts every push ever, qbase what has been consumed)
+                    if (pos < PL_QCAP) w.queue[(size_t)q2 * PL_QCAP + pos] = ((unsigned long long)nd[k] << 32) | (unsigned long long)nid[k];
+                    else s.qover = 1;
+                }
+            }
         }
+        if (cells) atomicAdd((unsigned long long*)&s.h_cells, (unsigned long long)cells);
         if (q == 0) b0 += full; else if (q == 1) b1 += full; else if (q == 2) b2 += full; else b3 += full;
         if (Coop::tid() == 0) s.qbase[q] += full;         // (read by pl_relax when bucket E + 2 pushes into this queue again)
         E += 1;
@@ -1401,9 +1527,22 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         wave_sync();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    if (lane == 0 && pop_ahead && s.nheap > 0) {
+#if PL_HEAP_POP_WAVE
+    if (pop_ahead && nheap > 0) {                       // (nheap: the count lane 0 has just stored, the same in every lane)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // heappop returns the root; the sift that follows only restores the heap. Publish the node first: on a record pop
-        // another wave fetches its expansion record (and waits for a pending one) while this lane walks the heap.
+        // another wave fetches its expansion record (and waits for a pending one) while this wave walks the heap.
+        const uint32_t root = pl_heap_get(w, s, 0).node;
+        if (lane == 0) {
+            s.next_cur = (int32_t)root; s.have_next = 1; s.fetch_nheap = nheap - 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            *(volatile int32_t*)&s.fetch_go = 1;
+        }
+        const uint32_t c = pl_heap_pop_wave(w, s, nheap);
+        if (lane == 0) { s.nheap = nheap - 1; w.nodes[c].state = 3; }
+    }
+#else
+    if (lane == 0 && pop_ahead && s.nheap > 0) {
         const uint32_t root = pl_heap_get(w, s, 0).node;
         s.next_cur = (int32_t)root; s.have_next = 1; s.fetch_nheap = s.nheap - 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1411,6 +1550,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         const uint32_t c = pl_heap_pop(w, s);
         w.nodes[c].state = 3;
     }
+#endif
     wave_sync();
     if constexpr (PROFILE) { if (threadIdx.x == 0) { s.phase[PH_RES_CLASSIFY] += t_r1 - t_r0; s.phase[PH_RES_WRITE] += t_r2 - t_r1; s.phase[PH_RES_PUSH] += t_r3 - t_r2; s.phase[PH_SPARE] += clock64() - t_r3; } }
 }
@@ -2204,7 +2344,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     PL_LOOK_DRAIN();
                     wave_sync();
                     if (lane == 0) { PL_FLAG_OR32(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
-                    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % PL_LOOK_FAULT == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
+                    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
                 }
                 continue;
             }

@@ -98,6 +98,12 @@ struct PwCommon {
     int64_t max_pops;                 // the caller's pop cap (status ITER_LIMIT)
     int64_t stage_pops;               // > 0: a search still running after this many pops is handed back (AVP_PLAN_RETRY)
     unsigned int* deferred;           // ... and counted here
+    // time slicing (slice_pops > 0; see plan_wave_kernel): problem i lives in workspace slot i
+    int32_t slice_pops, sl_pad;
+    int64_t n;
+    unsigned int* counter;            // unstarted problems are drawn from it
+    unsigned int* sl;                 // {resume tickets served, resume tickets issued, searches finished}
+    char* workspace;
 };
 
 // The waves that cooperate on one problem. NW = 1: one wave (wave-level syncs only). NW > 1: NW adjacent waves of the
@@ -105,11 +111,25 @@ struct PwCommon {
 // static LDS (s_barrier would stop the whole workgroup: the groups are independent searches).
 __shared__ uint32_t PW_BAR_CNT[PW_WAVES];
 __shared__ uint32_t PW_BAR_GEN[PW_WAVES];
+#ifndef PW_SLICE_POPS
+#define PW_SLICE_POPS 64       // default time slice of a search in pops (avp_plan_set_slice_pops; 32 ... 200, and a shorter first slice: no measurable difference)
+#endif
+#ifndef PW_ROTATE
+#define PW_ROTATE 0             // (measured on the 4 096-problem batch, quad form: 92.6 ms with, 91.8 ms without -- no gain, off)
+#endif
 template <int NW>
 struct PwGroup {
     static constexpr int N = 64 * NW;
-    static __device__ __forceinline__ int tid() { return threadIdx.x & (N - 1); }
-    static __device__ __forceinline__ int wv() { return (threadIdx.x >> 6) & (NW - 1); }
+    // Role of a wave inside its group (0 = the wave that runs the serial parts: pops, resolution, result record). The
+    // hardware places wave k of a workgroup on SIMD k % 4: with PW_ROTATE the role index is rotated by the group number, so
+    // that the groups of a CU have their wave 0 on different SIMDs (the serial parts wait on memory, not on the VALU: it
+    // makes no measurable difference).
+    static __device__ __forceinline__ int wv()
+    {
+        const int w = threadIdx.x >> 6;
+        return (PW_ROTATE && NW > 1) ? ((w + w / NW) & (NW - 1)) : (w & (NW - 1));
+    }
+    static __device__ __forceinline__ int tid() { return wv() * 64 + (int)(threadIdx.x & 63); }
     // lanes of the group hand data to each other through LDS and through global memory (queues, arena): both must have landed
     static __device__ __forceinline__ void sync()
     {
@@ -209,6 +229,7 @@ struct PwSharedT {
     static constexpr bool HEAP_POS = true;
     static constexpr int HEAP_LDS = 0;         // (no LDS heap top in these forms: the whole open list stays in the workspace)
     uint32_t phase[PW_PH_COUNT];               // instrumented instantiation only: shader cycles per phase (lane 0)
+    int32_t resume, fresh_done, park_now, sl_pad;   // time slicing: this problem continues a parked search / no unstarted problem is left / park decision
     __device__ __forceinline__ PlWaveChkT<PW_WQCAP>& wave_chk() { return wchk[PwGroup<NW>::wv()]; }
 };
 
@@ -710,6 +731,76 @@ __device__ __noinline__ void pw_ph_resolve_slow(PW_PHASE_ARGS)
 }
 
 // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) ------------------------------------------------------------
+// ---- time slicing: a search leaves its group (state -> its workspace slot, a ticket in the resume ring) / comes back ----
+// What survives between two pops of a search is the head of PwSharedT up to the per-phase scratch union plus its workspace
+// slot. The group that takes the search up again may sit on another XCD: agent-scope release / acquire around the hand-over
+// (write-back / invalidate of the L2s; every wave fences its own stores).
+#define PW_SAVE_WORDS(NW) ((int)((offsetof(PwSharedT<NW>, wchk) + 3) / 4))
+AVP_D uint32_t* pw_ring_word(const PwCommon& c, uint32_t ticket)
+{
+    return (uint32_t*)(c.workspace + (size_t)(ticket % (uint32_t)c.n) * c.dims.bytes + c.dims.parkOff + (PL_PARK_BYTES - 4));
+}
+template <int NW>
+__device__ __noinline__ void pw_ph_park(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    static_assert(offsetof(PwSharedT<NW>, wchk) + 8 <= PL_PARK_BYTES, "park area");
+    uint32_t* dst = (uint32_t*)s.w.park;
+    const int32_t pid = s.pid;
+    const uint32_t* src = (const uint32_t*)&s;
+    for (int i = gtid; i < PW_SAVE_WORDS(NW); i += G::N) dst[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    G::sync();
+    if (gtid == 0) {
+        const uint32_t t = atomicAdd(c.sl + 1, 1u);
+        __hip_atomic_store(pw_ring_word(c, t), (uint32_t)pid + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    G::sync();
+}
+template <int NW>
+__device__ __noinline__ void pw_ph_restore(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    const uint32_t* src = (const uint32_t*)(c.workspace + (size_t)s.pid * c.dims.bytes + c.dims.parkOff);
+    G::sync_lds();                                      // (every lane holds the address before the head of s is overwritten)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint32_t* dst = (uint32_t*)&s;
+    for (int i = gtid; i < PW_SAVE_WORDS(NW); i += G::N) dst[i] = src[i];
+    G::sync();
+}
+// The next problem of this group: an unstarted one while there are any, then a parked search from the ring (in the order
+// they were parked), or 0x7fffffff once every search of the batch has finished. Lane 0 of the group.
+AVP_D void pw_next_problem(const PwCommon& c, const int32_t* order, int32_t& pid, int32_t& resume, int32_t& fresh_done)
+{
+    pid = 0x7fffffff; resume = 0;
+    if (!fresh_done) {
+        const uint32_t t = atomicAdd(c.counter, 1u);
+        if ((int64_t)t < c.n) { pid = order ? order[t] : (int32_t)t; return; }
+        fresh_done = 1;
+    }
+    if (c.slice_pops <= 0) return;
+    for (uint32_t spin = 0; spin < (1u << 26); spin++) {         // (bounded: a lost ticket must not hang the device)
+        if ((int64_t)__hip_atomic_load(c.sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= c.n) return;
+        const uint32_t h = __hip_atomic_load(c.sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tl = __hip_atomic_load(c.sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(tl - h) > 0) {
+            if (atomicCAS(c.sl + 0, h, h + 1u) != h) continue;
+            uint32_t* e = pw_ring_word(c, h);                    // ticket h is ours: its entry follows the ticket's issue at once
+            uint32_t v = 0;
+            for (uint32_t w2 = 0; w2 < (1u << 24); w2++) {
+                v = __hip_atomic_load(e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!v) return;
+            __hip_atomic_store(e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pid = (int32_t)(v - 1u); resume = 1;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 template <int NW>
 __device__ __noinline__ void pw_ph_finish(PW_PHASE_ARGS)
 {
@@ -741,7 +832,8 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
                                                                double* __restrict__ paths, int32_t max_path,
                                                                double* __restrict__ trace, int32_t max_trace,
                                                                const int32_t* __restrict__ order, int32_t stage_pops, int32_t retry_only,
-                                                               unsigned int* __restrict__ deferred, int32_t gate_lo, int32_t gate_hi)
+                                                               unsigned int* __restrict__ deferred, int32_t gate_lo, int32_t gate_hi,
+                                                               int32_t slice_pops, unsigned int* __restrict__ sl)
 {
     typedef PwGroup<NW> G;
     // second stage of a staged call (retry_only with a gate): the host launches every form, the one whose range
@@ -766,7 +858,9 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
             c.max_path = max_path; c.max_trace = max_trace; c.maxNodes = maxNodes; c.nchild = 2 * p.n_steer; c.nsubs = 2 * p.n_steer * p.n_sub; c.retry_only = retry_only;
             c.max_pops = p.max_pops > 0 ? p.max_pops : (int64_t)1 << 40;
             c.stage_pops = stage_pops; c.deferred = retry_only ? nullptr : deferred;
+            c.slice_pops = (PROFILE || retry_only) ? 0 : slice_pops; c.n = n; c.counter = counter; c.sl = sl; c.workspace = workspace;
         }
+        if (gtid == 0) s.fresh_done = 0;
         if (tid < PW_WAVES) { PW_BAR_CNT[tid] = 0; PW_BAR_GEN[tid] = 0; }
     }
 #pragma unroll
@@ -794,18 +888,42 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
     if (tid == 0) pl_chk_env_fill(c.env, m, p, STAGE ? mt.X : nullptr, STAGE ? mt.Y : nullptr, STAGE ? mt.bits : nullptr);
     __syncthreads();                                   // the last workgroup barrier: from here on every group is on its own
 
+    // Time slicing (slice_pops > 0; the host gives every problem its own workspace slot): a search that is still running
+    // after slice_pops pops is parked when another problem is waiting for a group -- an unstarted one, or a parked one in
+    // the resume ring -- and the group takes the next problem: unstarted ones first, then the parked ones in turn. The long
+    // searches of a batch (a fifth of the problems, nine tenths of the pops) advance side by side instead of one after the
+    // other, and the batch ends within a slice of the moment the work runs out, not within a whole long search of it.
+    // A search is the same search wherever it runs: results do not depend on the slicing.
+    const bool sliced = !PROFILE && !retry_only && slice_pops > 0;
     for (;;) {
         G::sync();
-        if (gtid == 0) { const uint32_t t = atomicAdd(counter, 1u); s.pid = (int64_t)t < n ? (order ? order[t] : (int32_t)t) : 0x7fffffff; }
+        if (gtid == 0) {
+            int32_t pid, resume, fd = s.fresh_done;
+            pw_next_problem(c, order, pid, resume, fd);
+            s.pid = pid; s.resume = resume; s.fresh_done = fd;
+            if (sliced && pid < n) { s.w = plan_carve(workspace + (size_t)pid * c.dims.bytes, c.dims); s.slot = pid; }
+        }
         G::sync();
         if (s.pid >= n) break;
         if (retry_only && results[s.pid].status != AVP_PLAN_RETRY) continue;      // (second stage: only what the first handed back)
         long long t_ph = PROFILE ? clock64() : 0ll;
         if constexpr (PROFILE) { if (gtid == 0) for (int k = 0; k < PW_PH_COUNT; k++) s.phase[k] = 0; }
-        pw_ph_init<NW>(sp, cp);
+        if (sliced && s.resume) pw_ph_restore<NW>(sp, cp);
+        else pw_ph_init<NW>(sp, cp);
         PW_T(PW_PH_INIT);
+        int64_t slice_end = sliced ? s.n_pops + slice_pops : (int64_t)1 << 62;
+        bool parked = false;
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
         while (s.status == 0 && !s.done) {
+            if (s.n_pops >= slice_end) {
+                if (gtid == 0) {
+                    const uint32_t h = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tl = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s.park_now = ((int64_t)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n || (int32_t)(tl - h) > 0) ? 1 : 0;
+                }
+                G::sync_lds();
+                if (s.park_now) { pw_ph_park<NW>(sp, cp); parked = true; break; }
+                slice_end += slice_pops;
+            }
             pw_ph_pop<NW>(sp, cp);
             if (s.status != 0) break;
             PW_T(PW_PH_POP);
@@ -825,8 +943,10 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
             pw_ph_resolve_slow<NW>(sp, cp);
             PW_T(PW_PH_SLOW);
         }
+        if (parked) continue;
         if constexpr (PROFILE) t_ph = clock64();
         pw_ph_finish<NW>(sp, cp);
+        if (sliced && gtid == 0) atomicAdd(sl + 2, 1u);
         if constexpr (PROFILE) { if (gtid == 0 && s.status != AVP_PLAN_RETRY) { s.phase[PW_PH_FINISH] += (uint32_t)(clock64() - t_ph); for (int k = 0; k < PW_PH_COUNT; k++) results[s.pid].phase_cycles[k] = s.phase[k]; } }
         G::sync();
     }

@@ -482,7 +482,11 @@ __global__ __launch_bounds__(64) void rs_optimal_kernel(const double* __restrict
     rs_lds_tables_fill();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    RsPath p;
+    // the winning word lives in LDS (its segments are indexed at run time by the sampler: a private copy would be a
+    // scratch array), one record per lane at an odd stride in doubles
+    static_assert(sizeof(RsPath) <= 8 * 8, "RsPath record");
+    __shared__ double lp[64 * 9];
+    RsPath& p = *reinterpret_cast<RsPath*>(lp + 9 * threadIdx.x);
     const double ax = q0[3 * i], ay = q0[3 * i + 1], at = q0[3 * i + 2];
     int st = rs_optimal(ax, ay, at, q1[3 * i], q1[3 * i + 1], q1[3 * i + 2], maxc, p);
     for (int k = 0; k < 5; k++) { types[i * 5 + k] = st ? (int8_t)-1 : p.t[k]; lens[i * 5 + k] = st ? 0.0 : p.l[k] / maxc; }

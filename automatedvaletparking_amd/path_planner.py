@@ -89,7 +89,8 @@ class BatchPlanner:
 
     def __init__(self, device_map: _native.DeviceMap, max_nodes: int = 65536, n_slots: Optional[int] = None,
                  max_path: int = 512, mode: int = 0, lookahead: Optional[bool] = None,
-                 longest_first: bool = False, stage_pops: int = 16):
+                 longest_first: bool = False, stage_pops: int = 16, time_slice: Optional[bool] = None,
+                 slice_pops: Optional[int] = None):
         """mode: 0 = the library's choice by batch size, 1 = one workgroup per problem, 2 = one wave, 3 = a pair of waves,
         4 = four waves per problem (include/avp.h: avp_plan_batch_mode), STAGED = avp_plan_batch_staged: every problem in
         the wave form for stage_pops pops, the searches still running then planned again in the form that suits their
@@ -98,6 +99,10 @@ class BatchPlanner:
         lookahead: let the compute units without a problem of their own pre-compute node expansions for the running
         searches (avp_plan_batch_ex; results are identical either way). None = when the library wants it for the batch
         and its record store fits LOOK_BYTES_MAX, True = whenever the library supports it, False = never.
+        time_slice: group forms (modes 2 - 4) with more problems than groups: give every problem its own workspace slot, so
+        that the kernel parks a search that is still running after slice_pops pops (default: the library's, 64) while
+        others wait and the long searches advance side by side (include/avp.h: avp_plan_set_slice_pops; same results).
+        None = when the slots fit SLICE_FREE_FRAC of the free device memory, True = always, False = never.
         longest_first: start a batch with more problems than slots by decreasing start-goal distance (the `order` argument of
         avp_plan_batch_ex; results keep the caller's order). Off by default: on the bench's random pairs the distance does not
         predict the length of the search (4 096 problems: 119 vs 116 ms in index order, scripts/order_bench.py)."""
@@ -114,11 +119,30 @@ class BatchPlanner:
         self.lookahead = lookahead
         self.longest_first = bool(longest_first)
         self.stage_pops = int(stage_pops)
+        self.time_slice = time_slice
+        self.slice_pops = slice_pops
+        self.last_time_sliced = False
         self._look = None
         self.last_lookahead = False
 
     LOOK_BYTES_MAX = 24 << 30          # (512 problems x 16 384 nodes x 4 x 708 B = 23.8 GB of MI355X's 288)
     LOOK_FREE_FRAC = 0.25              # ... and at most this share of the device memory that is free right now
+    SLICE_FREE_FRAC = 0.5              # time slicing: one workspace slot per problem, at most this share of the free memory
+
+    def _slice_slots(self, n, wg, mode):
+        """Slot count for a time-sliced launch of n problems in group form `mode` (a slot per problem), or 0."""
+        if self.time_slice is False or self.n_slots or mode < 2:
+            return 0
+        L = _native.lib()
+        if n <= int(L.avp_plan_slots(self.dm.h, C.c_int32(mode))):
+            return 0                                        # every problem has a group of its own from the start
+        want = wg * ((n + wg - 1) // wg)
+        if self.time_slice is None and not (self._ws is not None and self._ws_slots >= want):
+            nbytes = int(L.avp_plan_workspace_bytes(self.dm.h, C.c_int32(want), C.c_int32(self.max_nodes)))
+            free, _ = self.dm.torch.cuda.mem_get_info(self.dm.device)
+            if nbytes <= 0 or nbytes > self.SLICE_FREE_FRAC * free:
+                return 0
+        return want
 
     def _look_workspace(self, n):
         """The lookahead's record store, or None. lookahead=None (the default) is conservative: never for a single problem
@@ -166,6 +190,7 @@ class BatchPlanner:
         first stage; unfinished searches carry status 100 (DEFERRED)."""
         torch = self.dm.torch
         self.dm.use_current_stream()
+        self.dm.planner_launch_begin()
         n = starts_t.shape[0]
         L = _native.lib()
         if self.mode == STAGED and not profile:
@@ -182,6 +207,7 @@ class BatchPlanner:
                                                 C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
                                                 C.c_void_p(trace.data_ptr()) if trace is not None else None, C.c_int32(max_trace),
                                                 C.c_int32(self.stage_pops), C.c_int32(1 if first_stage_only else 0), None), "avp_plan_batch_staged")
+            self.dm.planner_launch_end()
             return res, paths, trace
         mode = (self.mode if self.mode in (2, 3, 4) else 1) if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode if self.mode != STAGED else 0)))
         cap = self.n_slots if self.n_slots else int(L.avp_plan_slots(self.dm.h, C.c_int32(mode)))
@@ -189,6 +215,11 @@ class BatchPlanner:
         slots = max(1, min(cap, wg * ((n + wg - 1) // wg)))
         if mode >= 2 and slots < wg:
             mode = 1                                        # fewer than one workgroup of slots: the workgroup form
+        sliced = 0 if profile else self._slice_slots(n, wg, mode)
+        self.last_time_sliced = bool(sliced)
+        if sliced:
+            slots = sliced
+            _native.chk(L.avp_plan_set_slice_pops(self.dm.h, C.c_int32(-1 if self.slice_pops is None else int(self.slice_pops))), "avp_plan_set_slice_pops")
         ws = self._workspace(slots)
         res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
         paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
@@ -210,6 +241,7 @@ class BatchPlanner:
                                             C.c_void_p(look.data_ptr()) if look is not None else None, C.c_int64(look.numel() if look is not None else 0),
                                             C.c_void_p(order.data_ptr()) if order is not None else None), "avp_plan_batch_ex")
         self._keep = (look, order)                          # (alive until the next call: the launch is asynchronous)
+        self.dm.planner_launch_end()
         return res, paths, trace
 
     def plan(self, starts, goals, max_trace: int = 0) -> List[PlanResult]:

@@ -79,12 +79,12 @@ def cpu_model():
 class Group:
     """One map + its problems on this rank's GPU."""
 
-    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP, mode=0, lookahead=None, max_nodes=MAX_NODES):
+    def __init__(self, m, veh, cfg, starts, goals, local, cap=POP_CAP, mode=0, lookahead=None, max_nodes=MAX_NODES, time_slice=None):
         import ctypes as C
         from automatedvaletparking_amd import _native, path_planner
         self.m = m
         self.dm = _native.DeviceMap(m, veh, cfg, device=local, max_pops=cap)
-        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=max_nodes, max_path=MAX_PATH, mode=mode, lookahead=lookahead, stage_pops=STAGE_POPS)
+        self.bp = path_planner.BatchPlanner(self.dm, max_nodes=max_nodes, max_path=MAX_PATH, mode=mode, lookahead=lookahead, stage_pops=STAGE_POPS, time_slice=time_slice)
         self.set_problems(starts, goals)
         L = _native.lib()
         # the kernel form that runs: 1 workgroup / 2 wave / 3 pair of waves / 4 four waves per problem, STAGED
@@ -460,6 +460,7 @@ def main():
                     r4, p4 = records(o4[0], g4.n), o4[1].cpu().numpy()
                     forms[mode] = summarize([r4], [g4.slots], sec)
                     forms[mode]["kernel_form"] = FORM_NAMES[mode]
+                    forms[mode]["time_sliced"] = bool(g4.bp.last_time_sliced)
                     if ref_rp is None:
                         ref_rp = (r4, p4)
                     else:
@@ -483,11 +484,21 @@ def main():
                 st16 = np.concatenate([st4] * 4)
                 go16 = np.concatenate([np.roll(go4, 17 * k, axis=0) for k in range(4)])
                 sat = {"workload": "Case1 map, 16384 problems (the 4096 starts against 4 rotations of the goals), pop cap 1000"}
-                for mode, key in ((1, "workgroup_per_problem"), (2, "wave_per_problem"), (3, "pair_per_problem"), (4, "quad_per_problem"), (path_planner.STAGED, "staged")):
-                    g16 = Group(mm, veh, xcfg, st16, go16, local, xcap, mode=mode)
+                # (group forms: a workspace slot per problem, long searches time-sliced -- it pays where they outnumber the groups)
+                for mode, key, ts in ((1, "workgroup_per_problem", None), (2, "wave_per_problem", None), (3, "pair_per_problem", None), (4, "quad_per_problem", None),
+                                      (path_planner.STAGED, "staged", None), (2, "wave_per_problem_unsliced", False), (3, "pair_per_problem_unsliced", False)):
+                    g16 = Group(mm, veh, xcfg, st16, go16, local, xcap, mode=mode, time_slice=ts)
                     sec, o16 = time_group(g16, reps=1)
                     sat[key] = summarize([records(o16[0], g16.n)], [g16.slots], sec)
+                    sat[key]["time_sliced"] = bool(g16.bp.last_time_sliced)
                     del g16
+                st32, go32 = np.concatenate([st16] * 2), np.concatenate([go16, np.roll(go16, 5, axis=0)])
+                for key, ts in (("wave_per_problem", None), ("wave_per_problem_unsliced", False)):
+                    g32 = Group(mm, veh, xcfg, st32, go32, local, xcap, mode=2, time_slice=ts)
+                    sec, o32 = time_group(g32, reps=1)
+                    sat["n32768_" + key] = summarize([records(o32[0], g32.n)], [g32.slots], sec)
+                    sat["n32768_" + key]["time_sliced"] = bool(g32.bp.last_time_sliced)
+                    del g32
                 out["saturating_batch"] = sat
                 # ---- cap sensitivity: the headline set and config[4] at pop caps 300 / 1000 / 3000 -----------------------------
                 sweep = {}

@@ -219,6 +219,16 @@ int32_t avp_plan_batch_staged(avp_map* map, const double* starts, const double* 
                               double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t stage_pops,
                               int32_t first_stage_only, const int32_t* order);
 int32_t avp_plan_slots(avp_map* map, int32_t mode);
+/*
+ * Time slicing of the group forms (modes 2 - 4). With n_slots >= n -- a workspace slot for every problem of the batch --
+ * and more problems than the form has groups, a search that is still running after `pops` pops is parked (its state goes
+ * to its own slot) whenever another problem is waiting for a group, and taken up again in turn by whichever group is
+ * free: the long searches of a batch advance side by side, and the launch ends within a slice of the moment the work
+ * runs out instead of within a whole long search of it. Which group runs which part of a search never changes a result
+ * (tests/test_gpu_plan_wave.py). pops = 0: never park (the behaviour with n_slots < n); pops < 0: the default, 64.
+ * No reference counterpart (the reference plans one problem at a time, path_plan/path_planner.py:58-110).
+ */
+int32_t avp_plan_set_slice_pops(avp_map* map, int32_t pops);
 int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the kernel form: slot counts are multiples of it (mode 1: 1) */
 
 /*

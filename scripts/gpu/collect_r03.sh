@@ -27,5 +27,7 @@ for f in sorted(glob.glob(f"{O}/soak_*.json")):
 json.dump(s, open(f"{P}/r03_lookahead_soak.json", "w"), indent=1)
 PY
 cp $O/lookahead.json $P/r03_lookahead.json
+cp $O/large_maps.json $P/r03_large_maps.json
+cat $O/slice_*_off.json $O/slice_*_on.json > $P/r03_time_slicing.jsonl
 tail -n 6 $O/pytest_gpu.log > $P/r03_pytest_gpu_tail.txt
 ls -la $P | grep r03

@@ -34,4 +34,8 @@ for v in default look_atomics look_sleep1 look_sleep127 look_wait0 look_wait50k 
   L=""; [ $v != default ] && L="--lib $V/libavp_hip_$v.so"
   [ $v = default -o -f $V/libavp_hip_$v.so ] && timeout -k 10 300 python scripts/look_soak.py $L --launches 300 > $O/soak_$v.json 2> $O/soak_$v.err
 done
+timeout -k 10 500 python scripts/large_map_bench.py > $O/large_maps.json 2> $O/large_maps.err
+for sl in off on; do for cfgs in "16384 3" "32768 2"; do set -- $cfgs
+  timeout -k 10 300 python scripts/variant_bench.py --no-profile --big $1 --big-mode $2 --steps 1 --slice $sl > $O/slice_$1_m$2_$sl.json 2>/dev/null
+done; done
 find $O -name "*kernel_stats.csv" | head; du -sh $O

@@ -154,3 +154,34 @@ def test_group_forms_shot_at_every_pop(form, vehicle, cfg):
     got = path_planner.BatchPlanner(dm, max_nodes=8192, mode=form).plan(st, go, max_trace=150)
     _same_results(got, ref)
     assert all(r.counters["n_rs"] >= r.n_pops for r in ref)
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_time_sliced_group_forms(form, vehicle, cfg):
+    """More problems than the form has groups, a workspace slot per problem: searches are parked after slice_pops pops
+    while others wait and resumed by whichever group is free (another CU, another XCD). Records, traces, counters and paths
+    equal the unsliced launch's and the workgroup form's, for a short and the default slice."""
+    import ctypes as C
+    from automatedvaletparking_amd import _native, path_planner
+    m = case_map_from_gold(1)
+    cap = 120
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
+    L = _native.lib()
+    n = int(L.avp_plan_slots(dm.h, C.c_int32(form))) + 150
+    rng = np.random.default_rng(31 + form)
+    b = m.boundary
+    poses = np.stack([rng.uniform(b[0] + 6, b[1] - 6, 6 * n), rng.uniform(b[2] + 6, b[3] - 6, 6 * n), rng.uniform(-np.pi, np.pi, 6 * n)], 1)
+    free = poses[dm.check_batch(poses) == 0]
+    assert len(free) >= 2 * n
+    st, go = free[0:2 * n:2], free[1:2 * n:2]
+    plain = path_planner.BatchPlanner(dm, max_nodes=4096, mode=form, time_slice=False)
+    ref = plain.plan(st, go, max_trace=cap)
+    assert not plain.last_time_sliced
+    assert sum(r.n_pops > 64 for r in ref) > 50 and sum(r.status == 0 for r in ref) > n // 2
+    for sp in (8, None):
+        bp = path_planner.BatchPlanner(dm, max_nodes=4096, mode=form, time_slice=True, slice_pops=sp)
+        got = bp.plan(st, go, max_trace=cap)
+        assert bp.last_time_sliced
+        _same_results(got, ref)
+        _same_results(bp.plan(st, go, max_trace=cap), ref)          # again on the same workspace (ring words re-zeroed)
+    _same_results(ref[:256], path_planner.BatchPlanner(dm, max_nodes=4096, mode=1, lookahead=False).plan(st[:256], go[:256], max_trace=cap))
