@@ -102,7 +102,8 @@ class BatchPlanner:
         time_slice: group forms (modes 2 - 4) with more problems than groups: give every problem its own workspace slot, so
         that the kernel parks a search that is still running after slice_pops pops (default: the library's, 64) while
         others wait and the long searches advance side by side (include/avp.h: avp_plan_set_slice_pops; same results).
-        None = when the slots fit SLICE_FREE_FRAC of the free device memory, True = always, False = never.
+        None = from SLICE_MIN_RATIO problems per group on, when the slots fit SLICE_FREE_FRAC of the free device memory;
+        True = whenever there are more problems than groups; False = never.
         longest_first: start a batch with more problems than slots by decreasing start-goal distance (the `order` argument of
         avp_plan_batch_ex; results keep the caller's order). Off by default: on the bench's random pairs the distance does not
         predict the length of the search (4 096 problems: 119 vs 116 ms in index order, scripts/order_bench.py)."""
@@ -128,14 +129,17 @@ class BatchPlanner:
     LOOK_BYTES_MAX = 24 << 30          # (512 problems x 16 384 nodes x 4 x 708 B = 23.8 GB of MI355X's 288)
     LOOK_FREE_FRAC = 0.25              # ... and at most this share of the device memory that is free right now
     SLICE_FREE_FRAC = 0.5              # time slicing: one workspace slot per problem, at most this share of the free memory
+    SLICE_MIN_RATIO = 6                # ... and by default only from this many problems per group on (measured on the Case1 sets:
+                                       # 4 per group: 0 to -4 %; 8 per group: +14 % wave form, +19 % pair form)
 
     def _slice_slots(self, n, wg, mode):
         """Slot count for a time-sliced launch of n problems in group form `mode` (a slot per problem), or 0."""
         if self.time_slice is False or self.n_slots or mode < 2:
             return 0
         L = _native.lib()
-        if n <= int(L.avp_plan_slots(self.dm.h, C.c_int32(mode))):
-            return 0                                        # every problem has a group of its own from the start
+        groups = int(L.avp_plan_slots(self.dm.h, C.c_int32(mode)))
+        if n <= groups or (self.time_slice is None and n < self.SLICE_MIN_RATIO * groups):
+            return 0                                        # every problem has a group of its own from the start / too few to pay
         want = wg * ((n + wg - 1) // wg)
         if self.time_slice is None and not (self._ws is not None and self._ws_slots >= want):
             nbytes = int(L.avp_plan_workspace_bytes(self.dm.h, C.c_int32(want), C.c_int32(self.max_nodes)))

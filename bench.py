@@ -127,9 +127,10 @@ def records(res_t, n):
     return res_t.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:n]
 
 
-def summarize(recs, n_slots, elapsed_per_step):
+def summarize(recs, n_slots, elapsed_per_step, time_sliced=False):
     """Throughput figures of one step over the given record arrays (one per group). n_slots: problem slots of the kernel
-    form that ran, or a list, one per group."""
+    form that ran, or a list, one per group. time_sliced: the launch moved searches between groups (a record's slot is
+    then the problem's own workspace slot, not the group that ran it): no slot utilisation."""
     if not isinstance(n_slots, (list, tuple)):
         n_slots = [n_slots] * len(recs)
     rec = np.concatenate(recs)
@@ -146,7 +147,7 @@ def summarize(recs, n_slots, elapsed_per_step):
             "expansions_per_s": pops / elapsed_per_step, "problems": int(len(rec)), "completed": int(done.sum()),
             "solved_frac": float((rec["status"] == 0).mean()), "iter_limit_frac": float((rec["status"] == 4).mean()),
             "capacity_frac": float((rec["status"] == 5).mean()),
-            "slot_utilisation": float(util_num / max(util_den, 1)), "ms_per_step": elapsed_per_step * 1e3}
+            "slot_utilisation": None if time_sliced else float(util_num / max(util_den, 1)), "ms_per_step": elapsed_per_step * 1e3}
 
 
 def same_results(ra, pa, rb, pb):
@@ -356,7 +357,7 @@ def main():
             groups.append(g)
 
     if rank == 0:
-        head = summarize(recs, slots_all, elapsed / a.steps)
+        head = summarize(recs, slots_all, elapsed / a.steps, time_sliced=any(g.bp.last_time_sliced for g in groups))
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_k[a.warmup:a.warmup + a.steps]])) if a.steps else 0.0
         rec = np.concatenate(recs)
         P = groups[0].dm.P
@@ -444,7 +445,7 @@ def main():
                     xo = plan_groups(xg)
                 torch.cuda.synchronize()
                 xe = (time.perf_counter() - t0) / 2
-                xs = summarize([records(o[0], g.n) for o, g in zip(xo, xg)], [g.slots for g in xg], xe)
+                xs = summarize([records(o[0], g.n) for o, g in zip(xo, xg)], [g.slots for g in xg], xe, time_sliced=any(g.bp.last_time_sliced for g in xg))
                 xs["workload"] = lab
                 xs["kernel_form"] = FORM_NAMES.get(xg[0].mode)
                 out[name] = xs
@@ -458,7 +459,7 @@ def main():
                     g4 = Group(mm, veh, xcfg, st4, go4, local, xcap, mode=mode)
                     sec, o4 = time_group(g4, reps=2)
                     r4, p4 = records(o4[0], g4.n), o4[1].cpu().numpy()
-                    forms[mode] = summarize([r4], [g4.slots], sec)
+                    forms[mode] = summarize([r4], [g4.slots], sec, time_sliced=bool(g4.bp.last_time_sliced))
                     forms[mode]["kernel_form"] = FORM_NAMES[mode]
                     forms[mode]["time_sliced"] = bool(g4.bp.last_time_sliced)
                     if ref_rp is None:
@@ -489,14 +490,14 @@ def main():
                                       (path_planner.STAGED, "staged", None), (2, "wave_per_problem_unsliced", False), (3, "pair_per_problem_unsliced", False)):
                     g16 = Group(mm, veh, xcfg, st16, go16, local, xcap, mode=mode, time_slice=ts)
                     sec, o16 = time_group(g16, reps=1)
-                    sat[key] = summarize([records(o16[0], g16.n)], [g16.slots], sec)
+                    sat[key] = summarize([records(o16[0], g16.n)], [g16.slots], sec, time_sliced=bool(g16.bp.last_time_sliced))
                     sat[key]["time_sliced"] = bool(g16.bp.last_time_sliced)
                     del g16
                 st32, go32 = np.concatenate([st16] * 2), np.concatenate([go16, np.roll(go16, 5, axis=0)])
                 for key, ts in (("wave_per_problem", None), ("wave_per_problem_unsliced", False)):
                     g32 = Group(mm, veh, xcfg, st32, go32, local, xcap, mode=2, time_slice=ts)
                     sec, o32 = time_group(g32, reps=1)
-                    sat["n32768_" + key] = summarize([records(o32[0], g32.n)], [g32.slots], sec)
+                    sat["n32768_" + key] = summarize([records(o32[0], g32.n)], [g32.slots], sec, time_sliced=bool(g32.bp.last_time_sliced))
                     sat["n32768_" + key]["time_sliced"] = bool(g32.bp.last_time_sliced)
                     del g32
                 out["saturating_batch"] = sat
@@ -510,7 +511,7 @@ def main():
                         # (the node arena grows with the cap: a search makes up to 10 nodes per pop)
                         gs = Group(ms_, veh, scfg, st_, go_, local, cap_s, max_nodes=max(MAX_NODES, 12 * cap_s))
                         sec, os_ = time_group(gs, reps=1)
-                        x = summarize([records(os_[0], gs.n)], [gs.slots], sec)
+                        x = summarize([records(os_[0], gs.n)], [gs.slots], sec, time_sliced=bool(gs.bp.last_time_sliced))
                         sweep[wname][str(cap_s)] = {k: x[k] for k in ("plans_per_s", "expansions_per_s", "completed", "problems", "iter_limit_frac", "capacity_frac", "ms_per_step")}
                         del gs
                 sweep["note"] = ("completed plans/s is a function of the cap only through the searches the cap stops: on Case1 a fifth of the random pairs never "
