@@ -28,6 +28,7 @@ json.dump(s, open(f"{P}/r03_lookahead_soak.json", "w"), indent=1)
 PY
 cp $O/lookahead.json $P/r03_lookahead.json
 cp $O/large_maps.json $P/r03_large_maps.json
+cp $O/slice_soak.json $P/r03_time_slicing_soak.json
 cat $O/slice_*_off.json $O/slice_*_on.json > $P/r03_time_slicing.jsonl
 tail -n 6 $O/pytest_gpu.log > $P/r03_pytest_gpu_tail.txt
 ls -la $P | grep r03

@@ -38,4 +38,5 @@ timeout -k 10 500 python scripts/large_map_bench.py > $O/large_maps.json 2> $O/l
 for sl in off on; do for cfgs in "16384 3" "32768 2"; do set -- $cfgs
   timeout -k 10 300 python scripts/variant_bench.py --no-profile --big $1 --big-mode $2 --steps 1 --slice $sl > $O/slice_$1_m$2_$sl.json 2>/dev/null
 done; done
+timeout -k 10 600 python scripts/slice_soak.py --launches 100 --slice-pops 4 > $O/slice_soak.json 2> $O/slice_soak.err
 find $O -name "*kernel_stats.csv" | head; du -sh $O

@@ -185,3 +185,37 @@ def test_time_sliced_group_forms(form, vehicle, cfg):
         _same_results(got, ref)
         _same_results(bp.plan(st, go, max_trace=cap), ref)          # again on the same workspace (ring words re-zeroed)
     _same_results(ref[:256], path_planner.BatchPlanner(dm, max_nodes=4096, mode=1, lookahead=False).plan(st[:256], go[:256], max_trace=cap))
+
+
+def test_time_slicing_soak(vehicle, cfg):
+    """The resume ring under load: 1 536 problems in the quad form with slices of 4 pops -- every long search changes groups
+    dozens of times, between CUs and XCDs --, 25 consecutive launches, every launch's records and way-points equal to the
+    unsliced launch's (scripts/slice_soak.py runs the longer version for profiles/)."""
+    import ctypes as C
+    import hashlib
+    import torch
+    from automatedvaletparking_amd import _native, path_planner, workloads
+    m = case_map_from_gold(1)
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=200)
+    L = _native.lib()
+    n = int(L.avp_plan_slots(dm.h, C.c_int32(4))) + 512
+    st, go = workloads.sample_pairs(m, dm.check_batch, n, np.random.default_rng(77))
+    stt, got = dm.dev_tensor(st), dm.dev_tensor(go)
+
+    def digest(bp):
+        r, p, _ = bp.plan_dev(stt, got)
+        torch.cuda.synchronize()
+        rec = r.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:n]
+        h = hashlib.sha256()
+        for k in ("status", "n_pops", "n_final", "n_checks", "n_rs", "n_closed", "n_open", "h_cells", "h_misses", "global_index", "n_nodes", "rs_L"):
+            h.update(np.ascontiguousarray(rec[k]).tobytes())
+        pa = p.cpu().numpy()
+        for i in range(n):
+            h.update(np.ascontiguousarray(pa[i, :int(rec["n_final"][i])]).tobytes())
+        return h.hexdigest(), rec
+    want, rec = digest(path_planner.BatchPlanner(dm, max_nodes=8192, max_path=256, mode=4, time_slice=False))
+    assert int((rec["n_pops"] > 100).sum()) > 100
+    on = path_planner.BatchPlanner(dm, max_nodes=8192, max_path=256, mode=4, time_slice=True, slice_pops=4)
+    for k in range(25):
+        got_d, _ = digest(on)
+        assert on.last_time_sliced and got_d == want, k

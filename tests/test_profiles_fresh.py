@@ -73,6 +73,27 @@ def test_lookahead_evidence_is_consistent():
     assert soak["look_fault5"]["records_used_min_median_max"][1] < soak["default"]["records_used_min_median_max"][1]
 
 
+def test_time_slicing_evidence_is_consistent():
+    """The time-sliced group forms: same digests as the unsliced launches, in the soak and in the timing runs; the bench's
+    saturating batch carries the sliced and the unsliced entries."""
+    soak = _load("r03_time_slicing_soak.json")
+    assert set(soak["forms"]) == {"four waves per problem", "a pair of waves per problem", "one wave per problem"}
+    for name, f in soak["forms"].items():
+        assert f["time_sliced"] and f["launches_with_a_different_digest"] == 0 and soak["launches_per_form"] >= 100, name
+        assert f["searches_longer_than_a_slice"] > 100, name
+    runs = [json.loads(l) for l in open(os.path.join(PROF, "r03_time_slicing.jsonl")) if l.strip()]
+    by = {}
+    for r in runs:
+        by.setdefault((r["big_n"], r["big_mode"]), {})[bool(r["time_sliced"])] = r
+    assert len(by) >= 2
+    for key, ab in by.items():
+        assert set(ab) == {False, True} and ab[False]["big_digest"] == ab[True]["big_digest"], key
+        assert ab[True]["big_ms"] < ab[False]["big_ms"], key
+    sat = _load("r03_bench_n1.json")["saturating_batch"]
+    assert sat["pair_per_problem"]["time_sliced"] and not sat["pair_per_problem_unsliced"]["time_sliced"]
+    assert sat["n32768_wave_per_problem"]["time_sliced"] and sat["n32768_wave_per_problem"]["ms_per_step"] < sat["n32768_wave_per_problem_unsliced"]["ms_per_step"]
+
+
 def test_compiler_remarks_of_the_planner_kernels():
     """the group forms fit 4 waves per SIMD without a spilled VGPR; plan_kernel (LDS-staged instantiations:
     the ones every bench workload runs) spills none either."""
