@@ -111,6 +111,8 @@ struct PwCommon {
 // static LDS (s_barrier would stop the whole workgroup: the groups are independent searches).
 __shared__ uint32_t PW_BAR_CNT[PW_WAVES];
 __shared__ uint32_t PW_BAR_GEN[PW_WAVES];
+__shared__ uint32_t PW_SUB_CNT[PW_WAVES];     // the same for the waves 1 .. NW-1 of a group alone (pw_sub_sync_lds)
+__shared__ uint32_t PW_SUB_GEN[PW_WAVES];
 #ifndef PW_SLICE_POPS
 #define PW_SLICE_POPS 64       // default time slice of a search in pops (avp_plan_set_slice_pops; 32 ... 200, and a shorter first slice: no measurable difference)
 #endif
@@ -163,6 +165,23 @@ struct PwGroup {
         wave_sync();
     }
 };
+
+// LDS-only barrier among the waves 1 .. NW-1 of a group (the shot's checking waves while wave 0 resolves the children).
+template <int NW>
+AVP_D void pw_sub_sync_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (NW > 2) {
+        if ((threadIdx.x & 63) == 0) {
+            const int wave = threadIdx.x >> 6, grp = wave & ~(NW - 1);
+            const uint32_t g = PW_SUB_GEN[wave] + 1u;
+            PW_SUB_GEN[wave] = g;
+            atomicAdd(&PW_SUB_CNT[grp], 1u);
+            while (*(volatile uint32_t*)&PW_SUB_CNT[grp] < g * (uint32_t)(NW - 1)) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    wave_sync();
+}
 
 // Reeds-Shepp evaluation scratch of one wave: running best per query (indexed by position in rsq), round scratch
 struct PwRsBest {
@@ -229,6 +248,7 @@ struct PwSharedT {
     static constexpr bool HEAP_POS = true;
     static constexpr int HEAP_LDS = 0;         // (no LDS heap top in these forms: the whole open list stays in the workspace)
     uint32_t phase[PW_PH_COUNT];               // instrumented instantiation only: shader cycles per phase (lane 0)
+    int64_t snap[5];                           // counters saved before a resolution that runs beside the shot (pw_ph_shot_resolve)
     int32_t resume, fresh_done, park_now, sl_pad;   // time slicing: this problem continues a parked search / no unstarted problem is left / park decision
     __device__ __forceinline__ PlWaveChkT<PW_WQCAP>& wave_chk() { return wchk[PwGroup<NW>::wv()]; }
 };
@@ -650,6 +670,90 @@ __device__ __noinline__ void pw_ph_resolve_fast(PW_PHASE_ARGS)
     G::sync();
 }
 // ... else lane 0 in child order, the group extending the heuristic sweep at every miss; then the node is closed (:235-239)
+// ---- NW > 1, node inside flag_radius: the shot on the waves 1 .. NW-1 WHILE wave 0 resolves the children ------------------
+// The shot's outcome is not an input of expand_node, so the resolution may run beside it (plan_kernel does the same): when
+// the shot then turns out collision free the search ends at this pop, BEFORE expand_node in the reference -- the counters
+// are put back (the arena / heap / hash side effects touch no node on the final path's parent chain). What this phase
+// leaves behind equals pw_ph_shot followed by pw_ph_resolve_fast.
+#ifndef PW_SPECULATE
+#define PW_SPECULATE 1
+#endif
+template <bool STAGE, bool PROFILE, int NW>
+__device__ __noinline__ void pw_ph_shot_resolve(PW_PHASE_ARGS)
+{
+    PW_PHASE_REFS;
+    static_assert(NW > 1, "needs a wave beside the resolving one");
+    const avp_params& p = c.p;
+    const PlanWs& w = s.w;
+    if (s.rs_status) { if (gtid == 0) s.status = 3; G::sync_lds(); return; }       // no Reeds-Shepp path / the reference's assertion
+    if (wv == 0) {
+        if (lane == 0) {
+            s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = s.can_fast;
+            s.snap[0] = s.nnodes; s.snap[1] = s.n_checks; s.snap[2] = s.n_rs; s.snap[3] = s.nclosed; s.snap[4] = s.nheap;
+        }
+        wave_sync();
+        if (!s.can_fast) { if (lane < c.nchild) s.child[lane].pre_d = pl_id_in_range(c.m, s.child[lane].id) ? w.dist[s.child[lane].id] : PL_UNSEEN; }
+        else {
+            const PlNode cn0 = s.cn;
+            pl_resolve_fast_wave<false>(c.m, p, w, s, c.dims, cn0, c.nchild, s.n_pops < c.max_pops && !(c.stage_pops > 0 && s.n_pops >= c.stage_pops));
+        }
+    } else {
+        // the sampler's index bookkeeping (one lane) beside the chain of segment origins (a wave; in the pair form behind it)
+        if (wv == 1 && lane == 0) s.book_status = pl_rs_sample_book(s, p);
+        if (wv == (NW > 2 ? 2 : 1)) { wave_sync(); pl_rs_sample_origins(s, p); }
+        pw_sub_sync_lds<NW>();
+        if (!s.book_status) {                           // (else: more samples than this form holds -- handed back below)
+            constexpr int NS = NW - 1;                      // checking waves
+            const int sw = wv - 1;
+            const PlNode cn = s.cn;
+            const int total = s.smp_hi + 1;
+            double cm, sm;
+            avp_sincos(-cn.th, sm, cm);
+            int base0 = 0;
+            for (int r = 0; base0 < total; r++) {
+                const int per = NS == 1 ? PL_WPOSE : min(PL_WPOSE, max(1, PL_WPOSE / NS) << r);
+                const int base = base0 + sw * per;
+                if (base < total) {
+                    const int cnt = min(per, total - base);
+                    double tx = 0.0, ty = 0.0, tth = 0.0;
+                    const int mine = base + lane;
+                    if (lane < cnt) pl_rs_sample_world(w, s, p, cn, cm, sm, mine, tx, ty, tth);
+                    uint32_t* hits = &s.wave_chk().hit[0];
+                    pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
+                        x = tx; y = ty; th = avp_pi_2_pi(tth); /* :339 */
+                        avp_sincos(th, sn, cs);
+                    }, hits);
+                    if (lane < cnt && hits[lane]) atomicMin(&s.rs_first_coll, mine);
+                }
+                base0 += NS * per;
+                // (as in pw_ph_shot: every sample before base0 is checked; ONE lane decides whether the known hit ends the shot)
+                if constexpr (NS > 1) {
+                    pw_sub_sync_lds<NW>();
+                    if (sw == 0 && lane == 0) { const int fc = s.rs_first_coll, np = s.rs_npts; s.shot_stop = (fc != 0x7fffffff && fc < np) ? 1 : 0; }
+                    pw_sub_sync_lds<NW>();
+                    if (s.shot_stop) break;
+                } else {
+                    wave_sync();
+                    const int fc = s.rs_first_coll, np = s.rs_npts;
+                    if (fc != 0x7fffffff && fc < np) break;
+                }
+            }
+        }
+    }
+    G::sync();
+    if (s.book_status) { if (gtid == 0) s.status = AVP_PLAN_RETRY; G::sync_lds(); return; }
+    if (gtid == 0) {
+        // a hit at or past the trimmed length belongs to a popped entry (rs_curve.py:588-592)
+        if (s.rs_first_coll != 0x7fffffff && s.rs_first_coll >= s.rs_npts) s.rs_first_coll = 0x7fffffff;
+        if (s.rs_first_coll == 0x7fffffff) {
+            // success: the reference returns before expand_node -- undo the speculative bookkeeping
+            s.nnodes = (int32_t)s.snap[0]; s.n_checks = s.snap[1]; s.n_rs = s.snap[2]; s.nclosed = (int32_t)s.snap[3]; s.nheap = (int32_t)s.snap[4];
+            s.n_checks += s.rs_npts; s.done = 1;
+        } else { s.collision = 1; s.n_checks += s.rs_first_coll + 1; }
+    }
+    G::sync_lds();
+}
+
 template <int NW>
 __device__ __noinline__ void pw_ph_resolve_slow(PW_PHASE_ARGS)
 {
@@ -861,7 +965,7 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
             c.slice_pops = (PROFILE || retry_only) ? 0 : slice_pops; c.n = n; c.counter = counter; c.sl = sl; c.workspace = workspace;
         }
         if (gtid == 0) s.fresh_done = 0;
-        if (tid < PW_WAVES) { PW_BAR_CNT[tid] = 0; PW_BAR_GEN[tid] = 0; }
+        if (tid < PW_WAVES) { PW_BAR_CNT[tid] = 0; PW_BAR_GEN[tid] = 0; PW_SUB_CNT[tid] = 0; PW_SUB_GEN[tid] = 0; }
     }
 #pragma unroll
     for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
@@ -935,10 +1039,14 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
             pw_ph_rs<NW>(sp, cp);
             if constexpr (PROFILE) { if (gtid == 0) s.phase[PW_PH_NROUND] += s.nq; }
             PW_T(PW_PH_RS);
-            if (s.in_radius) pw_ph_shot<STAGE, PROFILE, NW>(sp, cp);
+            bool resolved = false;
+            if (s.in_radius) {
+                if constexpr (NW > 1 && PW_SPECULATE) { pw_ph_shot_resolve<STAGE, PROFILE, NW>(sp, cp); resolved = true; }
+                else pw_ph_shot<STAGE, PROFILE, NW>(sp, cp);
+            }
             PW_T(PW_PH_SHOT);
             if (s.status != 0 || s.done) break;
-            pw_ph_resolve_fast<NW>(sp, cp);
+            if (!resolved) pw_ph_resolve_fast<NW>(sp, cp);
             PW_T(PW_PH_RESOLVE);
             pw_ph_resolve_slow<NW>(sp, cp);
             PW_T(PW_PH_SLOW);

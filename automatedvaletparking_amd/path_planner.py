@@ -23,7 +23,7 @@ from .costmap import Map, Vehicle
 from .rs_curve import PATH, path_from_arrays
 
 STATUS_NAMES = {0: "OK", 1: "NO_PATH", 2: "H_UNREACHABLE", 3: "RS_ERROR", 4: "ITER_LIMIT", 5: "CAPACITY", 6: "LATTICE",
-                100: "DEFERRED"}       # (DEFERRED: only from the first stage of a staged call run on its own, BatchPlanner.plan_dev(first_stage_only=True))
+                100: "DEFERRED", -1: "UNFINISHED"}       # (DEFERRED: only from the first stage of a staged call run on its own, BatchPlanner.plan_dev(first_stage_only=True))
 STAGED = 16                           # BatchPlanner mode: avp_plan_batch_staged
 
 
@@ -258,6 +258,8 @@ class BatchPlanner:
             return []
         res, paths, trace = self.plan_dev(self.dm.dev_tensor(starts), self.dm.dev_tensor(goals), True, max_trace)
         rec = res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)[:n]
+        if (rec["status"] < 0).any():
+            raise RuntimeError(f"{int((rec['status'] < 0).sum())} searches of a time-sliced launch were never finished (status UNFINISHED): internal error")
         paths = paths.cpu().numpy()
         trace = trace.cpu().numpy() if trace is not None else None
         out = []

@@ -193,7 +193,7 @@ int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, 
  *   mode 3: a pair of waves per problem, half as many problems per workgroup as mode 2 -- a pop takes ~0.6 x the time of
  *           mode 2: right for a few problems per CU (their long searches all run at once: their latency is the launch time);
  *   mode 4: four waves per problem, a quarter as many problems per workgroup as mode 2 (a pop takes ~0.45 x the time);
- *   mode 0: avp_plan_batch's choice: mode 2 when n >= 32 x the number of CUs (4 problems per wave slot), else mode 1.
+ *   mode 0: avp_plan_batch's choice by problems per CU: mode 1 below 12, mode 4 below 24, mode 3 below 80, mode 2 from there.
  * n_slots counts problem slots in either form (avp_plan_slots(map, mode) = avp_plan_group(mode) x CUs); the workspace is
  * avp_plan_workspace_bytes(map, n_slots, max_nodes) as before. avp_plan_pick_mode returns the form mode 0 would use.
  */
@@ -226,8 +226,10 @@ int32_t avp_plan_slots(avp_map* map, int32_t mode);
  * free: the long searches of a batch advance side by side, and the launch ends within a slice of the moment the work
  * runs out instead of within a whole long search of it. Which group runs which part of a search never changes a result
  * (tests/test_gpu_plan_wave.py). pops = 0: never park (the behaviour with n_slots < n); pops < 0: the default, 64.
+ * A time-sliced launch presets every record's status to AVP_PLAN_UNFINISHED (-1); none is left after a correct launch.
  * No reference counterpart (the reference plans one problem at a time, path_plan/path_planner.py:58-110).
  */
+#define AVP_PLAN_UNFINISHED (-1)
 int32_t avp_plan_set_slice_pops(avp_map* map, int32_t pops);
 int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the kernel form: slot counts are multiples of it (mode 1: 1) */
 
