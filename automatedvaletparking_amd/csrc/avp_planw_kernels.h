@@ -1,6 +1,7 @@
 // avp_planw_kernels.h -- batched hybrid-A* planner, the GROUP forms: NW waves = one (start, goal) problem (NW = 1 the
 // wave form, 2 the pair form, 4 the quad form), PW_WAVES / NW independent problems per workgroup = per CU, persistent
-// groups of waves pull problems from a global counter.
+// groups of waves pull problems from a global counter -- and, when every problem has a workspace slot of its own, hand
+// long searches to each other through a resume ring (time slicing, see plan_wave_kernel).
 //
 // plan_kernel (avp_plan_kernels.h) spends a whole 512-thread workgroup on one problem to shorten a pop's critical
 // path: one problem per CU. A pop is a chain of dependent scalar fp64 code, so what a batch larger than the chip needs is
@@ -20,7 +21,9 @@
 // What differs from plan_kernel is only WHO does the work:
 //   * the collision passes (pl_check_pass), the wave-parallel child resolution (pl_resolve_fast_wave) and the heuristic
 //     sweep (with the group as the cooperating set) are the shared device functions;
-//   * the shot is checked BEFORE the children are resolved, as in the reference (no speculation, no roll-back);
+//   * wave form: the shot is checked BEFORE the children are resolved, as in the reference; pair / quad form: wave 0
+//     resolves the children WHILE the other waves sample and check the shot (pw_ph_shot_resolve; a collision-free shot ends
+//     the search before expand_node in the reference: the counters the resolution moved are put back, as in plan_kernel);
 //   * Reeds-Shepp: only the queries the pop can use are solved (the shot inside flag_radius; a child unless expand_node
 //     drops it before calc_node_heuristic), solver group by solver group with the words of one set_path type group in
 //     adjacent lanes: the duplicate test (rs_curve.py:137-156) is a few shuffles inside the group and the running
@@ -698,7 +701,8 @@ __device__ __noinline__ void pw_ph_shot_resolve(PW_PHASE_ARGS)
             pl_resolve_fast_wave<false>(c.m, p, w, s, c.dims, cn0, c.nchild, s.n_pops < c.max_pops && !(c.stage_pops > 0 && s.n_pops >= c.stage_pops));
         }
     } else {
-        // the sampler's index bookkeeping (one lane) beside the chain of segment origins (a wave; in the pair form behind it)
+        // the sampler's index bookkeeping (one lane; a whole-wave version of it measured the same) beside the chain of
+        // segment origins (a wave; in the pair form behind it)
         if (wv == 1 && lane == 0) s.book_status = pl_rs_sample_book(s, p);
         if (wv == (NW > 2 ? 2 : 1)) { wave_sync(); pl_rs_sample_origins(s, p); }
         pw_sub_sync_lds<NW>();

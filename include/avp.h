@@ -227,6 +227,8 @@ int32_t avp_plan_slots(avp_map* map, int32_t mode);
  * runs out instead of within a whole long search of it. Which group runs which part of a search never changes a result
  * (tests/test_gpu_plan_wave.py). pops = 0: never park (the behaviour with n_slots < n); pops < 0: the default, 64.
  * A time-sliced launch presets every record's status to AVP_PLAN_UNFINISHED (-1); none is left after a correct launch.
+ * The ticket counters of the planner are per map handle: one planner launch per handle at a time (launches on one stream
+ * are ordered anyway; callers with several streams order them, as automatedvaletparking_amd._native.DeviceMap does).
  * No reference counterpart (the reference plans one problem at a time, path_plan/path_planner.py:58-110).
  */
 #define AVP_PLAN_UNFINISHED (-1)
