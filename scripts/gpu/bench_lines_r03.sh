@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, GPU call P: the bench line again (host-side changes only: default slicing threshold, slot utilisation of sliced launches)
+# the two bench lines of the round-3 evidence alone (after host-side changes that leave the kernel sources untouched)
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03; mkdir -p $O
 timeout -k 10 900 python bench.py --steps 5 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err; head -c 300 $O/bench_n1.json; tail -3 $O/bench_n1.err

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 3, GPU call S: which form at which batch size, with the resolution beside the shot and time slicing
+# which kernel form at which batch size (the table in plan_pick_mode, csrc/avp_capi_plan.inc): 8 ... 128 problems per CU, auto time slicing
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03s; mkdir -p $O
+O=gpurun_out/form_crossover; mkdir -p $O
 vb() { timeout 300 python scripts/variant_bench.py --no-profile "$@" 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
