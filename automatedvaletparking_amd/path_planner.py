@@ -206,6 +206,7 @@ class BatchPlanner:
             paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
             trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
             self.last_lookahead = False
+            self.last_time_sliced = False
             _native.chk(L.avp_plan_batch_staged(self.dm.h, C.c_void_p(starts_t.data_ptr()), C.c_void_p(goals_t.data_ptr()), C.c_int64(n), C.c_int32(slots),
                                                 C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
                                                 C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
@@ -220,7 +221,7 @@ class BatchPlanner:
         if mode >= 2 and slots < wg:
             mode = 1                                        # fewer than one workgroup of slots: the workgroup form
         sliced = 0 if profile else self._slice_slots(n, wg, mode)
-        self.last_time_sliced = bool(sliced)
+        self.last_time_sliced = bool(sliced) and self.slice_pops != 0
         if sliced:
             slots = sliced
             _native.chk(L.avp_plan_set_slice_pops(self.dm.h, C.c_int32(-1 if self.slice_pops is None else int(self.slice_pops))), "avp_plan_set_slice_pops")
