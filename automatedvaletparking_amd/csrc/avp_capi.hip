@@ -279,6 +279,15 @@ AVP_EXPORT int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, doub
     return AVP_OK;
 }
 
+AVP_EXPORT int32_t avp_libm_batch(avp_map* map, int32_t kind, const double* a, const double* b, int64_t n, double* out)
+{
+    if (!map || n <= 0 || !a || !out || kind < 0 || kind > 4 || (kind == 0 && !b)) return set_err(AVP_ERR_ARG, "avp_libm_batch: bad argument");
+    AVP_ON_DEVICE(map->device);
+    hipLaunchKernelGGL(libm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, map->stream, kind, a, b, n, out);
+    HIPCHK(hipGetLastError());
+    return AVP_OK;
+}
+
 AVP_EXPORT int32_t avp_ieee_batch(avp_map* map, const double* a, const double* b, int64_t n, double* q, double* r, double* h)
 {
     if (!map || n <= 0 || !a || !b || !q || !r || !h) return set_err(AVP_ERR_ARG, "avp_ieee_batch: bad argument");

@@ -254,10 +254,9 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
                     const int bpos = __ffsll((unsigned long long)bits) - 1;
                     bits &= bits - 1;
                     const double py = m.Y[(w << 6) + bpos];
-                    // the reference squares with libm pow(v, 2.0); v*v is its correctly rounded value
                     const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
-                    if (sqrt(d0x * d0x + d0y * d0y) <= Rd) hit = true;
-                    else if (sqrt(d1x * d1x + d1y * d1y) <= Rd) hit = true;
+                    if (avp_circle_hit(d0x, d0y, Rd)) hit = true;
+                    else if (avp_circle_hit(d1x, d1y, Rd)) hit = true;
                 }
             }
         }
@@ -552,6 +551,23 @@ __global__ void trig_kernel(const double* __restrict__ x, int64_t n, double* __r
         s[i] = same ? sv : NAN; c[i] = same ? cv : NAN;
     }
 }
+// test hook: the restated glibc libm on the device. kind 0 atan2(a, b), 1 asin(a), 2 acos(a), 3 tan(a), 4 pow(a, 2)
+__global__ void libm_kernel(int32_t kind, const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i];
+    double r;
+    switch (kind) {
+    case 0: r = avp_atan2(x, b[i]); break;
+    case 1: r = avp_asin(x); break;
+    case 2: r = avp_acos(x); break;
+    case 3: r = avp_tan(x); break;
+    default: r = avp_pow2(x); break;
+    }
+    out[i] = r;
+}
+
 __global__ void ieee_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ q,
                             double* __restrict__ r, double* __restrict__ h)
 {

@@ -7,24 +7,33 @@
 #include "../../include/avp_libm.h"
 
 // static LDS taken by the trig tables in every kernel that evaluates trig
-#define AVP_LDS_TABLE_BYTES (sizeof(AVP_SINCOS_TAB) + sizeof(AVP_ATAN_TAB) + 1024)   /* + the Reeds-Shepp word tables (avp_rs_kernels.h) */
+#define AVP_LDS_TABLE_BYTES (sizeof(AVP_SINCOS_TAB) + 1024)   /* + the Reeds-Shepp word tables (avp_rs_kernels.h) */
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Copy the sin/cos and atan tables into LDS; all threads of the workgroup, once, before any trig call.
+// Copy the sin/cos table into LDS; all threads of the workgroup, once, before any trig call. (WITH_ATAN is a leftover of
+// the rounds that staged an atan table too: glibc's atan2 / asin / acos / tan / pow tables -- 46 KB, include/avp_glibc_tab.h --
+// stay in global memory and are read through L1 / L2.)
 template <bool WITH_ATAN>
 __device__ __forceinline__ void avp_lds_tables_fill()
 {
     const int n1 = (int)(sizeof(AVP_SINCOS_TAB) / sizeof(double));
     for (int i = threadIdx.x; i < n1; i += blockDim.x) (&AVP_SINCOS_LDS[0][0])[i] = (&AVP_SINCOS_TAB[0][0])[i];
-    if (WITH_ATAN) {
-        const int n2 = (int)(sizeof(AVP_ATAN_TAB) / sizeof(double));
-        for (int i = threadIdx.x; i < n2; i += blockDim.x) (&AVP_ATAN_LDS[0][0])[i] = (&AVP_ATAN_TAB[0][0])[i];
-    }
     __syncthreads();
 }
 #else
 template <bool WITH_ATAN> __device__ inline void avp_lds_tables_fill() {}       // host pass of hipcc: declaration only
 #endif
+
+// two_circle_checker's point test (collision_check.py:131-134): np.sqrt(pow(dx, 2) + pow(dy, 2)) <= Rd, where pow is libm's,
+// which is NOT dx*dx (0.08 % of arguments differ in the last bit). pow(v, 2) and v*v differ by <= 1 ulp, the sum by
+// <= 2 ulp, its root by <= 2 ulp: outside a band of 8 ulp around Rd the plain squares decide, inside it the exact
+// avp_pow2 (about one test in 1e14 on real maps) -- the same booleans as the reference at the cost of one comparison.
+AVP_HD bool avp_circle_hit(double dx, double dy, double Rd)
+{
+    const double s = sqrt(dx * dx + dy * dy);
+    if (fabs(s - Rd) > Rd * 0x1p-49) return s <= Rd;
+    return sqrt(avp_pow2(dx) + avp_pow2(dy)) <= Rd;
+}
 
 // Costmap resident in HBM. Column-major occupancy in two forms:
 //  - obstacle points in np.where(cost_map == 255) order (sorted by ix, then iy): ox/oy + colStart

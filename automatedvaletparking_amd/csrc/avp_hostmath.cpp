@@ -1,5 +1,6 @@
 // Host build of avp_math.h for CPU-side unit tests (bit-compare against this host's libm).
 #include "avp_math.h"
+#include "../../include/avp_libm.h"
 extern "C" {
 __attribute__((visibility("default"))) void avp_host_linspace0(double stop, int num, double* out)
 { for (int q = 0; q < num; q++) out[q] = avp_linspace0(stop, num, q); }
@@ -20,4 +21,17 @@ __attribute__((visibility("default"))) void avp_host_sincos_fused(const double* 
 { for (long i = 0; i < n; i++) avp_sincos(x[i], s[i], c[i]); }
 __attribute__((visibility("default"))) void avp_host_misc(const double* a, const double* b, long n, double* hyp, double* mod, double* p2p, double* M)
 { for (long i = 0; i < n; i++) { hyp[i] = avp_hypot(a[i], b[i]); mod[i] = avp_pymod(a[i], b[i]); p2p[i] = avp_pi_2_pi(a[i]); M[i] = avp_M(a[i]); } }
+// the restated glibc libm as the host compiles it (kind as in avp_libm_batch, include/avp.h)
+__attribute__((visibility("default"))) void avp_host_libm(int kind, const double* a, const double* b, long n, double* out)
+{
+    for (long i = 0; i < n; i++) {
+        switch (kind) {
+        case 0: out[i] = avp_atan2(a[i], b[i]); break;
+        case 1: out[i] = avp_asin(a[i]); break;
+        case 2: out[i] = avp_acos(a[i]); break;
+        case 3: out[i] = avp_tan(a[i]); break;
+        default: out[i] = avp_pow2(a[i]); break;
+        }
+    }
+}
 }

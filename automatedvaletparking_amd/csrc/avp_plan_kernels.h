@@ -319,8 +319,8 @@ __device__ __forceinline__ bool pl_check_pose(const PlChkEnv& e, TX X, TX Y, TB 
                     bits &= bits - 1;
                     const double py = Y[(w << 6) + bpos];
                     const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
-                    if (sqrt(d0x * d0x + d0y * d0y) <= Rd) return true;
-                    if (sqrt(d1x * d1x + d1y * d1y) <= Rd) return true;
+                    if (avp_circle_hit(d0x, d0y, Rd)) return true;
+                    if (avp_circle_hit(d1x, d1y, Rd)) return true;
                 }
             }
         }
@@ -784,10 +784,17 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, S& s, int64_t id)
             if (d != PL_UNSEEN && pl_bucket(d) <= E) break;
         }
         const uint32_t c0 = s.qcount[0] - b0, c1 = s.qcount[1] - b1, c2 = s.qcount[2] - b2, c3 = s.qcount[3] - b3;
-        if (c0 + c1 + c2 + c3 == 0 || s.qover) break;
+        if (c0 + c1 + c2 + c3 == 0) break;
         const int q = E & (PL_NQ - 1);
         const uint32_t full = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
         if (full == 0) { E += 1; continue; }              // an empty bucket costs nothing
+        // A queue that overflowed (its pushes beyond PL_QCAP were dropped, s.qover set by the pusher) ends the sweep HERE,
+        // when its bucket comes up: `full` is final at the barrier before, so every wave of the group takes this exit in
+        // the same iteration. (Until round 4 the loop tested s.qover itself at the top: a fast wave could set it during
+        // the pushes of the very iteration a slow wave was still entering, the slow wave left, the fast one went on to the
+        // barrier below, and the group's software barriers were skewed by one for the rest of the search.) Buckets before
+        // it are complete, so a query they settle is still answered; one they do not settle ends with status 5.
+        if (full > (uint32_t)PL_QCAP) break;
         const uint32_t cnt = min(full, (uint32_t)PL_QCAP);
         // PL_SWEEP_U (entry, neighbour) pairs per lane and trip, stage by stage: the U queue loads, then the U distance/flag
         // loads, the U pre-check loads and the U atomics are each in flight together -- a trip costs one chain of memory
@@ -2068,7 +2075,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const long long t_pop0 = t_d;
             const bool one_pass = nchild + 1 <= PL_RSQ;          // shot + all children fit one RS pass
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
-            const double distance = sqrt(ddx * ddx + ddy * ddy);      // libm pow(v,2.0) in the reference; threshold test only
+            const double distance = sqrt(avp_pow2(ddx) + avp_pow2(ddy));  // np.sqrt(dx ** 2 + dy ** 2): ** is libm pow (hybrid_a_star.py:308)
             const bool in_radius = distance < p.flag_radius;
             bool can_fast = false;
             long long t_f = 0;

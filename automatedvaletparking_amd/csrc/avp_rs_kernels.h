@@ -6,14 +6,11 @@
 // equal minima wins :106-108), generate_local_course/interpolate :537-624 for the winner, world
 // transform :125-131.
 //
-// sin/cos are the glibc-exact avp_sin/avp_cos, hypot is CPython's algorithm (avp_hypot), float %
-// is CPython's (avp_pymod): all bit-identical to what the reference executes. tan/atan2/asin/acos
-// are the portable kernels of include/avp_libm.h (the CPU oracle's "portable" mode compiles the very
-// same functions, so device == CPU-port bit for bit) and the reference's libm pow(v, 2.0) is
-// evaluated as v*v (its correctly rounded value). Against glibc these differ by <= 1.5 ulp in a few
-// percent of calls: lengths and way-points agree to ~1e-14; where two mirror-image words tie exactly
-// in real arithmetic (about 1 % of random queries) the reference's winner is decided by libm rounding
-// noise and may be the other, equally long, word ("Numerics").
+// Every libm call of the reference is reproduced bit for bit: sin/cos are the glibc-exact avp_sin/avp_cos, hypot is
+// CPython's algorithm (avp_hypot), float % is CPython's (avp_pymod), and tan/atan2/asin/acos and the libm pow(v, 2.0)
+// behind Python's v ** 2 are the restatements of what glibc 2.35's x86-64 FMA build executes (include/avp_glibc_libm.h
+// via include/avp_libm.h; host build == platform libm on 1e9 arguments per function, device == host build in
+// tests/test_gpu_rs.py). Exact ties between mirror-image words therefore fall the way they fall in the reference.
 #pragma once
 #include "avp_device.h"
 #include "../../include/avp_libm.h"
@@ -38,6 +35,7 @@ __device__ __noinline__ double avp_atan2_fn(double y, double x) { return avp_ata
 __device__ __noinline__ double avp_asin_fn(double x) { return avp_asin(x); }
 __device__ __noinline__ double avp_acos_fn(double x) { return avp_acos(x); }
 __device__ __noinline__ double avp_tan_fn(double x) { return avp_tan(x); }
+__device__ __noinline__ double avp_pow2_fn(double x) { return avp_pow2(x); }
 __device__ __noinline__ double avp_M_fn(double x) { return avp_M(x); }
 __device__ __noinline__ double avp_pi_2_pi_fn(double x) { return avp_pi_2_pi(x); }
 __device__ __noinline__ double avp_hypot_fn(double a, double b) { return avp_hypot(a, b); }
@@ -48,6 +46,7 @@ __device__ __noinline__ double avp_hypot_fn(double a, double b) { return avp_hyp
 #define avp_asin(x) avp_asin_fn(x)
 #define avp_acos(x) avp_acos_fn(x)
 #define avp_tan(x) avp_tan_fn(x)
+#define avp_pow2(x) avp_pow2_fn(x)
 #define avp_M(x) avp_M_fn(x)
 #define avp_pi_2_pi(x) avp_pi_2_pi_fn(x)
 #define avp_hypot(a, b) avp_hypot_fn(a, b)
@@ -78,7 +77,7 @@ AVP_D bool rs_LSR(double x, double y, double phi, double sp, double cp, double& 
 {
     double u1, t1;
     rs_polar(x + sp, y - 1.0 - cp, u1, t1);
-    u1 = u1 * u1;
+    u1 = avp_pow2(u1);                                            // u1 ** 2: libm pow
     if (u1 >= 4.0) {
         const double uu = sqrt(u1 - 4.0);
         const double theta = avp_atan2(2.0, uu);
@@ -110,7 +109,7 @@ AVP_D bool rs_SLS(double x, double y, double phi, double& t, double& u, double& 
     if (!(0.0 < phi && phi < AVP_PI * 0.99) || !(y > 0.0 || y < 0.0)) return false;
     const double tan_phi = avp_tan(phi), tan_half = avp_tan(phi / 2.0);
     const double xd = -y / tan_phi + x;
-    const double r = sqrt((x - xd) * (x - xd) + y * y);
+    const double r = sqrt(avp_pow2(x - xd) + avp_pow2(y));          // math.sqrt((x - xd) ** 2 + y ** 2): ** is libm pow
     t = xd - tan_half;
     u = phi;
     v = (y > 0.0 ? r : -r) - tan_half;

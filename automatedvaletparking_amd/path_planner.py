@@ -183,6 +183,7 @@ class BatchPlanner:
             nbytes = int(L.avp_plan_workspace_bytes(self.dm.h, C.c_int32(slots), C.c_int32(self.max_nodes)))
             if nbytes <= 0:
                 raise RuntimeError(_native.last_error())
+            self._ws, self._ws_slots = None, 0              # (release the old buffer first: the two need not coexist)
             self._ws = self.dm.empty(nbytes, self.dm.torch.uint8)
             self._ws_slots = slots
         return self._ws
@@ -195,6 +196,13 @@ class BatchPlanner:
         torch = self.dm.torch
         self.dm.use_current_stream()
         self.dm.planner_launch_begin()
+        try:
+            return self._plan_dev(starts_t, goals_t, want_paths, max_trace, profile, first_stage_only)
+        finally:
+            self.dm.planner_launch_end()                    # also when a launch raised: the next one is ordered after what was enqueued
+
+    def _plan_dev(self, starts_t, goals_t, want_paths, max_trace, profile, first_stage_only):
+        torch = self.dm.torch
         n = starts_t.shape[0]
         L = _native.lib()
         if self.mode == STAGED and not profile:
@@ -212,7 +220,6 @@ class BatchPlanner:
                                                 C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
                                                 C.c_void_p(trace.data_ptr()) if trace is not None else None, C.c_int32(max_trace),
                                                 C.c_int32(self.stage_pops), C.c_int32(1 if first_stage_only else 0), None), "avp_plan_batch_staged")
-            self.dm.planner_launch_end()
             return res, paths, trace
         mode = (self.mode if self.mode in (2, 3, 4) else 1) if profile else int(L.avp_plan_pick_mode(self.dm.h, C.c_int64(n), C.c_int32(self.mode if self.mode != STAGED else 0)))
         cap = self.n_slots if self.n_slots else int(L.avp_plan_slots(self.dm.h, C.c_int32(mode)))
@@ -221,11 +228,27 @@ class BatchPlanner:
         if mode >= 2 and slots < wg:
             mode = 1                                        # fewer than one workgroup of slots: the workgroup form
         sliced = 0 if profile else self._slice_slots(n, wg, mode)
-        self.last_time_sliced = bool(sliced) and self.slice_pops != 0
-        if sliced:
-            slots = sliced
-            _native.chk(L.avp_plan_set_slice_pops(self.dm.h, C.c_int32(-1 if self.slice_pops is None else int(self.slice_pops))), "avp_plan_set_slice_pops")
-        ws = self._workspace(slots)
+        try:
+            ws = self._workspace(sliced if sliced else slots)
+            if sliced:
+                slots = sliced
+        except torch.cuda.OutOfMemoryError:
+            if not sliced or self.time_slice is True:
+                raise
+            sliced = 0                                      # default time slicing is opportunistic: plan unsliced instead
+            ws = self._workspace(slots)
+        # The library parks searches whenever the workspace has a slot per problem, there are more problems than groups and
+        # the handle's slice length is non-zero (avp_plan_batch_mode). The slice length is state of the handle, so it is set
+        # for EVERY group-form launch -- 0 when this planner does not want slicing -- and last_time_sliced is the library's
+        # own condition, not a guess (a caller's explicit n_slots >= n used to be sliced silently with whatever length the
+        # handle's previous user left behind).
+        pops = 0
+        if mode >= 2 and not profile:
+            if sliced or (self.n_slots and self.time_slice is True):
+                pops = -1 if self.slice_pops is None else int(self.slice_pops)
+            _native.chk(L.avp_plan_set_slice_pops(self.dm.h, C.c_int32(pops)), "avp_plan_set_slice_pops")
+        self.last_time_sliced = bool(mode >= 2 and not profile and pops != 0 and slots >= n
+                                     and n > int(L.avp_plan_slots(self.dm.h, C.c_int32(mode))))
         res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
         paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
         trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
@@ -246,7 +269,6 @@ class BatchPlanner:
                                             C.c_void_p(look.data_ptr()) if look is not None else None, C.c_int64(look.numel() if look is not None else 0),
                                             C.c_void_p(order.data_ptr()) if order is not None else None), "avp_plan_batch_ex")
         self._keep = (look, order)                          # (alive until the next call: the launch is asynchronous)
-        self.dm.planner_launch_end()
         return res, paths, trace
 
     def plan(self, starts, goals, max_trace: int = 0) -> List[PlanResult]:

@@ -302,6 +302,11 @@ int32_t avp_rasterize_edges(int32_t device, void* stream, const double* xs, cons
 
 /* Device evaluation of the shared scalar maths (test hook): out_sin/out_cos = avp_sin/avp_cos(x). */
 int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos);
+/* Device evaluation of the restated glibc libm (test hook; include/avp_glibc_libm.h): kind 0 out = atan2(a, b) as
+ * math.atan2 (rs_curve.py:176,313,414,503,664), 1 asin(a) (:190), 2 acos(a) (:332,346), 3 tan(a) (:217-226),
+ * 4 pow(a, 2.0) = Python's a ** 2 (:172,220,226; hybrid_a_star.py:308; collision_check.py:131-134). b is read for
+ * kind 0 only. */
+int32_t avp_libm_batch(avp_map* map, int32_t kind, const double* a, const double* b, int64_t n, double* out);
 /* Device IEEE check hook: q = a / b, r = sqrt(|a|), h = hypot(a, b) as the kernels compute them. */
 int32_t avp_ieee_batch(avp_map* map, const double* a, const double* b, int64_t n, double* q, double* r, double* h);
 

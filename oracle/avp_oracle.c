@@ -27,13 +27,15 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-/* "portable" mode: atan2/asin/acos/tan come from include/avp_libm.h (the functions the device
- * compiles) and pow(v, 2.0) becomes v*v, so that this oracle is bit-identical to the HIP path.
- * Default (0) = glibc libm = the reference's arithmetic, pinned by the golden vectors. */
+/* "restated libm" mode (check instrumentation; default 0 = the platform's glibc libm, the reference's arithmetic,
+ * pinned by the golden vectors): atan2 / asin / acos / tan / pow(v, 2.0) come from include/avp_libm.h -- the bit-for-bit
+ * restatement of glibc 2.35's kernels that libavp_hip.so compiles for the device. The two modes must agree everywhere
+ * (tests/test_oracle_restated.py runs every trace fixture and the BASELINE workloads in both); the switch exists so that
+ * a disagreement between the restatement and the libm the goldens were captured with shows up on the CPU, by name. */
 #include "../include/avp_libm.h"
-static int g_portable = 0;
-ORC_API void orc_set_portable(int v) { g_portable = v; }
-ORC_API int orc_get_portable(void) { return g_portable; }
+static int g_restated = 0;
+ORC_API void orc_set_restated_libm(int v) { g_restated = v; }
+ORC_API int orc_get_restated_libm(void) { return g_restated; }
 /* What-if switch for the heuristic Dijkstra (test instrumentation; default 0 = the reference's behaviour): the
  * reference lowers the distance of an open cell IN PLACE without restoring the heap order (compute_h.py:226-227), so a
  * cell is occasionally popped one step early. With g_dij_reheap = 1 the decrease is followed by the sift-up a correct
@@ -43,11 +45,11 @@ ORC_API int orc_get_portable(void) { return g_portable; }
 static int g_dij_reheap = 0;
 ORC_API void orc_set_dij_reheap(int v) { g_dij_reheap = v; }
 ORC_API int orc_get_dij_reheap(void) { return g_dij_reheap; }
-#define ATAN2(y, x) (g_portable ? avp_atan2((y), (x)) : atan2((y), (x)))
-#define ASIN(x) (g_portable ? avp_asin(x) : asin(x))
-#define ACOS(x) (g_portable ? avp_acos(x) : acos(x))
-#define TAN(x) (g_portable ? avp_tan(x) : tan(x))
-#define POW2(v) (g_portable ? (v) * (v) : pow((v), 2.0))
+#define ATAN2(y, x) (g_restated ? avp_atan2((y), (x)) : atan2((y), (x)))
+#define ASIN(x) (g_restated ? avp_asin(x) : asin(x))
+#define ACOS(x) (g_restated ? avp_acos(x) : acos(x))
+#define TAN(x) (g_restated ? avp_tan(x) : tan(x))
+#define POW2(v) (g_restated ? avp_pow2(v) : pow((v), 2.0))
 
 /* ------------------------------------------------------------------------------------------ */
 /* context: map + vehicle + config                                                            */

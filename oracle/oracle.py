@@ -77,8 +77,8 @@ def lib():
         L.orc_dij_nclosed.restype = C.c_int64
         L.orc_dij_nclosed.argtypes = [C.c_void_p]
         L.orc_dij_dump.argtypes = [C.c_void_p] + [C.c_void_p] * 4
-        L.orc_set_portable.argtypes = [C.c_int]
-        L.orc_get_portable.restype = C.c_int
+        L.orc_set_restated_libm.argtypes = [C.c_int]
+        L.orc_get_restated_libm.restype = C.c_int
         L.orc_set_dij_reheap.argtypes = [C.c_int]
         L.orc_get_dij_reheap.restype = C.c_int
         L.orc_plan.restype = C.c_int32
@@ -109,36 +109,36 @@ class exact_dijkstra_order:
 
 
 class device_arithmetic:
-    """Context manager: the oracle configured exactly as the device computes -- portable atan2/asin/acos/tan
-    (`portable_libm`) and exact (distance, id) pop order in the heuristic Dijkstra (`exact_dijkstra_order`). The GPU
-    parity tests compare against this mode with no tolerance at all; what the two switches change relative to the
-    reference-faithful default is measured on the CPU (tests/test_oracle_portable.py, tests/test_dijkstra_stale_key.py)."""
+    """Context manager: the oracle configured as the device computes. Since round 4 the device's atan2 / asin / acos /
+    tan / pow are glibc's bit for bit (include/avp_glibc_libm.h), so the libm here is the PLATFORM's, the one the golden
+    vectors were captured with; the only switch left is the exact (distance, id) pop order of the heuristic Dijkstra
+    (`exact_dijkstra_order`), which can change nothing but the `h_misses` counter (tests/test_dijkstra_stale_key.py).
+    The GPU parity tests compare against this mode with no tolerance at all."""
 
     def __enter__(self):
-        self.a, self.b = portable_libm(), exact_dijkstra_order()
-        self.a.__enter__()
+        self.b = exact_dijkstra_order()
         self.b.__enter__()
         return self
 
     def __exit__(self, *a):
         self.b.__exit__(*a)
-        self.a.__exit__(*a)
 
 
-class portable_libm:
-    """Context manager: run the oracle with the portable atan2/asin/acos/tan of include/avp_libm.h
-    (bit-identical to the device path) instead of glibc's (the reference's arithmetic)."""
+class restated_libm:
+    """Context manager (check instrumentation): run the oracle with the atan2/asin/acos/tan/pow of include/avp_libm.h
+    -- the restatement of glibc's kernels that the device compiles -- instead of the platform libm. Both must give the
+    same results everywhere (tests/test_oracle_restated.py)."""
 
     def __init__(self, on: bool = True):
         self.on = 1 if on else 0
 
     def __enter__(self):
-        self.prev = lib().orc_get_portable()
-        lib().orc_set_portable(self.on)
+        self.prev = lib().orc_get_restated_libm()
+        lib().orc_set_restated_libm(self.on)
         return self
 
     def __exit__(self, *exc):
-        lib().orc_set_portable(self.prev)
+        lib().orc_set_restated_libm(self.prev)
         return False
 
 

@@ -17,22 +17,6 @@ CAP = 300                      # pop cap of the full-size runs (the reference ha
 THREADS = min(256, os.cpu_count() or 1)
 
 
-def same(r, w):
-    """GPU PlanResult r == oracle dict w: status, pops, the whole pop trace (node index, parent, grid id, pose, g, h, f,
-    gear -- bit for bit), counters, final path."""
-    if r.status != w["status"] or r.n_pops != w["n_pops"]:
-        return False
-    t, wt = r.trace, w["trace"]
-    if not np.array_equal(t[:, :10], wt[:len(t), :10]):
-        return False
-    c = r.counters
-    if any(c[k] != w[k] for k in ("n_closed", "n_open", "global_index", "n_rs", "n_checks")) or c["h_misses"] != w["n_dij_calls"]:
-        return False
-    if r.status == 0 and not np.array_equal(np.asarray(r.final_path), np.asarray(w["final_path"])):
-        return False
-    return True
-
-
 def free_pairs(m, dm, n_pairs, rng):
     """SURVEY 8(d) sampler: footprint-free (GPU check) poses outside every obstacle polygon, paired up."""
     from automatedvaletparking_amd import workloads
@@ -40,9 +24,11 @@ def free_pairs(m, dm, n_pairs, rng):
 
 
 def plan_and_compare(m, veh, cfg, starts, goals, cap=CAP, threads=THREADS, max_nodes=8192):
-    """Plans the batch on the GPU (with traces) and on the oracle (portable libm, one problem per host thread).
-    Returns (results, indices that differ, gpu seconds, cpu seconds)."""
+    """Plans the batch on the GPU (with traces) and on the oracle in its PINNED mode (platform glibc libm, the reference's
+    Dijkstra pop order; one problem per host thread) and compares every observable field (tests/_parity.py).
+    Returns (results, [(index, what differs)], gpu seconds, cpu seconds)."""
     import torch
+    import _parity
     from automatedvaletparking_amd import _native, path_planner
     from oracle import oracle
     dm = _native.DeviceMap(m, veh, cfg, max_pops=cap)
@@ -55,11 +41,9 @@ def plan_and_compare(m, veh, cfg, starts, goals, cap=CAP, threads=THREADS, max_n
     t_gpu = time.perf_counter() - t0
     o = oracle.Oracle(m, veh, cfg, max_pops=cap)
     t1 = time.perf_counter()
-    with oracle.device_arithmetic():
-        with ThreadPoolExecutor(threads) as ex:
-            ws = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=cap), zip(starts, goals)))
+    bad, h_diff = _parity.compare_pinned(o, res, starts, goals, cap, threads)
     t_cpu = time.perf_counter() - t1
-    bad = [i for i, (r, w) in enumerate(zip(res, ws)) if not same(r, w)]
+    plan_and_compare.h_diff = getattr(plan_and_compare, "h_diff", 0) + len(h_diff)
     return res, bad, t_gpu, t_cpu
 
 

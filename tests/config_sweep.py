@@ -1,4 +1,4 @@
-"""BASELINE.json configs 3-5 at full size on one GPU: throughput + parity against the CPU oracle (portable libm).
+"""BASELINE.json configs 3-5 at full size on one GPU: throughput + parity against the CPU oracle in its pinned mode (tests/_parity.py).
 
     python tests/config_sweep.py [--pairs 128] [--cap 300] [--threads 64] > profiles/rNN_config_sweep.jsonl
 

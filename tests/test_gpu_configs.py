@@ -1,6 +1,6 @@
 """BASELINE.json configs 3, 4 and 5 at FULL size under `pytest -m gpu`, every problem compared with the CPU oracle
-(portable libm = the device's arithmetic) bit for bit: status, pop count, the whole pop trace incl. grid ids, counters,
-final path.
+in its PINNED mode (the platform's glibc libm and the reference's Dijkstra pop order, tests/_parity.py) bit for bit:
+status, pop count, the whole pop trace incl. grid ids, counters, A* path, Reeds-Shepp tail, final path.
 
   C3: all 20 BenchmarkCases x 128 random start/goal pairs (seed 20260927 + k), pop cap 300 -> 2 560 problems;
   C4: synthetic 200 x 200 grid, 32 convex polygons: 4 096-pose check batch (both checkers) + 256 plans;

@@ -1,16 +1,15 @@
 """The parity chain on the BASELINE workloads themselves, closed on the CPU.
 
-    reference  ==  oracle (glibc libm, the reference's Dijkstra pop order)      pinned by the 215 golden fixtures
-    oracle (glibc)  ~  oracle (device arithmetic)                               THIS FILE, per workload
-    oracle (device arithmetic)  ==  GPU                                         tests/test_gpu_*.py, no tolerance
+    reference  ==  oracle (platform glibc libm, the reference's Dijkstra pop order)     pinned by the 215 golden fixtures
+    oracle (pinned)  ==  oracle (restated libm + exact (distance, id) sweep order)      THIS FILE, per workload
+    oracle (pinned)  ==  GPU                                                            tests/test_gpu_*.py (tests/_parity.py)
 
-The GPU parity tests compare with the oracle in the device's arithmetic (portable atan2 / asin / acos / tan of
-include/avp_libm.h, exact (distance, id) order in the heuristic sweep). What that mode changes relative to the
-reference-faithful default was measured on the golden fixtures only (tests/test_oracle_portable.py); here it is measured
-on the problems bench.py times: all 256 of config[1] and a 256-problem slice each of configs [2], [3], [4]. north_star's
-bar: the popped grid-id sequence is identical (for searches the pop cap stops: their whole capped trace) and the
-way-points of a finished plan agree within max(1e-6, 4 ulp). Divergences are listed by name below, not tolerated silently.
-"""
+The device differs from the pinned oracle in two implementation facts: it computes atan2 / asin / acos / tan / pow with the
+RESTATEMENT of glibc's kernels (include/avp_glibc_libm.h) and it sweeps the heuristic field in exact (distance, id) order.
+This file runs the oracle both ways on the problems bench.py times -- all 256 of config[1] and a 256-problem slice each of
+configs [2], [3], [4] -- and asserts that NOTHING observable differs: status, pop count, the complete pop trace (all
+columns, bit for bit), the A* counters and the final path. There is no list of known divergences (rounds 1-3 had two
+config[4] problems here whose Reeds-Shepp ties a nearly-correctly-rounded atan2 broke the other way)."""
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -20,14 +19,6 @@ import pytest
 from automatedvaletparking_amd import workloads
 
 THREADS = min(16, os.cpu_count() or 1)
-
-# (workload, problem index) whose grid-id trace differs between the two arithmetics -- measured, each an exact tie of
-# two open nodes / two Reeds-Shepp words decided by last-bit libm noise (cf. KNOWN_TIE_DIVERGENCE in test_oracle_portable.py)
-# c5 (the mirror-symmetric parking lot, shot at every pop): problems 69 and 176 of the first 256 -- in each, two open nodes
-# whose keys agree to within 2 ulp in the reference's own arithmetic are popped in the other order
-# (`_assert_one_ulp_twin` below pins exactly that); 69 is a capped search, 176 finishes on a different, equally priced branch.
-KNOWN_TRACE_DIVERGENCE = {("c5", 69), ("c5", 176)}
-
 
 def _checker(veh, cfg):
     from oracle import oracle
@@ -45,60 +36,41 @@ def _both_modes(m, veh, cfg, starts, goals, cap):
     def run():
         with ThreadPoolExecutor(THREADS) as ex:
             return list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=cap), zip(starts, goals)))
-    ref = run()                                   # glibc libm + the reference's pop order: the pinned mode
-    with oracle.device_arithmetic():
-        dev = run()
+    ref = run()                                   # platform libm + the reference's pop order: the pinned mode
+    with oracle.restated_libm(), oracle.exact_dijkstra_order():
+        dev = run()                               # what the device implements
     return ref, dev
 
 
-def _compare(name, ref, dev, coords_scale):
-    """-> (list of diverging problem indices, stats)."""
+COUNTERS = ("n_closed", "n_open", "global_index", "n_rs", "n_checks")
+
+
+def _compare(name, ref, dev):
+    """-> (list of diverging problem indices, stats). Bit for bit; h_misses (n_dij_calls) is counted apart: it is the one
+    internal number the sweep order may change (tests/test_dijkstra_stale_key.py)."""
     bad = []
-    n_done = n_bit = 0
-    worst = 0.0
+    n_done = h_diff = 0
     for i, (a, b) in enumerate(zip(ref, dev)):
-        same = a["status"] == b["status"] and a["n_pops"] == b["n_pops"] and np.array_equal(a["trace"][:, 2], b["trace"][:, 2])
-        if same and a["status"] == 0:
-            fa, fb = a["final_path"], b["final_path"]
-            tol = max(1e-6, 4 * np.spacing(coords_scale))
-            same = fa.shape == fb.shape and (fa.size == 0 or np.abs(fa - fb).max() <= tol)
-            if same and fa.size:
-                worst = max(worst, float(np.abs(fa - fb).max()))
-                n_bit += bool(np.array_equal(fa, fb))
-            n_done += 1
+        same = (a["status"] == b["status"] and a["n_pops"] == b["n_pops"] and np.array_equal(a["trace"], b["trace"], equal_nan=True)
+                and all(a[k] == b[k] for k in COUNTERS) and np.array_equal(a["final_path"], b["final_path"])
+                and np.array_equal(a["astar_path"], b["astar_path"]))
+        n_done += a["status"] == 0
+        h_diff += a["n_dij_calls"] != b["n_dij_calls"]
         if not same:
             bad.append(i)
-    return bad, dict(problems=len(ref), finished=n_done, bit_identical_paths=n_bit, worst_waypoint_diff=worst)
+    return bad, dict(problems=len(ref), finished=int(n_done), h_misses_differ=int(h_diff))
 
 
-def _assert_one_ulp_twin(a, b):
-    """A listed divergence is a swap of two open nodes of (almost) equal cost and nothing else: up to the first differing
-    pop the traces are identical (node, parent, grid id); there the reference pops node A, the device arithmetic node B,
-    B is in the reference's own trace later on, and the reference's own keys of A and B differ by a few ulp at most (a key
-    is g + a Reeds-Shepp length, itself a sum of up to five segment lengths, each within an ulp of libm noise)."""
-    ta, tb = a["trace"], b["trace"]
-    n = min(len(ta), len(tb))
-    k = int(np.where(ta[:n, 2] != tb[:n, 2])[0][0])
-    assert np.array_equal(ta[:k, :3], tb[:k, :3])
-    later = np.where(ta[k:, 0] == tb[k, 0])[0]
-    assert len(later), "the node popped instead never shows up in the reference-arithmetic trace"
-    fa, fb = float(ta[k, 8]), float(ta[k + int(later[0]), 8])
-    assert abs(fa - fb) <= 4 * np.spacing(max(abs(fa), abs(fb))), (k, fa, fb)
-    assert abs(float(tb[k, 8]) - fb) <= 4 * np.spacing(abs(fb))
-
-
-def _assert_chain(name, bad, stats, ref=None, dev=None):
-    listed = {i for (w, i) in KNOWN_TRACE_DIVERGENCE if w == name}
-    assert set(bad) == listed, f"{name}: diverging problems {sorted(bad)} vs listed {sorted(listed)}; {stats}"
+def _assert_chain(name, bad, stats):
+    assert not bad, f"{name}: problems {sorted(bad)} differ between the pinned oracle and the device's arithmetic; {stats}"
     assert stats["finished"] > 0, stats
-    for i in sorted(listed):
-        _assert_one_ulp_twin(ref[i], dev[i])
+    assert stats["h_misses_differ"] <= max(2, stats["problems"] // 50), stats
 
 
 def test_config1_all_256(vehicle, cfg):
     m, st, go = workloads.case1_pairs(cfg, _checker(vehicle, cfg), 256)
     ref, dev = _both_modes(m, vehicle, cfg, st, go, cap=1000)
-    bad, stats = _compare("c2", ref, dev, max(abs(v) for v in m.boundary))
+    bad, stats = _compare("c2", ref, dev)
     _assert_chain("c2", bad, stats)
     assert sum(r["status"] == 4 for r in ref) == sum(r["status"] == 4 for r in dev)        # the same searches hit the cap
 
@@ -109,21 +81,20 @@ def test_config2_slice(vehicle, cfg):
     for k in range(1, 21):
         m, st, go = workloads.c3_map_pairs(k, cfg, make, 128)
         ref, dev = _both_modes(m, vehicle, cfg, st[:13], go[:13], cap=300)
-        bad, stats = _compare(f"c3/{k}", ref, dev, max(abs(v) for v in m.boundary))
-        listed = {i for (w, i) in KNOWN_TRACE_DIVERGENCE if w == f"c3/{k}"}
-        assert set(bad) == listed, (k, bad, stats)
+        bad, stats = _compare(f"c3/{k}", ref, dev)
+        assert not bad, (k, bad, stats)
 
 
 def test_config3_plans(vehicle, cfg):
     m, _ = workloads.c4_map()
     st, go = workloads.c4_plan_pairs(m, _checker(vehicle, cfg), 256)
     ref, dev = _both_modes(m, vehicle, cfg, st, go, cap=300)
-    bad, stats = _compare("c4", ref, dev, 24.0)
+    bad, stats = _compare("c4", ref, dev)
     _assert_chain("c4", bad, stats)
 
 
 def test_config4_slice(vehicle, cfg):
     m, c5, st, go, _ = workloads.c5_problems(cfg, 1024)
     ref, dev = _both_modes(m, vehicle, c5, st[:256], go[:256], cap=300)
-    bad, stats = _compare("c5", ref, dev, max(abs(v) for v in m.boundary))
-    _assert_chain("c5", bad, stats, ref, dev)
+    bad, stats = _compare("c5", ref, dev)
+    _assert_chain("c5", bad, stats)
