@@ -24,15 +24,30 @@ __device__ __forceinline__ void avp_lds_tables_fill()
 template <bool WITH_ATAN> __device__ inline void avp_lds_tables_fill() {}       // host pass of hipcc: declaration only
 #endif
 
-// two_circle_checker's point test (collision_check.py:131-134): np.sqrt(pow(dx, 2) + pow(dy, 2)) <= Rd, where pow is libm's,
-// which is NOT dx*dx (0.08 % of arguments differ in the last bit). pow(v, 2) and v*v differ by <= 1 ulp, the sum by
-// <= 2 ulp, its root by <= 2 ulp: outside a band of 8 ulp around Rd the plain squares decide, inside it the exact
-// avp_pow2 (about one test in 1e14 on real maps) -- the same booleans as the reference at the cost of one comparison.
+// libm pow(v, 2) behind Python's ** / pow(v, 2) in two THRESHOLD tests of the reference:
+//   two_circle_checker (collision_check.py:131-134)   np.sqrt(pow(dx, 2) + pow(dy, 2)) <= Rd
+//   try_reach_goal (hybrid_a_star.py:308-310)         np.sqrt(dx ** 2 + dy ** 2) < flag_radius
+// pow(v, 2) is NOT v*v (0.08 % of arguments differ in the last bit), but the two differ by <= 1 ulp, the sum by <= 2 ulp,
+// its root by <= 2 ulp: outside a band of 8 ulp around the threshold the plain squares decide, inside it (one test in
+// ~1e13 on real maps) the exact avp_pow2 -- the reference's booleans at the cost of one comparison. The exact form is a
+// called function on the device: inlined, its table look-ups and 40 live doubles sat in the register budget of the
+// planner's pop loop (29 spilled VGPRs in plan_kernel).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__ double avp_pow2_norm(double dx, double dy) { return sqrt(avp_pow2(dx) + avp_pow2(dy)); }
+#else
+static inline double avp_pow2_norm(double dx, double dy) { return sqrt(avp_pow2(dx) + avp_pow2(dy)); }
+#endif
 AVP_HD bool avp_circle_hit(double dx, double dy, double Rd)
 {
     const double s = sqrt(dx * dx + dy * dy);
     if (fabs(s - Rd) > Rd * 0x1p-49) return s <= Rd;
-    return sqrt(avp_pow2(dx) + avp_pow2(dy)) <= Rd;
+    return avp_pow2_norm(dx, dy) <= Rd;
+}
+AVP_HD bool avp_within_radius(double dx, double dy, double radius)
+{
+    const double s = sqrt(dx * dx + dy * dy);
+    if (fabs(s - radius) > radius * 0x1p-49) return s < radius;
+    return avp_pow2_norm(dx, dy) < radius;
 }
 
 // Costmap resident in HBM. Column-major occupancy in two forms:

@@ -992,13 +992,13 @@ AVP_D double pl_node_cost(const avp_params& p, int node_forward, double node_the
 // and the chunks are spread over the waves (longest-processing-time first, measured solver costs), each
 // chunk in its own round of its wave: sched[round][wave][lane].
 static __device__ const int8_t PL_SCHED_WORDS[9][8] = { { 18, 19, 20, 21, -1, -1, -1, -1 }, { 22, 23, 24, 25, -1, -1, -1, -1 }, { 0, 1, -1, -1, -1, -1, -1, -1 },
-                                                        { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 }, { 6, 7, 8, 9, -1, -1, -1, -1 },
+                                                        { 6, 7, 8, 9, -1, -1, -1, -1 }, { 10, 11, 12, 13, 14, 15, 16, 17 }, { 26, 27, 28, 29, 34, 35, 36, 37 },
                                                         { 30, 31, 32, 33, 38, 39, 40, 41 }, { 2, 3, 4, 5, -1, -1, -1, -1 }, { 42, 43, 44, 45, -1, -1, -1, -1 } };
-static __device__ const int32_t PL_SCHED_COST[9] = { 106, 85, 78, 60, 60, 59, 45, 43, 30 };
+static __device__ const int32_t PL_SCHED_COST[9] = { 78, 67, 63, 54, 49, 45, 31, 30, 16 };
 __device__ __noinline__ void pl_rs_build_schedule(PlShared& s, int nq)      // (a leaf call: runs once, must not be unrolled into the kernel body)
 {
-    // solvers by descending cost (x100 cycles per call of one wave, scripts/microbench/rs_words.hip on MI355X):
-    // LRLRn, LRLRp (tauOmega: 5 sin/cos + acos + atan2), SLS (two nearly-CR tan), LRL, LRSL, LSR, LRSR, LSL, LRSLR
+    // solvers by descending cost (x100 cycles per call of one wave, scripts/microbench/rs_words.hip on MI355X with round 4's
+    // glibc-exact libm): LRLRn, LRLRp (tauOmega: 5 sin/cos + acos + atan2), SLS (two tan, two pow), LRL, LSR, LRSL, LRSR, LSL, LRSLR
     // (runs once per workgroup and per child count, on one thread; its work arrays live in LDS: no stack objects)
     const int nwave = PL_THREADS / 64;
 #pragma nounroll
@@ -2075,8 +2075,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const long long t_pop0 = t_d;
             const bool one_pass = nchild + 1 <= PL_RSQ;          // shot + all children fit one RS pass
             const double ddx = cn.x - s.goal[0], ddy = cn.y - s.goal[1];
-            const double distance = sqrt(avp_pow2(ddx) + avp_pow2(ddy));  // np.sqrt(dx ** 2 + dy ** 2): ** is libm pow (hybrid_a_star.py:308)
-            const bool in_radius = distance < p.flag_radius;
+            const bool in_radius = avp_within_radius(ddx, ddy, p.flag_radius);   // np.sqrt(dx ** 2 + dy ** 2) < flag_radius, ** = libm pow (hybrid_a_star.py:308)
             bool can_fast = false;
             long long t_f = 0;
             int32_t pre_cand = -1;

@@ -477,8 +477,7 @@ __device__ __noinline__ void pw_ph_children(PW_PHASE_ARGS)
     if (wv == 0) {
         const double cnx = s.cn.x, cny = s.cn.y, cnth = s.cn.th;
         const double ddx = cnx - s.goal[0], ddy = cny - s.goal[1];
-        const double distance = sqrt(avp_pow2(ddx) + avp_pow2(ddy));      // ** is libm pow (hybrid_a_star.py:308)
-        const bool in_radius = distance < p.flag_radius;
+        const bool in_radius = avp_within_radius(ddx, ddy, p.flag_radius);   // ** is libm pow (hybrid_a_star.py:308)
         if (lane == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; }
         if (lane < nchild) {
             PlChild& ch = s.child[lane];

@@ -60,6 +60,11 @@ AVP_GLIBC_FN double avpg_copysign(double mag, double sgn)
 #define AVPG_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #endif
 #define AVPG_T(tab, i) avpg_from_bits(tab[(i)])
+/* where the rows of uatan.tbl are read from: row i = 7 words {x_i, atan x_i, c1 .. c5}. A kernel that stages the table
+ * elsewhere (LDS) defines AVPG_CIJ_ROW before including this header. */
+#ifndef AVPG_CIJ_ROW
+#define AVPG_CIJ_ROW(i) (AVP_G_CIJ + 7 * (i))
+#endif
 
 /* ================================================================================================ atan2 */
 /* the odd Taylor polynomial of atan on |u| < 1/16, coefficients d3 .. d13 of e_atan2.c's atnat2.h */
@@ -80,7 +85,8 @@ AVP_GLIBC_FN int avpg_atan2_row(double u)
     return (int)(AVPG_FMA(u, 256.0, two52) - two52) - 16;
 }
 
-AVP_GLIBC_FN double avpg_atan2(double y, double x)
+/* the literal translation: every range, every special case; the slow path of avpg_atan2 below */
+AVP_GLIBC_FN double avpg_atan2_ref(double y, double x)
 {
     const double hpi = 0x1.921fb54442d18p+0, hpi1 = 0x1.1a62633145c07p-54;     /* pi/2 = hpi + hpi1 */
     const double opi = 0x1.921fb54442d18p+1, opi1 = 0x1.1a62633145c07p-53;     /* pi   = opi + opi1 */
@@ -137,7 +143,7 @@ AVP_GLIBC_FN double avpg_atan2(double y, double x)
                 z = u + zz;
                 return avpg_copysign(z, y);
             }
-            const uint64_t* c = AVP_G_CIJ + 7 * avpg_atan2_row(u);
+            const uint64_t* c = AVPG_CIJ_ROW(avpg_atan2_row(u));
             const double t3 = u - AVPG_T(c, 0);
             double dv;
             v = t3 + du;
@@ -164,7 +170,7 @@ AVP_GLIBC_FN double avpg_atan2(double y, double x)
             return avpg_copysign(z, y);
         }
         {
-            const uint64_t* c = AVP_G_CIJ + 7 * avpg_atan2_row(u);
+            const uint64_t* c = AVPG_CIJ_ROW(avpg_atan2_row(u));
             v = (u - AVPG_T(c, 0)) + du;
             double p = AVPG_T(c, 6);
             p = AVPG_FMA(p, v, AVPG_T(c, 5));
@@ -188,7 +194,7 @@ AVP_GLIBC_FN double avpg_atan2(double y, double x)
             z = t3 + t2;
             return avpg_copysign(z, y);
         }
-        const uint64_t* c = AVP_G_CIJ + 7 * avpg_atan2_row(u);
+        const uint64_t* c = AVPG_CIJ_ROW(avpg_atan2_row(u));
         v = (u - AVPG_T(c, 0)) + du;
         double p = AVPG_T(c, 6);
         p = AVPG_FMA(p, v, AVPG_T(c, 5));
@@ -211,7 +217,7 @@ AVP_GLIBC_FN double avpg_atan2(double y, double x)
         return avpg_copysign(z, y);
     }
     {
-        const uint64_t* c = AVP_G_CIJ + 7 * avpg_atan2_row(u);
+        const uint64_t* c = AVPG_CIJ_ROW(avpg_atan2_row(u));
         v = (u - AVPG_T(c, 0)) + du;
         double p = AVPG_T(c, 6);
         p = AVPG_FMA(p, v, AVPG_T(c, 5));
@@ -223,6 +229,70 @@ AVP_GLIBC_FN double avpg_atan2(double y, double x)
         z = t1 + zz;
         return avpg_copysign(z, y);
     }
+}
+
+/* atan2 for wave-wide evaluation. The translation above is a tree of eight leaves -- (i) .. (iv) by the signs and the
+ * larger of |x|, |y|, each with a polynomial (u < 1/16) and a table branch -- and a wave whose lanes hold directions all
+ * around the circle (the Reeds-Shepp words: one word, 64 queries) executes all eight one after the other. Here the eight
+ * are ONE instruction stream with per-lane selects: (ii), (iii), (iv) are the same expressions up to the constants
+ * (pi/2 or pi, their tails) and exact sign flips (a - b == a + (-b), fma(-p, v, c) == fma(p, -v, c) bit for bit), (i)
+ * shares the division, the table row and the first three Horner steps; both the polynomial and the table form are
+ * evaluated and the lane's one is kept. Same operations on the same operands in the same order for every lane, so the
+ * results are those of avpg_atan2_ref bit for bit (scripts/glibc_libm_sweep.c compares both with libm). Zeros,
+ * infinities, NaNs, exponents that need glibc's rescaling and ratios beyond 2^+-57 take avpg_atan2_ref. */
+AVP_GLIBC_FN double avpg_atan2(double y, double x)
+{
+    const double hpi = 0x1.921fb54442d18p+0, hpi1 = 0x1.1a62633145c07p-54;
+    const double opi = 0x1.921fb54442d18p+1, opi1 = 0x1.1a62633145c07p-53;
+    const int ex = (avpg_hi(x) >> 20) & 0x7ff, ey = (avpg_hi(y) >> 20) & 0x7ff;
+    const int dxy = ey - ex;
+    if (!(ex >= 524 && ex <= 1522 && ey >= 524 && ey <= 1522 && dxy >= -56 && dxy <= 56)) return avpg_atan2_ref(y, x);
+    const double ax = fabs(x), ay = fabs(y);
+    const int swap = !(ay < ax);                       /* u = ax / ay */
+    const double num = swap ? ax : ay, den = swap ? ay : ax;
+    const double u = num / den;
+    /* table row (garbage but in range for u < 1/16, where it is not used): issued before the second division */
+    int row = avpg_atan2_row(u);
+    row = row < 0 ? 0 : row;
+    const uint64_t* c = AVPG_CIJ_ROW(row);
+    const double c0 = AVPG_T(c, 0), c1 = AVPG_T(c, 1), c2 = AVPG_T(c, 2), c3 = AVPG_T(c, 3), c4 = AVPG_T(c, 4), c5 = AVPG_T(c, 5), c6 = AVPG_T(c, 6);
+    const double vq = den * u;
+    const double vv = AVPG_FMA(den, u, -vq);
+    const double du = ((num - vq) - vv) / den;
+    const int xpos = x > 0.0;
+    const int case1 = xpos && !swap;                   /* (i)   atan(ay/ax)          */
+    const int case3 = !xpos && ay > ax;                /* (iii) pi/2 + atan(ax/ay)   */
+    const int case4 = !xpos && !(ay > ax);             /* (iv)  pi - atan(ay/ax); (ii) pi/2 - atan(ax/ay) is the rest */
+    const double H = case4 ? opi : hpi, H1 = case4 ? opi1 : hpi1;
+    const int neg = !case3;                            /* (ii), (iv): the atan term is subtracted */
+    /* polynomial form, u < 1/16 */
+    const double v2 = u * u;
+    const double P = avpg_atan2_poly(v2);
+    const double uv = u * v2;
+    const double z1s = u + AVPG_FMA(uv, P, du);                                   /* (i) */
+    const double su = neg ? -u : u, sdu = neg ? -du : du;
+    const double zzs = uv * P;
+    const double t2s = H + su;
+    const double cors = (H - t2s) + su;
+    const double t3s = ((cors + H1) + sdu) + (neg ? -zzs : zzs);
+    const double zos = t3s + t2s;                                                 /* (ii) .. (iv) */
+    /* table form, u >= 1/16 */
+    const double t3 = u - c0;
+    const double v = t3 + du;
+    const double dv = fabs(t3) > fabs(du) ? (t3 - v) + du : (du - v) + t3;
+    double p = AVPG_FMA(c6, v, c5);
+    p = AVPG_FMA(p, v, c4);
+    p = AVPG_FMA(p, v, c3);
+    double zz1 = (v * v) * p;
+    zz1 = AVPG_FMA(dv, c2, zz1);
+    zz1 = AVPG_FMA(v, c2, zz1);
+    const double z1t = zz1 + c1;                                                  /* (i) */
+    p = AVPG_FMA(p, v, c2);
+    const double zzt = AVPG_FMA(neg ? -p : p, v, H1);
+    const double zot = (H + (neg ? -c1 : c1)) + zzt;                              /* (ii) .. (iv) */
+    const int small = u < 0.0625;
+    const double z = case1 ? (small ? z1s : z1t) : (small ? zos : zot);
+    return avpg_copysign(z, y);
 }
 
 /* ========================================================================================== asin / acos */
@@ -251,17 +321,22 @@ AVP_GLIBC_FN int avpg_asin_row(int32_t k, int* deg)
     *deg = 10;
     return 768 + 15 * ((k >> 13) & 0x7f);                                         /* [0.953125, 0.96875) */
 }
-/* the table polynomial: t = c1 xx + (c2 + c3 xx + .. + c_deg xx^(deg-2)) xx^2 + c_sq, Horner with fma,
- * the last step on xx^2, c1 last. Returns t; *tail = asin(x_n). */
+/* the table polynomial: t = c1 xx + (c2 + c3 xx + .. + c_deg xx^(deg-2)) xx^2 + c_sq, Horner with fma, the last step on
+ * xx^2, c1 last. Returns t; *tail = asin(x_n). The chain has the SAME length for every row -- steps above the row's degree
+ * run on a zero coefficient, and fma(0, xx, 0) = 0, fma(0, xx, c) = c exactly, so the value is glibc's -- which lets the
+ * lanes of a wave (rows of different degree) share one instruction stream whose 13 loads are all in flight at once. */
 AVP_GLIBC_FN double avpg_asin_tabpoly(double ax_signed, int n, int deg, double* tail)
 {
     const uint64_t* a = AVP_G_ASNCS + n;
     const double xx = ax_signed - AVPG_T(a, 0);
-    double p = AVPG_T(a, deg);
-    for (int j = deg - 1; j >= 2; --j) p = AVPG_FMA(p, xx, AVPG_T(a, j));
-    p = AVPG_FMA(p, xx * xx, AVPG_T(a, deg + 1));
-    *tail = AVPG_T(a, deg + 2);
-    return AVPG_FMA(xx, AVPG_T(a, 1), p);
+    const double k1 = AVPG_T(a, 1), csq = AVPG_T(a, deg + 1), tl = AVPG_T(a, deg + 2);
+    double cf[11];
+    for (int j = 2; j <= 10; ++j) cf[j] = AVPG_T(a, j);                     /* (reads within the table for every row) */
+    double p = 0.0;
+    for (int j = 10; j >= 2; --j) p = AVPG_FMA(p, xx, j <= deg ? cf[j] : 0.0);
+    p = AVPG_FMA(p, xx * xx, csq);
+    *tail = tl;
+    return AVPG_FMA(xx, k1, p);
 }
 /* sqrt branch shared by asin and acos for 31/32 <= |x| < 1: z = (1 - |x|)/2; c ~ sqrt(z) by the inroot /
  * powtwo seed and one polynomial + one Newton step; returns through pointers */
@@ -382,18 +457,19 @@ AVP_GLIBC_FN double avpg_tan_mcot(double a, double t2)
     const double s = c + dc;
     return -(((c - s) + dc) + s);
 }
-/* utan.tbl branch: ya + yya in (0.0608, pi/4], n = parity of the quadrant, sy = sign */
+/* utan.tbl branch: ya + yya in (0.0608, pi/4], n = parity of the quadrant, sy = sign. tan: fi + num/(gi - s), -cot:
+ * gi - num/(s + fi) -- one division on selected operands, so that lanes in even and odd quadrants share the stream. */
 AVP_GLIBC_FN double avpg_tan_table(double ya, double yya, int n, double sy)
 {
     const int i = (int)AVPG_FMA(256.0, ya, -15.5);
     const uint64_t* row = AVP_G_XFG + 4 * i;
-    const double z = (ya - AVPG_T(row, 0)) + yya;
+    const double x0 = AVPG_T(row, 0), fi = AVPG_T(row, 1), gi = AVPG_T(row, 2);
+    const double z = (ya - x0) + yya;
     const double z2 = z * z;
     const double s = AVPG_FMA(z * z2, AVPG_FMA(z2, 0x1.11112e0a6b45fp-3 /* e1 */, 0x1.5555555554dbdp-2 /* e0 */), z);
-    const double fi = AVPG_T(row, 1), gi = AVPG_T(row, 2);
     const double num = (fi + gi) * s;
-    if (n) return (gi - num / (s + fi)) * -sy;
-    return (num / (gi - s) + fi) * sy;
+    const double q = num / (n ? s + fi : gi - s);
+    return n ? (gi - q) * -sy : (q + fi) * sy;
 }
 /* common tail of the reduced ranges: a + da = x - n pi/2 */
 AVP_GLIBC_FN double avpg_tan_reduced(double a, double da, int n)
@@ -425,15 +501,8 @@ AVP_GLIBC_FN int avpg_tan_try(double x, double* res)
         *res = AVPG_FMA(x * x2, avpg_tan_poly(x2), x);
         return 1;
     }
-    if (w <= g3) {
-        const int i = (int)AVPG_FMA(256.0, w, -15.5);
-        const uint64_t* row = AVP_G_XFG + 4 * i;
-        const double sy = x < 0.0 ? -1.0 : 1.0;
-        const double z = w - AVPG_T(row, 0);
-        const double z2 = z * z;
-        const double s = AVPG_FMA(z * z2, AVPG_FMA(z2, 0x1.11112e0a6b45fp-3, 0x1.5555555554dbdp-2), z);
-        const double fi = AVPG_T(row, 1), gi = AVPG_T(row, 2);
-        *res = (((fi + gi) * s) / (gi - s) + fi) * sy;
+    if (w <= g3) {                                  /* (w - x_i) + 0.0 == w - x_i bit for bit: a difference is never -0.0 */
+        *res = avpg_tan_table(w, 0.0, 0, x < 0.0 ? -1.0 : 1.0);
         return 1;
     }
     if (w <= g4) {
@@ -489,26 +558,28 @@ AVP_GLIBC_FN double avpg_pow2(double x)
     const double z = avpg_from_bits(iz), kd = (double)k;
     const uint64_t* T = AVP_G_POWLOG_TAB + 4 * i;
     const double invc = AVPG_T(T, 0), logc = AVPG_T(T, 2), logctail = AVPG_T(T, 3);
-    const double ln2hi = AVPG_T(AVP_G_POWLOG_HEAD, 0), ln2lo = AVPG_T(AVP_G_POWLOG_HEAD, 1);
-#define AVPG_A(j) AVPG_T(AVP_G_POWLOG_HEAD, 2 + (j))
+    /* __pow_log_data: ln2hi, ln2lo and the polynomial A[0..6] (literals: the device keeps them in registers / as
+     * instruction constants instead of loading them; include/gen_glibc_tab.py checks them against the archive) */
+    const double ln2hi = 0x1.62e42fefa3800p-1, ln2lo = 0x1.ef35793c76730p-45;
+    const double A0 = -0x1p-1, A1 = -0x1.555555555556p-1, A2 = 0x1.0000000000006p-1, A3 = 0x1.999999959554ep-1,
+                 A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p+0, A6 = 0x1.0002b8b263fc3p+0;
     const double r = AVPG_FMA(z, invc, -1.0);
     const double t1 = AVPG_FMA(kd, ln2hi, logc);
     const double t2 = t1 + r;
     const double lo1 = AVPG_FMA(kd, ln2lo, logctail);
     const double lo2 = (t1 - t2) + r;
-    const double ar = AVPG_A(0) * r;
+    const double ar = A0 * r;
     const double ar2 = r * ar;
     const double ar3 = r * ar2;
     const double hi = t2 + ar2;
     const double lo3 = AVPG_FMA(ar, r, -ar2);
     const double lo4 = (t2 - hi) + ar2;
-    double q = AVPG_FMA(r, AVPG_A(6), AVPG_A(5));
-    q = AVPG_FMA(q, ar2, AVPG_FMA(AVPG_A(4), r, AVPG_A(3)));
-    q = AVPG_FMA(ar2, q, AVPG_FMA(AVPG_A(2), r, AVPG_A(1)));
+    double q = AVPG_FMA(r, A6, A5);
+    q = AVPG_FMA(q, ar2, AVPG_FMA(A4, r, A3));
+    q = AVPG_FMA(ar2, q, AVPG_FMA(A2, r, A1));
     const double lo = AVPG_FMA(ar3, q, ((lo1 + lo2) + lo3) + lo4);
     const double lhi = hi + lo;
     const double llo = (hi - lhi) + lo;
-#undef AVPG_A
     /* y * log x, y = 2 */
     const double ehi = 2.0 * lhi;
     const double elo = AVPG_FMA(2.0, llo, AVPG_FMA(lhi, 2.0, -ehi));
@@ -519,10 +590,10 @@ AVP_GLIBC_FN double avpg_pow2(double x)
         if (abstop >= 0x409u) return (avpg_bits(ehi) >> 63) ? 0x1p-767 * 0x1p-767 : 0x1p769 * 0x1p769;
         abstop = 0;
     }
-    const double invln2N = AVPG_T(AVP_G_EXP_HEAD, 0), shift = AVPG_T(AVP_G_EXP_HEAD, 1);
-    const double negln2hiN = AVPG_T(AVP_G_EXP_HEAD, 2), negln2loN = AVPG_T(AVP_G_EXP_HEAD, 3);
-    const double C2 = AVPG_T(AVP_G_EXP_HEAD, 4), C3 = AVPG_T(AVP_G_EXP_HEAD, 5);
-    const double C4 = AVPG_T(AVP_G_EXP_HEAD, 6), C5 = AVPG_T(AVP_G_EXP_HEAD, 7);
+    /* __exp_data: InvLn2N, Shift, NegLn2hiN, NegLn2loN, C2 .. C5 */
+    const double invln2N = 0x1.71547652b82fep+7, shift = 0x1.8p+52;
+    const double negln2hiN = -0x1.62e42fefa0000p-8, negln2loN = -0x1.cf79abc9e3b3ap-47;
+    const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
     double kd2 = AVPG_FMA(ehi, invln2N, shift);
     const uint64_t ki = avpg_bits(kd2);
     kd2 -= shift;
