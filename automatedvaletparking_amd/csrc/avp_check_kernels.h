@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void check_distance_naive_kernel(DevMap m, avp
 #define CHK_COLS 8             // map columns per broad-phase step
 #endif
 static_assert(CHK_QCAP >= 64 && (CHK_QCAP & (CHK_QCAP - 1)) == 0, "queue size: a power of two, at least one lane's column (64 rows)");
-#define CHK_FPN 22              // doubles of a Footprint that carry data (the two trailing pads are never read)
+#define CHK_FPN 22              // doubles of a FootprintFast (the check kernel's record) = leading doubles of a Footprint (the corridor kernel's)
 #define CHK_FPW 23              // LDS record stride in doubles: ODD, so that the same field of different poses' records falls into
                                 // different bank pairs (a stride of 24 doubles = 48 dwords puts every 4th record on the same banks:
                                 // rocprofv3 showed 47 % of the kernel's LDS cycles as bank conflicts in the narrow phase's gather)
@@ -72,6 +72,56 @@ __device__ __forceinline__ int wave_prefix_excl(int v, int lane, int& total)
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+// The two ends of a tile are CALLED functions on LDS addresses (round 4): inlined -- the narrow phase at each of the four
+// drain sites -- the kernel was one 256-VGPR body (167 in round 3, 373 spilled once the point test grew its division-free
+// first look). Now the set-up, the drain and the broad-phase loop each have their own register demand.
+template <bool STAGE> struct ChkTabs;
+template <> struct ChkTabs<true> { typedef AVP_LDS const double* D; typedef AVP_LDS const uint64_t* B; };
+template <> struct ChkTabs<false> { typedef const double* D; typedef const uint64_t* B; };
+
+// footprint of the lane's pose -> its LDS record (a FootprintFast); returns ixlo | ixhi << 16 | iylo << 32 | iyhi << 48
+// (node ranges under the AABB, 16 bits each: nx, ny <= 8191), or an empty column range for an invalid lane
+template <bool STAGE>
+__device__ __noinline__ uint64_t chk_setup(avp_params const* pp, double x, double y, double th, int valid, AVP_LDS double* rec,
+                                           typename ChkTabs<STAGE>::D sX, typename ChkTabs<STAGE>::D sY, int nx, int ny, double b0, double dx, double b2, double dy)
+{
+    Footprint f;
+    avp_footprint_setup(*pp, x, y, th, f);
+    double xmin, xmax, ymin, ymax;
+    avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
+    int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
+    if (valid) {
+        ixlo = avp_first_ge(sX, nx, b0, dx, xmin);
+        ixhi = avp_last_le(sX, nx, b0, dx, xmax);
+        iylo = avp_first_ge(sY, ny, b2, dy, ymin);
+        iyhi = avp_last_le(sY, ny, b2, dy, ymax);
+        if (iylo > iyhi) ixhi = ixlo - 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { rec[k] = f.cx[k]; rec[4 + k] = f.cy[k]; rec[8 + k] = f.k[k]; rec[12 + k] = f.b[k]; rec[16 + k] = f.rden[k]; }
+    rec[20] = f.wthr; rec[21] = f.lthr;
+    return (uint64_t)(uint16_t)ixlo | ((uint64_t)(uint16_t)ixhi << 16) | ((uint64_t)(uint16_t)iylo << 32) | ((uint64_t)(uint16_t)iyhi << 48);
+}
+
+// narrow phase over the wave's queue: one lane = one (pose, point) candidate, the pose's record gathered from LDS
+template <bool STAGE>
+__device__ __noinline__ void chk_drain(AVP_LDS const double* sFp, AVP_LDS const uint32_t* sQ, AVP_LDS volatile uint8_t* sHit, int qtail,
+                                       typename ChkTabs<STAGE>::D sX, typename ChkTabs<STAGE>::D sY)
+{
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < qtail; base += 64) {
+        const int e = base + lane;
+        if (e < qtail) {
+            const uint32_t ent = sQ[e];
+            const int pl = ent >> 26, ix = (ent >> 13) & 0x1fff, iy = ent & 0x1fff;
+            if (!sHit[pl]) {
+                const AVP_LDS FootprintFast* f = (const AVP_LDS FootprintFast*)(sFp + (size_t)pl * CHK_FPW);
+                if (avp_footprint_point_hit(*f, sX[ix], sY[iy])) sHit[pl] = 1;
+            }
+        }
+    }
+}
+
 template <bool STAGE>
 __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m, avp_params p,
                                                                         const double* __restrict__ x,
@@ -81,51 +131,40 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
 {
     avp_lds_tables_fill<false>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve: [bitmap words][X][Y][per-wave: footprints 64*24 doubles | queue | hit flags]
+    __shared__ avp_params sP;                       // the called set-up reads the vehicle constants here
+    // carve: [bitmap words][X][Y][per-wave: footprint records 64 * CHK_FPW doubles | queue | hit flags]
     // STAGE: map tables live in LDS; otherwise (map too large for 160 KB) they are read through L1/L2
     uint64_t* lBits = (uint64_t*)smem;
     double* lX = (double*)(lBits + (STAGE ? (size_t)m.nx * m.wpc : 0));
     double* lY = lX + (STAGE ? m.nx : 0);
     double* sWave = lY + (STAGE ? m.ny : 0);
-    const uint64_t* sBits = STAGE ? lBits : m.colBits;
-    const double* sX = STAGE ? lX : m.X;
-    const double* sY = STAGE ? lY : m.Y;
+    typedef typename ChkTabs<STAGE>::D TD;
+    typedef typename ChkTabs<STAGE>::B TB;
+    TB sBits; TD sX, sY;
+    if constexpr (STAGE) { sBits = (TB)lBits; sX = (TD)lX; sY = (TD)lY; } else { sBits = m.colBits; sX = m.X; sY = m.Y; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t perWave = 64 * CHK_FPW + CHK_QCAP / 2 + 8;   // in doubles
-    double* sFp = sWave + (size_t)wave * perWave;
-    uint32_t* sQ = (uint32_t*)(sFp + 64 * CHK_FPW);
-    volatile uint8_t* sHit = (volatile uint8_t*)(sQ + CHK_QCAP);
+    AVP_LDS double* sFp = (AVP_LDS double*)(sWave + (size_t)wave * perWave);
+    AVP_LDS uint32_t* sQ = (AVP_LDS uint32_t*)(sFp + 64 * CHK_FPW);
+    AVP_LDS volatile uint8_t* sHit = (AVP_LDS volatile uint8_t*)(sQ + CHK_QCAP);
 
+    if (threadIdx.x == 0) sP = p;
     if (STAGE) {
         for (int i = threadIdx.x; i < m.nx * m.wpc; i += blockDim.x) lBits[i] = m.colBits[i];
         for (int i = threadIdx.x; i < m.nx; i += blockDim.x) lX[i] = m.X[i];
         for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
-        __syncthreads();
     }
+    __syncthreads();
 
     const int64_t tiles = (n + 63) / 64;
     const int nwaves = (int)(blockDim.x >> 6);
+    const int wpc = m.wpc;
     for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < tiles; tile += (int64_t)gridDim.x * nwaves) {
         const int64_t i = tile * 64 + lane;
         const bool valid = i < n;
-        int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
-        {
-            Footprint f;
-            avp_footprint_setup(p, valid ? x[i] : 0.0, valid ? y[i] : 0.0, valid ? th[i] : 0.0, f);
-            double xmin, xmax, ymin, ymax;
-            avp_footprint_aabb(f, xmin, xmax, ymin, ymax);
-            if (valid) {
-                ixlo = avp_first_ge(sX, m.nx, m.b0, m.dx, xmin);
-                ixhi = avp_last_le(sX, m.nx, m.b0, m.dx, xmax);
-                iylo = avp_first_ge(sY, m.ny, m.b2, m.dy, ymin);
-                iyhi = avp_last_le(sY, m.ny, m.b2, m.dy, ymax);
-                if (iylo > iyhi) ixhi = ixlo - 1;
-            }
-            const double* src = (const double*)&f;
-            double* dst = sFp + (size_t)lane * CHK_FPW;
-#pragma unroll
-            for (int k = 0; k < CHK_FPN; k++) dst[k] = src[k];
-        }
+        const uint64_t rg = chk_setup<STAGE>(&sP, valid ? x[i] : 0.0, valid ? y[i] : 0.0, valid ? th[i] : 0.0, valid ? 1 : 0,
+                                             sFp + (size_t)lane * CHK_FPW, sX, sY, m.nx, m.ny, m.b0, m.dx, m.b2, m.dy);
+        const int ixlo = (int16_t)(rg & 0xffff), ixhi = (int16_t)((rg >> 16) & 0xffff), iylo = (int16_t)((rg >> 32) & 0xffff), iyhi = (int16_t)(rg >> 48);
         sHit[lane] = 0;
         wave_sync();
         int ncol = ixhi - ixlo + 1;
@@ -138,17 +177,7 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
 
         auto drain = [&]() {
             wave_sync();
-            for (int base = 0; base < qtail; base += 64) {
-                const int e = base + lane;
-                if (e < qtail) {
-                    const uint32_t ent = sQ[e];
-                    const int pl = ent >> 26, ix = (ent >> 13) & 0x1fff, iy = ent & 0x1fff;
-                    if (!sHit[pl]) {
-                        const Footprint* f = (const Footprint*)(sFp + (size_t)pl * CHK_FPW);
-                        if (avp_footprint_point_hit(*f, sX[ix], sY[iy])) sHit[pl] = 1;
-                    }
-                }
-            }
+            chk_drain<STAGE>(sFp, sQ, sHit, qtail, sX, sY);
             qtail = 0;
             wave_sync();
         };
@@ -165,7 +194,7 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
                 uint64_t bits0 = 0, bits1 = 0;
                 const int c = c0 + k;
                 if (c < ncol && live) {
-                    const uint64_t* col = sBits + (size_t)(ixlo + c) * m.wpc;
+                    const TB col = sBits + (size_t)(ixlo + c) * wpc;
                     bits0 = col[w0];
                     // mask rows below iylo and above iyhi
                     bits0 &= ~0ull << (iylo & 63);

@@ -6,6 +6,8 @@
 #include "avp_math.h"
 #include "../../include/avp_libm.h"
 
+#define AVP_LDS __attribute__((address_space(3)))     // pointers the called phases take: LDS addresses, 32 bits each
+
 // static LDS taken by the trig tables in every kernel that evaluates trig
 #define AVP_LDS_TABLE_BYTES (sizeof(AVP_SINCOS_TAB) + 1024)   /* + the Reeds-Shepp word tables (avp_rs_kernels.h) */
 
@@ -66,17 +68,27 @@ struct DevMap {
 };
 
 // Inflated vehicle rectangle prepared for distance_checker.check (collision_check.py:144-195).
-// 24 doubles = 192 bytes (one LDS record).
+// 26 doubles = 208 bytes. rden[i] = 1 / den[i] serves the division-free first look of avp_footprint_point_hit.
 struct Footprint {
     double cx[4], cy[4];      // rr, rf, lf, lr (map/costmap.py:106-113)
     double k[4], b[4], den[4];
     double wthr, lthr;        // v_lb - 0.01, v_length - 0.01
-    double pad0, pad1;
+    double rden[4];
+};
+// The 22 doubles the point test reads on its fast path (the check kernel's LDS record: den is recomputed from k on the
+// rare exact path, sqrt(1 + k*k) being the expression that produced it).
+struct FootprintFast {
+    double cx[4], cy[4];
+    double k[4], b[4], rden[4];
+    double wthr, lthr;
 };
 
 // Footprint corners: world = R(theta).local + (x, y), the 2x2 product rounded the way the
 // reference's BLAS call rounds it: acc = a0*b0; acc = fma(a1, b1, acc)  (numerics).
 // (the parameter block is any struct with the members fp_xr, fp_xf, fp_yr, fp_yl: avp_params or the planner's LDS copy)
+// 1 / den for the first look of the point test; NaN (= "always take the exact path") for a subnormal slope, where the
+// equality filter's relative bound does not hold (never seen: a slope is a quotient of metre-sized differences)
+AVP_HD double avp_footprint_rden(double k, double den) { return (k != 0.0 && fabs(k) < 0x1p-1000) ? NAN : 1.0 / den; }
 template <class P>
 AVP_HD void avp_footprint_setup_cs(const P& p, double x, double y, double cs, double sn, Footprint& f)
 {
@@ -97,8 +109,8 @@ AVP_HD void avp_footprint_setup_cs(const P& p, double x, double y, double cs, do
         f.k[i] = (f.cy[j] - f.cy[i]) / (f.cx[j] - f.cx[i]);   // +-inf / NaN when axis aligned, as numpy
         f.b[i] = f.cy[i] - f.k[i] * f.cx[i];
         f.den[i] = sqrt(1 + f.k[i] * f.k[i]);
+        f.rden[i] = avp_footprint_rden(f.k[i], f.den[i]);
     }
-    f.pad0 = f.pad1 = 0.0;
 }
 AVP_HD void avp_footprint_setup(const avp_params& p, double x, double y, double th, Footprint& f)
 {
@@ -120,13 +132,14 @@ AVP_HD void avp_footprint_aabb(const Footprint& f, double& xmin, double& xmax, d
     }
 }
 
-// One obstacle point against the rectangle (collision_check.py:197-238): inside test by
-// point-line distances, exact corner test, exact edge-slope test.
-AVP_HD bool avp_footprint_point_hit(const Footprint& f, double px, double py)
+// One obstacle point against the rectangle (collision_check.py:197-238): inside test by point-line distances, exact
+// corner test, exact edge-slope test -- the reference's booleans, eight IEEE divisions per point.
+template <class F>
+AVP_HD bool avp_footprint_point_hit_exact(const F& f, double px, double py)
 {
     double d[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) d[i] = fabs(f.k[i] * px + f.b[i] - py) / f.den[i];
+    for (int i = 0; i < 4; i++) d[i] = fabs(f.k[i] * px + f.b[i] - py) / sqrt(1 + f.k[i] * f.k[i]);   // (= / den[i], same expression)
     const bool c1 = fabs(d[0] - d[2]) < f.wthr;
     const bool c2 = fabs(d[1] - d[3]) < f.lthr;
     if (c1 && c2) return true;
@@ -141,6 +154,39 @@ AVP_HD bool avp_footprint_point_hit(const Footprint& f, double px, double py)
         edge |= (k1 == f.k[i]);
     }
     return edge;
+}
+// The same booleans without a division in all but ~1 point in 1e12. The divisions only feed COMPARISONS, so a first look
+// with bounded error settles them unless an operand sits within that bound of its threshold:
+//  * distances: n_i * rden_i instead of n_i / den_i differs from the reference's quotient by <= 3.01 u d_i (u = 2^-53:
+//    rden and the product round once each, the quotient once), so |d0 - d2| moves by <= 5.1 u (d0 + d2); the test
+//    against wthr is settled when it misses wthr by more than 32 u (d0 + d2 + wthr) -- likewise d1, d3, lthr;
+//  * slopes: fl(a / c) == k needs |k c - a| <= u |k c| (1 + u); fma(k, c, -a) rounds once, so |fma| > 8 u |fl(k c)| rules
+//    equality out (k = 0: fma = -a exactly; k subnormal: rden is NaN by avp_footprint_rden; inf / NaN make every
+//    comparison below false, which means "not settled").
+// Anything not settled -- including every point of an axis-aligned pose, whose slopes are +-inf -- takes the exact form.
+#ifndef AVP_POINT_FAST
+#define AVP_POINT_FAST 1          // 0: every point takes the exact form (A/B builds: make variant DEFS=-DAVP_POINT_FAST=0)
+#endif
+template <class F>
+AVP_HD bool avp_footprint_point_hit(const F& f, double px, double py)
+{
+    if (!AVP_POINT_FAST) return avp_footprint_point_hit_exact(f, px, py);
+    double q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = fabs(f.k[i] * px + f.b[i] - py) * f.rden[i];
+    const double D02 = fabs(q[0] - q[2]), D13 = fabs(q[1] - q[3]);
+    bool settled = fabs(D02 - f.wthr) > (q[0] + q[2] + f.wthr) * 0x1p-48 && fabs(D13 - f.lthr) > (q[1] + q[3] + f.lthr) * 0x1p-48;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double c = f.cx[i] - px;
+        settled = settled && fabs(AVP_FMA(f.k[i], c, -(f.cy[i] - py))) > fabs(f.k[i] * c) * 0x1p-50;
+    }
+    if (!settled) return avp_footprint_point_hit_exact(f, px, py);
+    if (D02 < f.wthr && D13 < f.lthr) return true;
+    bool on_x = false, on_y = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { on_x |= (px == f.cx[i]); on_y |= (py == f.cy[i]); }
+    return on_x && on_y;
 }
 
 // (the index searches avp_first_ge / avp_last_le / avp_first_gt / avp_last_lt / avp_node_search live in avp_math.h)

@@ -259,7 +259,6 @@ __device__ __forceinline__ unsigned long long pl_look_key3(int64_t pid, double g
 // ---- what a collision pass reads of the map and the vehicle: one copy per workgroup in LDS ------------
 // The passes are CALLED functions (pl_check_pass below): everything they need travels as three LDS addresses, so no
 // kernel argument has to be handed through registers or the stack, and their register demand is their own.
-#define AVP_LDS __attribute__((address_space(3)))
 // register budget of plan_wave_kernel and of the functions it calls (the attribute propagates): 512 / PW_WAVES_PER_EU per lane
 #ifndef PW_WAVES_PER_EU
 #define PW_WAVES_PER_EU 4
@@ -1288,7 +1287,7 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
                 else if (sub == 4) { u = cx[0] - cx[3]; v = cy[0] - cy[3]; }
                 else { u = cx[3] - cx[2]; v = cy[3] - cy[2]; }
                 const double r = sqrt(u * u + v * v);
-                if (sub < 4) { f.cx[sub] = x1; f.cy[sub] = y1; f.k[sub] = k; f.b[sub] = y1 - k * x1; f.den[sub] = r; }
+                if (sub < 4) { f.cx[sub] = x1; f.cy[sub] = y1; f.k[sub] = k; f.b[sub] = y1 - k * x1; f.den[sub] = r; f.rden[sub] = avp_footprint_rden(k, r); }
                 else if (sub == 4) f.wthr = r - 0.01;
                 else f.lthr = r - 0.01;
             }

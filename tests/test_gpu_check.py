@@ -116,3 +116,43 @@ def test_synthetic_polygon_map_c4(vehicle, cfg):
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), g["c4_dist"])
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), g["c4_dist"])
     assert np.array_equal(dm.check_batch(poses, kind=1), g["c4_circ"])
+
+
+def test_points_on_the_thresholds_vs_oracle(vehicle, cfg):
+    """avp_footprint_point_hit settles its comparisons without divisions unless an operand is within its error bound of the
+    threshold (csrc/avp_device.h). Here the obstacle points are PUT on the thresholds: poses built so that a map point
+    falls (to within rounding) on a footprint corner, on an edge line, or 5 mm inside an edge -- where |d0 - d2| meets
+    v_lb - 0.01 (collision_check.py:214-221) -- plus the same families nudged by 1e-13 .. 1e-9 m. Booleans == oracle."""
+    from oracle import oracle
+    m = case_map_from_gold(1)
+    dm = _dm(m, vehicle, cfg)
+    o = oracle.Oracle(m, vehicle, cfg)
+    pr = _native_params(dm)
+    xr, xf, yr, yl = pr
+    pk = m.pack()
+    ox, oy = np.asarray(pk["obs_x"]), np.asarray(pk["obs_y"])
+    rng = np.random.default_rng(31)
+    n = 60_000
+    j = rng.integers(0, len(ox), n)
+    th = rng.uniform(-np.pi, np.pi, n)
+    th[:3000] = rng.choice([0.0, np.pi / 2, -np.pi / 2, np.pi, 1e-9, np.pi / 4], 3000)
+    fam = rng.integers(0, 7, n)
+    t = rng.uniform(0, 1, n)
+    lx = np.select([fam == 0, fam == 1, fam == 2, fam == 3, fam == 4, fam == 5, fam == 6],
+                   [np.where(t < 0.5, xr, xf), xr + t * (xf - xr), xr + t * (xf - xr), np.full(n, xf), xr + t * (xf - xr), np.full(n, xr + 0.005), np.full(n, xf - 0.005)])
+    ly = np.select([fam == 0, fam == 1, fam == 2, fam == 3, fam == 4, fam == 5, fam == 6],
+                   [np.where(rng.uniform(0, 1, n) < 0.5, yr, yl), np.full(n, yr), np.full(n, yr + 0.005), yr + t * (yl - yr), np.full(n, yl - 0.005), yr + t * (yl - yr), yr + t * (yl - yr)])
+    nudge = np.where(rng.uniform(0, 1, n) < 0.5, 0.0, 10.0 ** rng.uniform(-13, -9, n) * rng.choice([-1, 1], n))
+    ly = ly + nudge
+    cs, sn = np.cos(th), np.sin(th)
+    poses = np.stack([ox[j] - (cs * lx - sn * ly), oy[j] - (sn * lx + cs * ly), th], 1)
+    want = o.check_batch(poses, kind=0)
+    assert 0.05 < want.mean() < 0.999
+    assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), want)
+    assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), want)
+
+
+def _native_params(dm):
+    """fp_xr, fp_xf, fp_yr, fp_yl of the inflated rectangle (map/costmap.py:85-121 with the config's safety margins)."""
+    p = dm.params
+    return float(p.fp_xr), float(p.fp_xf), float(p.fp_yr), float(p.fp_yl)
