@@ -6,6 +6,13 @@ read-only. The only exchanges are
   * one broadcast of the packed map blob from rank 0 (KB..MB, latency bound), and
   * one gather of fixed-stride result records + way-points to rank 0 per batch.
 There is no all-reduce and no per-step collective inside the search.
+
+Two ways to run a batch over N ranks (bench.py --gpus N):
+  * `plan_weak`      every rank plans its own block of a world x per problem set, ONE gather to rank 0 at the end of the
+                     step: no collective between the launches, per-GPU work fixed as N grows (weak scaling, throughput);
+  * `two_stage_plan` one fixed problem set split over the ranks (strong scaling): a first stage on the index slice, the
+                     records all-gathered (every rank must know which searches are still running), those dealt evenly,
+                     planned, gathered; the way-points travel to rank 0 only.
 """
 from __future__ import annotations
 
@@ -176,12 +183,52 @@ def deal_slice(n: int, rank: int, world: int):
     return np.concatenate([idx, -np.ones(per - len(idx), np.int64)]), per
 
 
+PAD_POSE = (0.0, 0.0, 0.0)         # padding problem: start == goal, ends at once with status RS_ERROR (rs_curve.py:153)
+
+
 def take_padded(starts, goals, idx):
-    """Problems idx (−1 = padding: a start == goal problem, which ends at once with status RS_ERROR)."""
-    safe = np.where(idx >= 0, idx, 0)
-    s_l, g_l = np.array(starts[safe], dtype=np.float64), np.array(goals[safe], dtype=np.float64)
-    s_l[idx < 0] = g_l[idx < 0] = goals[0]
+    """Problems idx (-1 = padding: a start == goal problem, which ends at once with status RS_ERROR)."""
+    idx = np.asarray(idx, dtype=np.int64)
+    s_l = np.tile(np.array(PAD_POSE, dtype=np.float64), (len(idx), 1))
+    g_l = s_l.copy()
+    keep = idx >= 0
+    if keep.any():
+        s_l[keep], g_l[keep] = np.asarray(starts, dtype=np.float64)[idx[keep]], np.asarray(goals, dtype=np.float64)[idx[keep]]
     return np.ascontiguousarray(s_l), np.ascontiguousarray(g_l)
+
+
+def gather_rows(local, dst: int = 0):
+    """Gather equally shaped row blocks (any dtype) to rank dst: (world, *local.shape) there, None elsewhere. One
+    point-to-point-per-rank collective (RCCL gather); no rank but dst receives anything."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local.unsqueeze(0)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    local = local.contiguous()
+    if rank == dst:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(local, list(out.unbind(0)), dst=dst)
+        return out
+    dist.gather(local, None, dst=dst)
+    return None
+
+
+def plan_weak(plan_block, starts, goals, rank: int, world: int, dst: int = 0):
+    """Weak-scaling step: the GLOBAL set holds world x per problems, rank r plans the contiguous block
+    [r * per, (r + 1) * per) with plan_block(starts (per,3), goals (per,3)) -> (records (per, stride) uint8 tensor,
+    paths (per, max_path, 4) float64 tensor) and the blocks are gathered to rank dst. No other collective.
+    Returns (records (n, stride), paths (n, max_path, 4)) in problem order on dst, (None, None) elsewhere."""
+    starts = np.asarray(starts, dtype=np.float64).reshape(-1, 3)
+    goals = np.asarray(goals, dtype=np.float64).reshape(-1, 3)
+    n = len(starts)
+    assert n % world == 0, "the weak-scaling set holds the same number of problems for every rank"
+    per = n // world
+    r, p = plan_block(starts[rank * per:(rank + 1) * per], goals[rank * per:(rank + 1) * per])
+    gr, gp = gather_rows(r, dst), gather_rows(p, dst)
+    if gr is None:
+        return None, None
+    return gr.reshape((n,) + tuple(r.shape[1:])), gp.reshape((n,) + tuple(p.shape[1:]))
 
 
 def gathered_in_list_order(g, count: int):
@@ -195,19 +242,28 @@ def record_status(rec_t):
     return rec_t[:, :4].contiguous().view(torch.int32).reshape(-1)
 
 
-def two_stage_plan(stage1, stage2, starts, goals, rank: int, world: int):
+def two_stage_plan(stage1, stage2, starts, goals, rank: int, world: int, paths_to: Optional[int] = None):
     """One step of the two-stage deal. stage1 / stage2: callables (starts (k,3), goals (k,3)) -> (records (k, stride)
     uint8 tensor, paths (k, max_path, 4) float64 tensor) on the communication device; stage1 leaves the searches it does
-    not finish with status DEFERRED. Returns (records (n, stride), paths (n, max_path, 4), deferred indices (numpy)) on
-    every rank, in problem order."""
+    not finish with status DEFERRED (AVP_PLAN_DEFERRED; the library uses the same value for a search the wave form
+    cannot hold at all, which is dealt like a long one). The records are all-gathered after each stage -- every rank
+    needs the statuses to deal the second stage --; the way-points (max_path x 4 doubles per problem, 98 % of the
+    payload) are all-gathered too when paths_to is None, and GATHERED to that rank alone otherwise. Returns
+    (records (n, stride), paths (n, max_path, 4) or None on a rank that did not receive them, deferred indices (numpy)),
+    in problem order. An empty problem list returns at once, without a collective (every rank sees the same n)."""
     import torch
     starts = np.asarray(starts, dtype=np.float64).reshape(-1, 3)
     goals = np.asarray(goals, dtype=np.float64).reshape(-1, 3)
     n = len(starts)
+    if n == 0:
+        r0, p0 = stage1(starts, goals)
+        return r0, p0, np.zeros(0, np.int64)
+    collect = (lambda t: all_gather_rows(t)) if paths_to is None else (lambda t: gather_rows(t, paths_to))
     idx1, _ = deal_slice(n, rank, world)
     r1, p1 = stage1(*take_padded(starts, goals, idx1))
     rec = gathered_in_list_order(all_gather_rows(r1), n).contiguous()
-    paths = gathered_in_list_order(all_gather_rows(p1), n).contiguous()
+    gp = collect(p1)
+    paths = gathered_in_list_order(gp, n).contiguous() if gp is not None else None
     deferred_t = (record_status(rec) == DEFERRED).nonzero().reshape(-1)
     deferred = deferred_t.cpu().numpy()                       # (the one host synchronisation of the step: stage 2's shape)
     nd = len(deferred)
@@ -216,7 +272,9 @@ def two_stage_plan(stage1, stage2, starts, goals, rank: int, world: int):
         share = np.where(idx2 >= 0, deferred[np.where(idx2 >= 0, idx2, 0)], -1)
         r2, p2 = stage2(*take_padded(starts, goals, share))
         rec.index_copy_(0, deferred_t, gathered_in_list_order(all_gather_rows(r2), nd))
-        paths.index_copy_(0, deferred_t, gathered_in_list_order(all_gather_rows(p2), nd))
+        gp2 = collect(p2)
+        if gp2 is not None:
+            paths.index_copy_(0, deferred_t, gathered_in_list_order(gp2, nd))
     return rec, paths, deferred
 
 

@@ -9,13 +9,18 @@ A "step" = one pass of the hot path over one batch of problems, inputs resident 
           128), `c5` (dense clutter, RS shot at every pop), `saturating_batch`, `cap_sweep`, `cases20` (the 20
           BenchmarkCases' own problems, run to termination), `single_plan_latency_ms`, the footprint kernel alone, and
           the CPU port timed on the host.
-  N > 1 : SURVEY 8(e), strong scaling of the SAME 4 096-problem set on the Case1 map: rank 0 samples the problems, the
-          map blob and the problems are broadcast (RCCL, untimed set-up), and the timed step is the two-stage deal of
-          automatedvaletparking_amd.distributed.two_stage_plan -- every rank runs the first stage (wave form, 16 pops) on
-          its index slice, one all-gather of the records and paths, the searches still running are dealt round-robin
-          (they are the long ones), planned, and all-gathered: the only data-path collectives. After the timed steps
-          rank 0 plans the whole set alone, timed: `speedup_vs_1gpu`, `parallel_efficiency`, and the shard-invariance
-          check (`shard_invariant`). AVP_BENCH_FORCE_DIST=1 runs exactly this code path with world size 1 (through RCCL).
+  N > 1 : SURVEY 8(e), WEAK scaling (the default): the global set holds N x 256 problems on the Case1 map -- config[1]'s
+          sampler and seed, so that N = 1 is the headline set --, rank 0 samples them, the map blob and the problems are
+          broadcast (RCCL, untimed set-up), every rank plans its own block of 256 exactly as the N = 1 headline does, and
+          ONE gather of the records and way-points to rank 0 closes the timed step
+          (automatedvaletparking_amd.distributed.plan_weak): no collective between the launches, per-GPU work fixed.
+          Rank 0 then plans the whole set alone and checks that the gathered result is identical (`shard_invariant`).
+          Two more points ride on the line (`strong_scaling_4096`, `throughput`): the fixed 4 096-problem set split over
+          the ranks by the two-stage deal (distributed.two_stage_plan: first stage on the index slice, records
+          all-gathered, the searches still running dealt evenly, way-points gathered to rank 0; with the in-run 1-GPU
+          time, `speedup_vs_1gpu`), and N x 16 384 problems, one time-sliced launch per rank, one gather -- the
+          saturated regime. `--workload batch4096` makes the strong-scaling set the headline instead.
+          AVP_BENCH_FORCE_DIST=1 runs exactly these code paths with world size 1 (through RCCL).
   --workload c3 with N > 1: every rank holds all 20 maps, each map's 128 problems are dealt by index slice.
 
 `value` counts COMPLETED searches only (status OK / NO_PATH); problems stopped by the pop cap (ITER_LIMIT; the reference
@@ -190,7 +195,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    workload = a.workload if a.workload != "auto" else ("batch4096" if use_dist else "c2")
+    workload = a.workload if a.workload != "auto" else "c2"
+    weak = use_dist and workload in ("c2", "c5")          # N > 1: every rank its own block (weak scaling); else the two-stage deal of one set
 
     cfg = config.default_config()
     veh = costmap.Vehicle()
@@ -202,9 +208,10 @@ def main():
     def build(name):
         """-> (label, cfg, cap, [(Map, starts, goals)]) (automatedvaletparking_amd/workloads.py holds the definitions)."""
         if name in ("c2", "batch4096"):
-            n = 256 if name == "c2" else 4096
+            n = 256 * (world if use_dist else 1) if name == "c2" else 4096
             m, st, go = workloads.case1_pairs(cfg, checker(POP_CAP), n)
-            label = ("Case1 map, 256 random start/goal pairs (config[1]), pop cap 1000" if name == "c2" else
+            label = (("Case1 map, 256 random start/goal pairs (config[1]), pop cap 1000" if n == 256 else
+                      "Case1 map, %d x 256 random start/goal pairs (config[1]'s sampler; a block of 256 per rank), pop cap 1000" % world) if name == "c2" else
                      "Case1 map, 4096 random start/goal pairs (north_star target batch), pop cap 1000")
             return label, cfg, POP_CAP, [(m, st, go)]
         if name == "c3":
@@ -247,28 +254,116 @@ def main():
         return (time.perf_counter() - t0) / reps, o
 
     # ---- headline -----------------------------------------------------------------------------------------------------
-    label, wcfg, cap, sets = build(workload) if rank == 0 else (None, None, None, None)
-    if use_dist:
-        meta = [label, wcfg, cap, len(sets) if rank == 0 else 0]
+    def bcast_sets(bundle):
+        """rank 0's (label, cfg, cap, [(Map, starts, goals)]) on every rank: RCCL broadcasts of the packed costmaps and of
+        the problem sets (untimed set-up)."""
+        if not use_dist:
+            return bundle
+        lab_, cfg_, cap_, sets_ = bundle if rank == 0 else (None, None, None, None)
+        meta = [lab_, cfg_, cap_, len(sets_) if rank == 0 else 0]
         dist.broadcast_object_list(meta, src=0)
-        label, wcfg, cap, nsets = meta
-        groups_full = []
+        lab_, cfg_, cap_, nsets = meta
+        full = []
         for g in range(nsets):
-            m = avd.broadcast_map(sets[g][0] if rank == 0 else None, src=0)          # RCCL broadcast of the packed costmap
-            prob = torch.as_tensor(np.concatenate([sets[g][1], sets[g][2]], 1), device=dev) if rank == 0 else None
-            nprob = torch.tensor([len(sets[g][1]) if rank == 0 else 0], dtype=torch.int64, device=dev)
+            m = avd.broadcast_map(sets_[g][0] if rank == 0 else None, src=0)         # RCCL broadcast of the packed costmap
+            prob = torch.as_tensor(np.concatenate([sets_[g][1], sets_[g][2]], 1), device=dev) if rank == 0 else None
+            nprob = torch.tensor([len(sets_[g][1]) if rank == 0 else 0], dtype=torch.int64, device=dev)
             dist.broadcast(nprob, src=0)
             if rank != 0:
                 prob = torch.empty((int(nprob.item()), 6), dtype=torch.float64, device=dev)
-            dist.broadcast(prob, src=0)                                               # ... and of the problem set
+            dist.broadcast(prob, src=0)                                              # ... and of the problem set
             pr = prob.cpu().numpy()
-            groups_full.append((m, pr[:, :3].copy(), pr[:, 3:].copy()))
-    else:
-        groups_full = sets
+            full.append((m, pr[:, :3].copy(), pr[:, 3:].copy()))
+        return lab_, cfg_, cap_, full
 
     ev_k = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps + a.warmup)]
     ev_i = [0]
     extra_dist = {}
+
+    def run_weak(full, xcfg, xcap, steps, warmup, events=False, **group_kw):
+        """Weak-scaling steps over a world x per problem set (one map): this rank plans its contiguous block, one gather of
+        records + way-points to rank 0 inside the step. -> (elapsed, [records] and [paths] on rank 0, this rank's Group)."""
+        m, st, go = full[0]
+        per = len(st) // world
+        blk = slice(rank * per, (rank + 1) * per)
+        g = Group(m, veh, xcfg, st[blk], go[blk], local, xcap, **group_kw)
+
+        def step():
+            if events:
+                e0, e1 = ev_k[ev_i[0] % len(ev_k)]
+                ev_i[0] += 1
+                e0.record()
+            o = avd.plan_weak(lambda s_, g_: g.plan()[:2], st, go, rank, world, dst=0)
+            if events:
+                e1.record()
+            return o
+
+        el, (rec_t, path_t) = timed_steps(step, steps, warmup)
+        if rank != 0:
+            return el, None, None, g
+        return el, [rec_t.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)], [path_t.cpu().numpy()], g
+
+    def run_strong(full, xcfg, xcap, steps, warmup, events=False):
+        """Strong-scaling steps: every set of `full` split over the ranks by the two-stage deal (way-points to rank 0)."""
+        planners = []
+        for (m, st, go) in full:
+            dm = _native.DeviceMap(m, veh, xcfg, device=local, max_pops=xcap)
+            planners.append((dm, path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=path_planner.STAGED, stage_pops=STAGE_POPS), {}))
+
+        def two_stage(k):
+            dm, bp1, bp2 = planners[k]
+            m, st, go = full[k]
+
+            def stage1(s_l, g_l):
+                r, p, _ = bp1.plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True, first_stage_only=True)
+                return r, p
+
+            def stage2(s_l, g_l):
+                # every search of the second stage is a long one: the form whose slots hold them all at once
+                mode2 = path_planner.long_search_mode(dm, len(s_l))
+                if mode2 not in bp2:
+                    bp2[mode2] = path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=mode2)
+                r, p, _ = bp2[mode2].plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True)
+                return r, p
+
+            return avd.two_stage_plan(stage1, stage2, st, go, rank, world, paths_to=0)
+
+        def step():
+            if events:
+                e0, e1 = ev_k[ev_i[0] % len(ev_k)]
+                ev_i[0] += 1
+                e0.record()
+            o = [two_stage(k) for k in range(len(full))]
+            if events:
+                e1.record()
+            return o
+
+        el, o = timed_steps(step, steps, warmup)
+        return el, o, planners
+
+    def strong_point(full, xcfg, xcap, el, o):
+        """rank 0: the sharded result against the whole set planned on this GPU alone (staged call), timed."""
+        info, ok, t1, slots = {}, True, 0.0, []
+        recs_ = [rec_t.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1) for (rec_t, _, _) in o]
+        for k, (m, st, go) in enumerate(full):
+            ref = Group(m, veh, xcfg, st, go, local, xcap, mode=path_planner.STAGED)
+            sec, (r_res, r_paths, _) = time_group(ref, reps=2)
+            t1 += sec
+            ok &= same_results(recs_[k], o[k][1].cpu().numpy(), records(r_res, ref.n), r_paths.cpu().numpy())
+            slots.append(ref.slots * world)
+            if k == 0:
+                rr = records(r_res, ref.n)
+                info["deal_simulation"] = avd.simulate_deals(rr["n_pops"], rr["status"], st, go, STAGE_POPS)
+                info["deferred_after_stage1"] = int(len(o[k][2]))
+                info["deferred_note"] = "searches still running after the first stage's 16 pops, plus any the wave form cannot hold (same status value)"
+            del ref
+        assert ok, "sharded result differs from the single-GPU result"
+        info.update({"one_gpu_ms_per_step": t1 * 1e3, "speedup_vs_1gpu": t1 / el, "parallel_efficiency": t1 / el / world,
+                     "one_gpu_note": "the whole set planned by rank 0 alone (staged call) right after the timed steps, same process, same GPU"})
+        return info, ok, recs_, slots
+
+    # ---- headline -----------------------------------------------------------------------------------------------------
+    label, wcfg, cap, groups_full = bcast_sets(build(workload) if rank == 0 else None)
 
     if not use_dist:
         groups = [Group(m, veh, wcfg, st, go, local, cap) for (m, st, go) in groups_full]
@@ -285,68 +380,33 @@ def main():
         recs = [records(o[0], g.n) for o, g in zip(outs, groups)]
         shard_invariant = None
         slots_all = [g.slots for g in groups]
-    else:
-        # ---- the two-stage deal: stage 1 on the index slice, all-gather, the unfinished searches dealt evenly, all-gather --
-        planners = []
-        for (m, st, go) in groups_full:
-            dm = _native.DeviceMap(m, veh, wcfg, device=local, max_pops=cap)
-            planners.append((dm, path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=path_planner.STAGED, stage_pops=STAGE_POPS),
-                             {}))
-
-        def two_stage(k):
-            dm, bp1, bp2 = planners[k]
-            m, st, go = groups_full[k]
-
-            def stage1(s_l, g_l):
-                r, p, _ = bp1.plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True, first_stage_only=True)
-                return r, p
-
-            def stage2(s_l, g_l):
-                # every search of the second stage is a long one: the form whose slots hold them all at once
-                mode2 = path_planner.long_search_mode(dm, len(s_l))
-                if mode2 not in bp2:
-                    bp2[mode2] = path_planner.BatchPlanner(dm, max_nodes=MAX_NODES, max_path=MAX_PATH, mode=mode2)
-                r, p, _ = bp2[mode2].plan_dev(dm.dev_tensor(s_l), dm.dev_tensor(g_l), want_paths=True)
-                return r, p
-
-            return avd.two_stage_plan(stage1, stage2, st, go, rank, world)
-
-        def step():
-            e0, e1 = ev_k[ev_i[0] % len(ev_k)]
-            ev_i[0] += 1
-            e0.record()
-            out = [two_stage(k) for k in range(len(groups_full))]
-            e1.record()
-            return out
-
-        elapsed, out = timed_steps(step, a.steps, a.warmup)
-        recs, shard_invariant = [], None
-        slots_all = []
+    elif weak:
+        # ---- weak scaling: every rank its own block of the world x per set, one gather to rank 0 per step ----------------
+        elapsed, recs, paths_w, gw = run_weak(groups_full, wcfg, cap, a.steps, a.warmup, events=True)
+        groups = [gw]
+        shard_invariant = None
+        slots_all = [gw.slots * world]
         if rank == 0:
-            for (rec_t, path_t, deferred) in out:
-                recs.append(rec_t.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1))
-        # ---- the same set on rank 0's GPU alone (staged call), timed: the in-run single-GPU reference + shard invariance -----
-        t1 = None
-        if rank == 0:
-            shard_invariant = True
-            t1 = 0.0
-            for k, (m, st, go) in enumerate(groups_full):
-                ref = Group(m, veh, wcfg, st, go, local, cap, mode=path_planner.STAGED)
-                sec, (r_res, r_paths, _) = time_group(ref, reps=2)
-                t1 += sec
-                shard_invariant &= same_results(recs[k], out[k][1].cpu().numpy(), records(r_res, ref.n), r_paths.cpu().numpy())
-                slots_all.append(ref.slots * world)
-                if k == 0:
-                    rr = records(r_res, ref.n)
-                    extra_dist["deal_simulation"] = avd.simulate_deals(rr["n_pops"], rr["status"], st, go, STAGE_POPS)
-                    extra_dist["deferred_after_stage1"] = int(len(out[k][2]))
+            m, st, go = groups_full[0]
+            # this rank's block alone, without the gather (the N = 1 time of the same per-GPU work), and the whole set on this
+            # GPU alone: the gathered result must be identical
+            sec_blk, _ = time_group(gw, reps=3)
+            ref = Group(m, veh, wcfg, st, go, local, cap)
+            sec_all, (r_res, r_paths, _) = time_group(ref, reps=1)
+            shard_invariant = same_results(recs[0], paths_w[0], records(r_res, ref.n), r_paths.cpu().numpy())
             assert shard_invariant, "sharded result differs from the single-GPU result"
-            extra_dist["one_gpu_ms_per_step"] = t1 * 1e3
-            extra_dist["speedup_vs_1gpu"] = t1 / (elapsed / a.steps)
-            extra_dist["parallel_efficiency"] = t1 / (elapsed / a.steps) / world
-            extra_dist["one_gpu_note"] = "the whole set planned by rank 0 alone (staged call) right after the timed steps, same process, same GPU"
-        if use_dist:
-            dist.barrier()
+            extra_dist.update({"block_ms_without_gather": sec_blk * 1e3, "weak_scaling_efficiency_in_run": sec_blk / (elapsed / a.steps),
+                               "weak_scaling_note": "one rank's 256-problem block planned alone, no collective, over the time of a step with %d ranks and the gather" % world,
+                               "whole_set_on_one_gpu_ms": sec_all * 1e3})
+            del ref
+        dist.barrier()
+    else:
+        elapsed, out, planners = run_strong(groups_full, wcfg, cap, a.steps, a.warmup, events=True)
+        recs, shard_invariant, slots_all = [], None, []
+        if rank == 0:
+            info, shard_invariant, recs, slots_all = strong_point(groups_full, wcfg, cap, elapsed / a.steps, out)
+            extra_dist.update(info)
+        dist.barrier()
 
         class _G:          # what the report below reads of a group
             pass
@@ -355,6 +415,36 @@ def main():
             g = _G()
             g.dm, g.m, g.mode, g.bp, g.n = planners[k][0], m, path_planner.STAGED, planners[k][1], len(st)
             groups.append(g)
+
+    if use_dist and weak and not a.no_extras:
+        # ---- the two other points of the multi-GPU picture, on every rank (collectives inside) -----------------------------
+        b4 = bcast_sets(build("batch4096") if rank == 0 else None)
+        el4, o4, _ = run_strong(b4[3], b4[1], b4[2], 2, 1)
+        if rank == 0:
+            info, ok4, r4, sl4 = strong_point(b4[3], b4[1], b4[2], el4 / 2, o4)
+            x = summarize(r4, sl4, el4 / 2)
+            x.update(info)
+            x.update({"workload": b4[0], "scaling": "strong", "shard_invariant": ok4,
+                      "note": "the fixed 4 096-problem set split over the ranks by the two-stage deal (records all-gathered after each stage, way-points gathered to rank 0)"})
+            extra_dist["strong_scaling_4096"] = x
+        dist.barrier()
+        # N x 16 384 problems (the 4 096 starts against rotations of the goals), one time-sliced launch per rank, one gather
+        if rank == 0:
+            mm, st4, go4 = b4[3][0]
+            st16 = np.concatenate([st4] * (4 * world))
+            go16 = np.concatenate([np.roll(go4, 17 * k, axis=0) for k in range(4 * world)])
+            tb = ("Case1 map, %d x 16384 problems (the 4096 starts against rotations of the goals), pop cap 1000" % world, b4[1], b4[2], [(mm, st16, go16)])
+        else:
+            tb = None
+        tb = bcast_sets(tb)
+        elt, rt, _, gt = run_weak(tb[3], tb[1], tb[2], 2, 1)
+        if rank == 0:
+            x = summarize(rt, [gt.slots * world], elt / 2, time_sliced=bool(gt.bp.last_time_sliced))
+            x.update({"workload": tb[0], "scaling": "weak", "kernel_form": FORM_NAMES.get(gt.mode), "time_sliced": bool(gt.bp.last_time_sliced),
+                      "note": "every rank plans its own 16 384 problems in one launch (long searches time-sliced), records + way-points gathered to rank 0 at the end of the step"})
+            extra_dist["throughput"] = x
+        del gt
+        dist.barrier()
 
     if rank == 0:
         head = summarize(recs, slots_all, elapsed / a.steps, time_sliced=any(g.bp.last_time_sliced for g in groups))
@@ -408,12 +498,13 @@ def main():
         out = {
             "metric": "hybrid-A* plans/sec, batched poses", "value": head["plans_per_s"], "unit": "plans/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if use_dist else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if (use_dist and not weak) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "problems": head["problems"], "pop_cap": cap, "obstacle_points": P,
-                       "kernel_form": FORM_NAMES.get(groups[0].mode, str(groups[0].mode)) if not use_dist else
+                       "kernel_form": FORM_NAMES.get(groups[0].mode, str(groups[0].mode)) if (not use_dist or weak) else
                        "two-stage deal: wave form for %d pops on the index slice, the rest dealt evenly (library's choice of form)" % STAGE_POPS,
                        "expansion_lookahead": bool(groups[0].bp.last_lookahead),
-                       "parallelism": f"shard{world}" + (" (records + paths all-gathered after each stage, inside the timed step)" if use_dist else "")},
+                       "parallelism": f"shard{world}" + ((" (every rank plans its own block; records + way-points gathered to rank 0 inside the timed step)" if weak else
+                                                         " (records all-gathered after each stage, way-points gathered to rank 0, inside the timed step)") if use_dist else "")},
             "value_counts": "completed searches (status OK or NO_PATH); ITER_LIMIT problems are excluded",
             "all_problems_per_s": head["all_problems_per_s"], "expansions_per_s": head["expansions_per_s"],
             "solved_frac": head["solved_frac"], "iter_limit_frac": head["iter_limit_frac"],

@@ -95,23 +95,40 @@ def _worker(rank, world, port, q):
         return run
 
     rec2s, path2s, deferred = avd.two_stage_plan(stage(K), stage(200), starts, goals, rank, world)
+    # the same step with the way-points gathered to rank 0 only (what bench.py runs): identical records everywhere,
+    # paths on rank 0 alone
+    rec2g, path2g, deferred_g = avd.two_stage_plan(stage(K), stage(200), starts, goals, rank, world, paths_to=0)
+    assert torch.equal(rec2g, rec2s) and np.array_equal(deferred_g, deferred)
+    assert (path2g is None) == (rank != 0) and (rank != 0 or torch.equal(path2g, path2s))
+    # an empty problem list: no collective, empty results
+    r0, p0, d0 = avd.two_stage_plan(stage(K), stage(200), starts[:0], goals[:0], rank, world, paths_to=0)
+    assert len(r0) == 0 and len(d0) == 0
+    # the weak-scaling step (bench.py --gpus N, default): the global set holds world x per problems, every rank plans its
+    # contiguous block, ONE gather to rank 0
+    nw = (len(starts) // world) * world
+    recw, pathw = avd.plan_weak(stage(200), starts[:nw], goals[:nw], rank, world, dst=0)
+    assert (recw is None) == (rank != 0)
     if rank == 0:
-        q.put((rec, avd.pack_map_blob(m), rec13, path13, rec2s.view(torch.int32).numpy().copy(), path2s.numpy().copy(), deferred))
+        q.put((rec, avd.pack_map_blob(m), rec13, path13, rec2s.view(torch.int32).numpy().copy(), path2s.numpy().copy(), deferred,
+               recw.view(torch.int32).numpy().copy(), pathw.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_shard_invariance_world2(vehicle, cfg):
+@pytest.mark.parametrize("world", [2, 4])
+def test_shard_invariance(world, vehicle, cfg):
+    """world 2 and 4 (12 problems: the index slices are uneven at 4 ranks only after the first stage -- the number of
+    deferred searches is not a multiple of 4 -- and the weak step runs 3 problems per rank)."""
     import torch.multiprocessing as mp
     from automatedvaletparking_amd import distributed as avd
     from oracle import oracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    rec2, blob, rec13, path13, rec2s, path2s, deferred = q.get(timeout=300)
+    rec2, blob, rec13, path13, rec2s, path2s, deferred, recw, pathw = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -141,6 +158,16 @@ def test_shard_invariance_world2(vehicle, cfg):
         assert list(rec2s[i, :3]) == [r["status"], r["n_pops"], k2], (i, list(rec2s[i, :3]), r["status"], r["n_pops"])
         assert np.array_equal(path2s[i, :k2, :3], r["final_path"][:k2])
         assert (i in set(deferred.tolist())) == (r["n_pops"] > 8 or (r["status"] == 4 and r["n_pops"] >= 8))
+    if world == 4:
+        assert len(deferred) % 4 != 0, "the world-4 case is meant to deal an uneven second stage"
+    # the weak-scaling step: every rank's block, gathered to rank 0 in problem order
+    nw = (len(starts) // world) * world
+    assert len(recw) == nw
+    for i in range(nw):
+        r = o.plan(starts[i], goals[i], max_trace=1)
+        k2 = min(len(r["final_path"]), 40)
+        assert list(recw[i, :3]) == [r["status"], r["n_pops"], k2]
+        assert np.array_equal(pathw[i, :k2, :3], r["final_path"][:k2])
 
 
 def test_map_blob_roundtrip():
