@@ -496,7 +496,7 @@ def main():
         elif pmc and pmc.get("stale"):
             rl["pmc_source"] = "profiles/%s is STALE (kernel sources changed): PMC-derived fields left null" % PMC_FILE
         out = {
-            "metric": "hybrid-A* plans/sec, batched poses", "value": head["plans_per_s"], "unit": "plans/s", "n_gpus": world,
+            "metric": "hybrid-A* plans/sec, batched poses (completed searches at pop cap %d; node expansions/sec in expansions_per_s)" % cap, "value": head["plans_per_s"], "unit": "plans/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (use_dist and not weak) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "problems": head["problems"], "pop_cap": cap, "obstacle_points": P,
@@ -652,7 +652,58 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             cms = e0.elapsed_time(e1) / 10
+            hit_frac = float(co.float().mean().item())
+            # the work-heavy case: collision-free poses only (no early exit: every near point of every pose is tested)
+            free = cp[:, (co.cpu().numpy() == 0)]
+            free = np.ascontiguousarray(np.tile(free, (1, n_chk // max(free.shape[1], 1) + 1))[:, :n_chk])
+            ft = dm.dev_tensor(free)
+            dm.check_batch_dev(ft[0], ft[1], ft[2], out=co)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                dm.check_batch_dev(ft[0], ft[1], ft[2], out=co)
+            e1.record()
+            torch.cuda.synchronize()
+            fms = e0.elapsed_time(e1) / 10
+            assert float(co.float().sum().item()) == 0.0
+            # near misses: collision-free poses whose footprint AABB holds >= 40 obstacle points (the reference's "near" set,
+            # collision_check.py:55-69): every one of them goes through the exact point test and none ends the pose early
+            pp_ = groups[0].dm.params
+            fr = free[:, :min(free.shape[1], 200000)]
+            pk_ = m.pack()
+            ox_, oy_ = np.asarray(pk_["obs_x"]), np.asarray(pk_["obs_y"])
+            near_n = np.zeros(fr.shape[1], np.int32)
+            for c0_ in range(0, fr.shape[1], 20000):
+                x_, y_, t_ = fr[0, c0_:c0_ + 20000], fr[1, c0_:c0_ + 20000], fr[2, c0_:c0_ + 20000]
+                cs_, sn_ = np.cos(t_), np.sin(t_)
+                cxs = np.stack([cs_ * lx - sn_ * ly + x_ for lx in (pp_.fp_xr, pp_.fp_xf) for ly in (pp_.fp_yr, pp_.fp_yl)])
+                cys = np.stack([sn_ * lx + cs_ * ly + y_ for lx in (pp_.fp_xr, pp_.fp_xf) for ly in (pp_.fp_yr, pp_.fp_yl)])
+                inx = (ox_[None, :] >= cxs.min(0)[:, None]) & (ox_[None, :] <= cxs.max(0)[:, None])
+                iny = (oy_[None, :] >= cys.min(0)[:, None]) & (oy_[None, :] <= cys.max(0)[:, None])
+                near_n[c0_:c0_ + 20000] = (inx & iny).sum(1)
+            nm = fr[:, near_n >= 40]
+            near_miss = None
+            if nm.shape[1] >= 1000:
+                mean_near = float(near_n[near_n >= 40].mean())
+                nm = np.ascontiguousarray(np.tile(nm, (1, n_chk // nm.shape[1] + 1))[:, :n_chk])
+                nt = dm.dev_tensor(nm)
+                dm.check_batch_dev(nt[0], nt[1], nt[2], out=co)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    dm.check_batch_dev(nt[0], nt[1], nt[2], out=co)
+                e1.record()
+                torch.cuda.synchronize()
+                nms = e0.elapsed_time(e1) / 10
+                assert float(co.float().sum().item()) == 0.0
+                near_miss = {"checks_per_s": n_chk / (nms * 1e-3), "launch_ms": nms, "mean_near_points_per_pose": mean_near,
+                             "point_tests_per_s": n_chk * mean_near / (nms * 1e-3),
+                             "note": "collision-free poses with >= 40 obstacle points under the footprint's AABB: the exact point test runs on every one of them and no pose ends early"}
             rc = {"kernel": "check_distance_kernel", "launch_ms": cms, "checks_per_s": n_chk / (cms * 1e-3), "bytes_per_check_reference": B_cc,
+                  "colliding_frac": hit_frac,
+                  "free_poses_only": {"checks_per_s": n_chk / (fms * 1e-3), "launch_ms": fms,
+                                      "note": "the same kernel on collision-free poses only (the random set's free poses, repeated): no early exit, but few near points (free poses are far from obstacles)"},
+                  "near_miss_poses": near_miss,
                   "hbm_algorithmic_GBps": n_chk * B_cc / (cms * 1e-3) / 1e9,
                   "note": "the reference formulation reads every obstacle point per check (16P+25 B); the kernel keeps the map in LDS and moves 25 B/check of HBM, so its bound is VALU/LDS issue, not HBM",
                   "hbm_traffic_GBps": n_chk * 25 / (cms * 1e-3) / 1e9, "frac_hbm_traffic": n_chk * 25 / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -683,15 +734,37 @@ def main():
                 out["cpu_baseline"] = {"value": done_cpu / tc, "unit": "plans/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
                                        "sample": f"the first {nb} problems of the headline workload, pop cap {cap}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s; completed searches only, like `value`",
                                        "all_problems_per_s": nb / tc, "expansions_per_s": pops_cpu / tc}
-                from concurrent.futures import ThreadPoolExecutor
+                # all host cores, steady state: a work queue over the same problems (shuffled once, cycled) keeps every thread
+                # busy for >= 12 s; in-flight plans are finished and counted, the clock stops when the last one ends
+                import itertools
+                import threading
                 ncore = os.cpu_count() or 1
+                order = np.random.default_rng(0).permutation(nb)
+                feed = itertools.cycle(order.tolist())
+                lock = threading.Lock()
+                tally = {"done": 0, "all": 0, "pops": 0}
                 t2 = time.perf_counter()
-                reps_mc = 8                       # (the set is planned 8 times over: a fraction of a second would time the thread pool)
-                with ThreadPoolExecutor(max_workers=ncore) as ex:
-                    st_all = list(ex.map(lambda sg: o.plan(sg[0], sg[1], max_trace=1)["status"], list(zip(g0.starts[:nb], g0.goals[:nb])) * reps_mc))
+                deadline = t2 + 12.0
+
+                def worker():
+                    while True:
+                        with lock:
+                            if time.perf_counter() >= deadline:
+                                return
+                            i = next(feed)
+                        w = o.plan(g0.starts[i], g0.goals[i], max_trace=1)
+                        with lock:
+                            tally["all"] += 1
+                            tally["done"] += w["status"] in (0, 1)
+                            tally["pops"] += w["n_pops"]
+
+                ths = [threading.Thread(target=worker) for _ in range(ncore)]
+                [t.start() for t in ths]
+                [t.join() for t in ths]
                 tm = time.perf_counter() - t2
-                out["cpu_baseline_all_cores"] = {"value": sum(s in (0, 1) for s in st_all) / tm, "unit": "plans/s", "cores": ncore, "kind": "port", "cpu_model": cpu_model(),
-                                                 "sample": f"the same {nb} problems {reps_mc} times over, one problem per thread, {tm:.1f} s"}
+                out["cpu_baseline_all_cores"] = {"value": tally["done"] / tm, "unit": "plans/s", "cores": ncore, "kind": "port", "cpu_model": cpu_model(),
+                                                 "all_problems_per_s": tally["all"] / tm, "expansions_per_s": tally["pops"] / tm,
+                                                 "sample": f"the same {nb} problems, shuffled and cycled through a work queue by {ncore} threads for {tm:.1f} s ({tally['all']} plans): steady state"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

@@ -459,6 +459,35 @@ def gen_random(case_id, n, seed_off=0, timeout=1200):
         print("random", case_id, i, d["status"], "pops", len(d["pops"]), "t", time.time() - t0, flush=True)
 
 
+def gen_irregular():
+    """G11: a goal whose goal-anchored lattice is NOT regular with respect to the id grid -- xf one ulp below a cell
+    border (nextafter(b0 + 171 * dx, -inf) on the Case1 map), so the accumulated lattice positions xf +- k*dx
+    (compute_h.py:58-66,89-186) step over grid-id columns: some id columns are never generated. The device refuses such
+    goals (AVP_PLAN_LATTICE); this fixture records what the reference does there, for tests/test_gpu_limits.py: it never
+    returns from PathPlanner.__init__ (the start's heuristic query is for an id the sweep never produces: the
+    `while` of compute_h.py:77 spins on), recorded as status "timeout" with no pops after 300 s -- or whatever exception
+    it ends with."""
+    cfg = config()
+    csv = os.path.join(CASES, "Case1.csv")
+    m0 = load_map(csv, cfg)
+    gx = float(np.nextafter(float(m0.boundary[0]) + 171 * float(m0._discrete_x), -np.inf))
+    go = np.array([gx, m0.case.yf, m0.case.thetaf])
+    st = np.array([m0.case.x0, m0.case.y0, m0.case.theta0])
+    t0 = time.time()
+    try:
+        d = run_plan(csv, cfg, start=st, goal=go, timeout=300)
+    except Exception as e:                                   # anything but Timeout / AttributeError
+        signal.alarm(0)
+        d = {"status": type(e).__name__, "pops": np.zeros((0, 11))}
+        d.update({"map_" + k: v for k, v in map_arrays(m0).items()})
+    d["case"] = 1
+    d["start"] = st
+    d["goal"] = go
+    d["seconds"] = time.time() - t0
+    save("g11_irregular_lattice_case1.npz", d)
+    print("irregular", d["status"], "pops", len(d["pops"]), "t", time.time() - t0, flush=True)
+
+
 VARIANTS = {
     "steer7_r6": {"steering_angle_num": 7, "flag_radius": 6.0},
     "steer3": {"steering_angle_num": 3},
@@ -593,3 +622,5 @@ if __name__ == "__main__":
         gen_synth()
     elif what == "corridor":
         gen_corridor()
+    elif what == "irregular":
+        gen_irregular()
