@@ -1244,6 +1244,24 @@ AVP_D void pl_rs_sample_world(const PlanWs& w, S& s, const avp_params& p, const 
 // (pl_check_wave below), the map / vehicle constants come from the workgroup's PlChkEnv, the hit flags go to
 // out_hit[k] (LDS). Its registers are its own -- inlined into the pop loops (twice per kernel) it set their
 // register demand.
+// the narrow phase of a pass, a called function of its own (round 4): one lane per (pose, point) candidate of the wave's
+// queue. Inside pl_check_pass its 22 record values per candidate competed with the pass's set-up and gather state for the
+// 128 registers of the group forms (7 - 9 spilled VGPRs, +150 B of scratch per lane once the point test had its
+// division-free first look).
+template <bool STAGE, int QCAP>
+__device__ __noinline__ void pl_check_narrow(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp)
+{
+    const PlTabs<STAGE> mt(*(const PlChkEnv*)envp);
+    const int lane = threadIdx.x & 63;
+    const int qn = wcp->qn;
+    for (int e = lane; e < qn; e += 64) {
+        const uint32_t ent = wcp->q[e];
+        const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
+        if (wcp->hit[i]) continue;
+        if (avp_footprint_point_hit(wcp->fp[i], mt.X[ix], mt.Y[iy])) wcp->hit[i] = 1;
+    }
+}
+
 template <bool STAGE, int QCAP>
 __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp, int count, AVP_LDS uint32_t* out_hit_p)
 {
@@ -1361,13 +1379,7 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
             // one pose with more candidates than the queue holds: a lane walks its columns serially
             if (lane == lo) wc.hit[lane] = pl_check_pose(env, mt.X, mt.Y, mt.bits, wc.pose[lane][0], wc.pose[lane][1], wc.pose[lane][2], wc.pose[lane][3], wc.pose[lane][4]) ? 1u : 0u;
         } else {
-            const int qn = wc.qn;
-            for (int e = lane; e < qn; e += 64) {
-                const uint32_t ent = wc.q[e];
-                const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
-                if (wc.hit[i]) continue;
-                if (avp_footprint_point_hit(wc.fp[i], mt.X[ix], mt.Y[iy])) wc.hit[i] = 1;
-            }
+            pl_check_narrow<STAGE, QCAP>(envp, wcp);
         }
         wave_sync();
         lo = hi;

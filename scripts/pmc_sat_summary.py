@@ -1,4 +1,4 @@
-"""SQ counters of the planner kernels on a saturating batch (profiles/r03_pmc_saturating_batch.json).
+"""SQ counters of the planner kernels on a saturating batch (profiles/r04_pmc_saturating_batch.json).
 
     python scripts/pmc_sat_summary.py <dir with sub-directories sq/ and lane/, each holding the rocprofv3 csv output of
         rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python scripts/variant_bench.py --big 16384 --big-mode M --no-profile --steps 1>
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
-from pmc_r03_summary import collect, durations  # noqa: E402
+from pmc_summary import collect, durations  # noqa: E402
 from bench import source_hash  # noqa: E402
 
 

@@ -218,3 +218,13 @@ def test_corridor_bounds(k, vehicle, cfg):
     r = o.corridor_batch(g[f"c{k}_poses"], float(g["expand_dis"]))
     assert np.array_equal(r[:, :2], g[f"c{k}_Hmax"], equal_nan=True)
     assert np.array_equal(r[:, 2:], g[f"c{k}_Hmin"], equal_nan=True)
+
+
+def test_g11_irregular_lattice_goal_blocks(vehicle, cfg):
+    """G11: the reference never returns for a goal one ulp below a cell border (its start query's id is never produced:
+    compute_h.py:77 blocks; recorded as a 300 s timeout with no pop). The oracle reports that situation as H_UNREACHABLE."""
+    from oracle import oracle
+    g = gold("g11_irregular_lattice_case1.npz")
+    assert str(g["status"]) == "timeout" and len(g["pops"]) == 0
+    w = oracle.Oracle(case_map_from_gold(1), vehicle, cfg, max_pops=50).plan(g["start"], g["goal"], max_trace=1)
+    assert w["status"] == 2 and w["n_pops"] == 0
