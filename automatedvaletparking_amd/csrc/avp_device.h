@@ -134,12 +134,15 @@ AVP_HD void avp_footprint_aabb(const Footprint& f, double& xmin, double& xmax, d
 
 // One obstacle point against the rectangle (collision_check.py:197-238): inside test by point-line distances, exact
 // corner test, exact edge-slope test -- the reference's booleans, eight IEEE divisions per point.
+// den[i] of a record: stored (Footprint), or recomputed by the expression that produced it (a record without den)
+template <class F> AVP_HD auto avp_footprint_den_(const F& f, int i, int) -> decltype(f.den[0] + 0.0) { return f.den[i]; }
+template <class F> AVP_HD double avp_footprint_den_(const F& f, int i, long) { return sqrt(1 + f.k[i] * f.k[i]); }
 template <class F>
 AVP_HD bool avp_footprint_point_hit_exact(const F& f, double px, double py)
 {
     double d[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) d[i] = fabs(f.k[i] * px + f.b[i] - py) / sqrt(1 + f.k[i] * f.k[i]);   // (= / den[i], same expression)
+    for (int i = 0; i < 4; i++) d[i] = fabs(f.k[i] * px + f.b[i] - py) / avp_footprint_den_(f, i, 0);
     const bool c1 = fabs(d[0] - d[2]) < f.wthr;
     const bool c2 = fabs(d[1] - d[3]) < f.lthr;
     if (c1 && c2) return true;

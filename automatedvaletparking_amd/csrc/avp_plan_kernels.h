@@ -457,6 +457,7 @@ struct PlShared {
     static constexpr int HEAP_LDS = PL_HEAP_LDS;
     double hl_f[PL_HEAP_LDS > 0 ? PL_HEAP_LDS : 1];      // the first HEAP_LDS entries of the open list's heap: keys,
     uint32_t hl_n[PL_HEAP_LDS > 0 ? PL_HEAP_LDS : 1];    // ... nodes
+    static constexpr bool POINT_FAST = false;         // (pl_check_narrow)
     __device__ __forceinline__ PlWaveChk& wave_chk() { return wchk[threadIdx.x >> 6]; }
     uint32_t chk_hit[PL_MAXCHILD * 4];   // hit flag per sub-step pose of the current pop
     int32_t next_cur, have_next;      // node popped ahead by wave 0 at the end of its resolution (see pl_resolve_fast_wave)
@@ -1248,7 +1249,13 @@ AVP_D void pl_rs_sample_world(const PlanWs& w, S& s, const avp_params& p, const 
 // queue. Inside pl_check_pass its 22 record values per candidate competed with the pass's set-up and gather state for the
 // 128 registers of the group forms (7 - 9 spilled VGPRs, +150 B of scratch per lane once the point test had its
 // division-free first look).
-template <bool STAGE, int QCAP>
+// FAST: the point test's division-free first look (avp_footprint_point_hit) or the exact form with its eight divisions.
+// Same booleans; which is quicker depends on what bounds the pass (measured in one run, round 4): four waves per problem
+// (latency bound: a pass is one dependent chain) 87.5 ms with the exact form against 91.3 ms on the 4 096 batch -- the
+// eight divisions overlap, the first look's comparisons and its fall-back code do not pay for themselves --, one wave per
+// problem on the saturating batch (issue bound) 194.5 ms with the first look against 197.4 ms. So: the first look where
+// sixteen searches share a CU (S::POINT_FAST), the exact form elsewhere.
+template <bool STAGE, int QCAP, bool FAST>
 __device__ __noinline__ void pl_check_narrow(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp)
 {
     const PlTabs<STAGE> mt(*(const PlChkEnv*)envp);
@@ -1258,11 +1265,12 @@ __device__ __noinline__ void pl_check_narrow(AVP_LDS const PlChkEnv* envp, AVP_L
         const uint32_t ent = wcp->q[e];
         const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
         if (wcp->hit[i]) continue;
-        if (avp_footprint_point_hit(wcp->fp[i], mt.X[ix], mt.Y[iy])) wcp->hit[i] = 1;
+        const bool h = FAST ? avp_footprint_point_hit(wcp->fp[i], mt.X[ix], mt.Y[iy]) : avp_footprint_point_hit_exact(wcp->fp[i], mt.X[ix], mt.Y[iy]);
+        if (h) wcp->hit[i] = 1;
     }
 }
 
-template <bool STAGE, int QCAP>
+template <bool STAGE, int QCAP, bool FAST>
 __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp, int count, AVP_LDS uint32_t* out_hit_p)
 {
     const PlChkEnv& env = *(const PlChkEnv*)envp;
@@ -1305,7 +1313,7 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
                 else if (sub == 4) { u = cx[0] - cx[3]; v = cy[0] - cy[3]; }
                 else { u = cx[3] - cx[2]; v = cy[3] - cy[2]; }
                 const double r = sqrt(u * u + v * v);
-                if (sub < 4) { f.cx[sub] = x1; f.cy[sub] = y1; f.k[sub] = k; f.b[sub] = y1 - k * x1; f.den[sub] = r; f.rden[sub] = avp_footprint_rden(k, r); }
+                if (sub < 4) { f.cx[sub] = x1; f.cy[sub] = y1; f.k[sub] = k; f.b[sub] = y1 - k * x1; f.den[sub] = r; if (FAST) f.rden[sub] = avp_footprint_rden(k, r); }   // (1 / den: only the first look reads it)
                 else if (sub == 4) f.wthr = r - 0.01;
                 else f.lthr = r - 0.01;
             }
@@ -1379,7 +1387,7 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
             // one pose with more candidates than the queue holds: a lane walks its columns serially
             if (lane == lo) wc.hit[lane] = pl_check_pose(env, mt.X, mt.Y, mt.bits, wc.pose[lane][0], wc.pose[lane][1], wc.pose[lane][2], wc.pose[lane][3], wc.pose[lane][4]) ? 1u : 0u;
         } else {
-            pl_check_narrow<STAGE, QCAP>(envp, wcp);
+            pl_check_narrow<STAGE, QCAP, FAST>(envp, wcp);
         }
         wave_sync();
         lo = hi;
@@ -1403,7 +1411,7 @@ AVP_D void pl_check_wave(const PlChkEnv& env, S& s, int count, PoseFn pose, uint
         wc.pose[lane][0] = x; wc.pose[lane][1] = y; wc.pose[lane][2] = th; wc.pose[lane][3] = cs; wc.pose[lane][4] = sn;
     }
     wave_sync();
-    pl_check_pass<STAGE, QCAP>((AVP_LDS const PlChkEnv*)&env, (AVP_LDS PlWaveChkT<QCAP>*)&wc, count, (AVP_LDS uint32_t*)out_hit);
+    pl_check_pass<STAGE, QCAP, S::POINT_FAST>((AVP_LDS const PlChkEnv*)&env, (AVP_LDS PlWaveChkT<QCAP>*)&wc, count, (AVP_LDS uint32_t*)out_hit);
 }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits until every global store of the wave

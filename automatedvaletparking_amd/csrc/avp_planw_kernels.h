@@ -253,6 +253,7 @@ struct PwSharedT {
     uint32_t phase[PW_PH_COUNT];               // instrumented instantiation only: shader cycles per phase (lane 0)
     int64_t snap[5];                           // counters saved before a resolution that runs beside the shot (pw_ph_shot_resolve)
     int32_t resume, fresh_done, park_now, sl_pad;   // time slicing: this problem continues a parked search / no unstarted problem is left / park decision
+    static constexpr bool POINT_FAST = NW == 1;       // (pl_check_narrow: the first look pays where the CU is issue bound)
     __device__ __forceinline__ PlWaveChkT<PW_WQCAP>& wave_chk() { return wchk[PwGroup<NW>::wv()]; }
 };
 
