@@ -184,18 +184,24 @@ int32_t avp_plan_batch(avp_map* map, const double* starts, const double* goals, 
                        double* paths, int32_t max_path, double* trace, int32_t max_trace);
 
 /*
- * Kernel form. The planner exists in two forms with bit-identical results (tests/test_gpu_plan_wave.py):
+ * Kernel form. The planner exists in four forms with bit-identical results (tests/test_gpu_plan_wave.py). A form gives
+ * every problem a GROUP of waves; avp_plan_group(mode) problems share a workgroup (= a compute unit), avp_plan_slots(map,
+ * mode) = avp_plan_group(mode) x CUs problems run at once:
  *   mode 1: one workgroup (512 threads) per problem -- the shortest time per problem; right when the batch is no larger
  *           than the chip (BASELINE config[1]: 256 problems on 256 CUs);
- *   mode 2: one wave per problem, eight problems per workgroup -- the most problems in flight; right for batches much
- *           larger than the chip (north_star's 4 096-pose batch). Problems it cannot hold (a Reeds-Shepp shot of more
- *           than 256 samples, more than 16 children) are planned by the mode-1 kernel in a second launch of the same call;
- *   mode 3: a pair of waves per problem, half as many problems per workgroup as mode 2 -- a pop takes ~0.6 x the time of
- *           mode 2: right for a few problems per CU (their long searches all run at once: their latency is the launch time);
- *   mode 4: four waves per problem, a quarter as many problems per workgroup as mode 2 (a pop takes ~0.45 x the time);
+ *   mode 2: one wave per problem, avp_plan_group(2) = 16 problems per workgroup -- the most problems in flight; right for
+ *           batches much larger than the chip. Problems a group form cannot hold (a Reeds-Shepp shot of more than 192
+ *           samples, more than 16 children) are planned by the mode-1 kernel in a later launch of the same call;
+ *   mode 3: a pair of waves per problem, avp_plan_group(3) = 8 per workgroup -- a pop takes ~0.7 x the time of mode 2:
+ *           right for a few problems per CU (their long searches all run at once: their latency is the launch time);
+ *   mode 4: four waves per problem, avp_plan_group(4) = 4 per workgroup (a pop takes ~0.6 x the time of mode 2);
  *   mode 0: avp_plan_batch's choice by problems per CU: mode 1 below 12, mode 4 below 24, mode 3 below 80, mode 2 from there.
- * n_slots counts problem slots in either form (avp_plan_slots(map, mode) = avp_plan_group(mode) x CUs); the workspace is
- * avp_plan_workspace_bytes(map, n_slots, max_nodes) as before. avp_plan_pick_mode returns the form mode 0 would use.
+ * n_slots counts problem slots in every form and is a multiple of avp_plan_group(mode) (size it from avp_plan_slots, not
+ * from a constant); the workspace is avp_plan_workspace_bytes(map, n_slots, max_nodes) as before. avp_plan_pick_mode
+ * returns the form mode 0 would use. IMPLICIT TIME SLICING: when n_slots >= n (a slot for every problem), n exceeds
+ * avp_plan_slots(map, mode) and the handle's slice length is non-zero (avp_plan_set_slice_pops below; 64 by default), a
+ * group-form launch parks long searches and presets every record's status to AVP_PLAN_UNFINISHED first -- call
+ * avp_plan_set_slice_pops(map, 0) before the launch to rule it out. Results are the same either way.
  */
 int32_t avp_plan_batch_mode(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
                             int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
@@ -211,7 +217,8 @@ int32_t avp_plan_pick_mode(avp_map* map, int64_t n, int32_t mode);
  * A restarted search is the same search: records, traces and paths are those of avp_plan_batch (tests/test_gpu_staged.py).
  * n_slots / workspace: as for mode 2 (avp_plan_slots(map, 2)). first_stage_only != 0: stop after stage 1; the
  * unfinished searches then carry status AVP_PLAN_DEFERRED and nothing else -- for callers that deal them to other
- * devices themselves (automatedvaletparking_amd.distributed).
+ * devices themselves (automatedvaletparking_amd.distributed). (A search the wave form cannot hold at all -- see mode 2 --
+ * carries the same status after stage 1: it, too, is for a later stage.)
  */
 #define AVP_PLAN_DEFERRED 100
 int32_t avp_plan_batch_staged(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
