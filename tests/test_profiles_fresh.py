@@ -117,7 +117,8 @@ def test_compiler_remarks_of_the_planner_kernels():
     assert len(waves) == 12
     for k in waves:
         assert rows[k]["VGPRs"] <= 128 and rows[k]["Occupancy"] == 4, (k, rows[k])
-        assert rows[k]["VGPRs Spill"] <= (1 if k.startswith("plan_wave_kernel<true, false") else 8), (k, rows[k])     # (LDS-staged product instantiations: <= 1)
+        lim = 1 if k.startswith("plan_wave_kernel<true, false") else 4 if k.startswith("plan_wave_kernel<false, false") else 64
+        assert rows[k]["VGPRs Spill"] <= lim, (k, rows[k])     # (product instantiations: LDS-staged <= 1, L2-backed <= 4; instrumented ones may spill)
     assert rows["plan_kernel<true, false, false>"]["VGPRs Spill"] == 0
     assert rows["plan_kernel<true, false, true>"]["VGPRs Spill"] <= 32
     for k in ("check_distance_kernel<true>", "check_distance_kernel<false>"):
