@@ -20,9 +20,8 @@
  * any later version. This file is distributed under the same terms.
  *
  * Domain notes. Rounding mode: round-to-nearest is assumed (glibc switches to it on entry). errno and the
- * floating-point exception flags are not reproduced. avpg_tan follows glibc up to |x| <= 1e8 (the RS words
- * call tan on angles within +-2 pi); beyond that glibc runs a Payne-Hanek reduction (__branred) that is not
- * restated: the caller (avp_tan in avp_libm.h) uses the fdlibm-form kernel there.
+ * floating-point exception flags are not reproduced. Every finite and non-finite double is covered, tan's
+ * Payne-Hanek range |x| > 1e8 (__branred, the generic SSE2 build: it has no FMA variant) included.
  */
 #ifndef AVP_GLIBC_LIBM_H
 #define AVP_GLIBC_LIBM_H
@@ -486,7 +485,60 @@ AVP_GLIBC_FN double avpg_tan_reduced(double a, double da, int n)
     return avpg_tan_table(ya, yya, n, sy);
 }
 
-/* returns 1 and *res when |x| <= 1e8 or x is not finite, 0 when the Payne-Hanek range is needed */
+/* __branred (branred.c): x - n pi/2 for |x| > 1e8 as a + aa, n mod 4 returned. x is scaled by 2^-600, split in two
+ * 27-bit halves, each multiplied by six 24-bit pieces of 2/pi picked by its exponent; the integer parts are peeled off
+ * with the 1.5 * 2^52 trick. The library's build of this file is plain SSE2: no contraction anywhere. */
+AVP_GLIBC_FN void avpg_branred_half(double xh, double* b_out, double* bb_out, double* sum_out)
+{
+    const double tm24 = 0x1p-24, big = 0x1.8p52, big1 = 0x1.8p54;
+    int k = (int)((avpg_bits(xh) >> 52) & 2047);
+    k = (k - 450) / 24;
+    if (k < 0) k = 0;
+    double gor = avpg_from_bits(((uint64_t)(0x63f00000u - (uint32_t)((k * 24) << 20))) << 32);      /* 2^(576 - 24 k) */
+    double r[6];
+    for (int i = 0; i < 6; i++) { r[i] = xh * AVPG_T(AVP_G_TOVERP, k + i) * gor; gor *= tm24; }
+    double sum = 0.0, s;
+    for (int i = 0; i < 3; i++) { s = (r[i] + big) - big; sum += s; r[i] -= s; }
+    double t = 0.0;
+    for (int i = 0; i < 6; i++) t += r[5 - i];
+    double bb = (((((r[0] - t) + r[1]) + r[2]) + r[3]) + r[4]) + r[5];
+    s = (t + big) - big;
+    sum += s;
+    t -= s;
+    const double b = t + bb;
+    bb = (t - b) + bb;
+    s = (sum + big1) - big1;
+    sum -= s;
+    *b_out = b; *bb_out = bb; *sum_out = sum;
+}
+AVP_GLIBC_FN int avpg_branred(double x, double* a, double* aa)
+{
+    const double split = 134217729.0, hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+    const double mp1 = 0x1.921fb58p+0, mp2 = -0x1.dde974p-27;                  /* branred.h's split of pi/2 (not s_tan.c's) */
+    x *= 0x1p-600;
+    double t = x * split;
+    const double x1 = t - (t - x), x2 = x - x1;
+    double b1, bb1, sum1, b2, bb2, sum2;
+    avpg_branred_half(x1, &b1, &bb1, &sum1);
+    avpg_branred_half(x2, &b2, &bb2, &sum2);
+    double sum = sum1 + sum2;
+    double b = b1 + b2;
+    double bb = fabs(b1) > fabs(b2) ? (b1 - b) + b2 : (b2 - b) + b1;
+    if (b > 0.5) { b -= 1.0; sum += 1.0; }
+    else if (b < -0.5) { b += 1.0; sum -= 1.0; }
+    double s = b + (bb + bb1 + bb2);
+    t = ((b - s) + bb) + (bb1 + bb2);
+    b = s * split;
+    const double t1 = b - (b - s), t2 = s - t1;
+    b = s * hp0;
+    bb = (((t1 * mp1 - b) + t1 * mp2) + t2 * mp1) + (t2 * mp2 + s * hp1 + t * hp0);
+    s = b + bb;
+    t = (b - s) + bb;
+    *a = s; *aa = t;
+    return ((int)sum) & 3;
+}
+
+/* tan(x); always returns 1 (kept as a "try" for the callers written when the Payne-Hanek range was not restated) */
 AVP_GLIBC_FN int avpg_tan_try(double x, double* res)
 {
     const double g1 = 0x1.b096cp-27, g2 = 0x1.f212dp-5, g3 = 0x1.92f1ap-1, g4 = 25.0, g5 = 1e8;
@@ -532,7 +584,15 @@ AVP_GLIBC_FN int avpg_tan_try(double x, double* res)
         *res = avpg_tan_reduced(s, ds, n);
         return 1;
     }
-    return 0;
+    {                                               /* |x| > 1e8: __branred, then the same tail */
+        double a, da;
+        const int n = avpg_branred(x, &a, &da) & 1;
+        const double s = a + da;
+        double ds;
+        if (fabs(a) > fabs(da)) ds = (a - s) + da; else ds = (da - s) + a;
+        *res = avpg_tan_reduced(s, ds, n);
+        return 1;
+    }
 }
 
 /* ========================================================================================== pow(x, 2.0) */

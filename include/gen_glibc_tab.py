@@ -7,7 +7,7 @@ words are decided by the last bit of those results. glibc's kernels evaluate pol
 points that are NOT round numbers (they were picked so that atan(x_i), asin(x_i), ... are unusually close to a
 double), so the tables cannot be regenerated from first principles the way the sin/cos table was
 (csrc/gen_sincos_table.py). They are data of the GNU C Library (LGPL-2.1-or-later; sysdeps/ieee754/dbl-64/
-uatan.tbl, asincos.tbl, root.tbl, powtwo.tbl, utan.tbl, e_pow_log_data.c, e_exp_data.c) and are read here from
+uatan.tbl, asincos.tbl, root.tbl, powtwo.tbl, utan.tbl, branred.h, e_pow_log_data.c, e_exp_data.c) and are read here from
 the distribution's own static archive /usr/lib/x86_64-linux-gnu/libm-2.35.a with binutils; the generated header
 carries that notice. include/avp_glibc_libm.h holds the arithmetic that uses them.
 
@@ -56,7 +56,7 @@ def emit(f, ctype, name, dims, words, per_line=4, as_double=True):
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        members = ["e_atan2-fma.o", "e_asin-fma.o", "s_tan-fma.o", "e_pow_log_data.o", "e_exp_data.o"]
+        members = ["e_atan2-fma.o", "e_asin-fma.o", "s_tan-fma.o", "e_pow_log_data.o", "e_exp_data.o", "branred.o"]
         subprocess.check_call(["ar", "x", ARCHIVE] + members, cwd=tmp)
         p = lambda m: os.path.join(tmp, m)
         atan2_ro = section(p("e_atan2-fma.o"), ".rodata", tmp)
@@ -79,6 +79,9 @@ def main():
         assert len(expd) >= 112 + 256 * 8
         exp_head = doubles(expd, 0, 14)                # invln2N, shift, negln2hiN, negln2loN, poly[4], exp2_shift, exp2_poly[5]
         exp_tab = doubles(expd, 112, 256)
+        br_ro = section(p("branred.o"), ".rodata", tmp)
+        assert symbols(p("branred.o"))["toverp"] == 0 and len(br_ro) == 75 * 8
+        toverp = doubles(br_ro, 0, 75)                 # 2/pi in 24-bit pieces (branred.h)
     # sanity: the values the arithmetic relies on
     as_f = lambda w: struct.unpack("<d", struct.pack("<Q", w))[0]
     assert abs(as_f(cij[0]) - 1.0 / 16) < 1e-3 and abs(as_f(cij[240 * 7]) - 1.0) < 5e-3
@@ -93,7 +96,7 @@ def main():
     with open(out, "w") as f:
         f.write("/* GENERATED by include/gen_glibc_tab.py from %s -- do not edit.\n" % os.path.basename(ARCHIVE))
         f.write(" *\n * Lookup tables of the GNU C Library 2.35 fp64 atan2 / asin / acos / tan / pow kernels\n")
-        f.write(" * (sysdeps/ieee754/dbl-64: uatan.tbl, asincos.tbl, root.tbl, powtwo.tbl, utan.tbl, e_pow_log_data.c,\n")
+        f.write(" * (sysdeps/ieee754/dbl-64: uatan.tbl, asincos.tbl, root.tbl, powtwo.tbl, utan.tbl, branred.h, e_pow_log_data.c,\n")
         f.write(" * e_exp_data.c). Copyright (C) Free Software Foundation, Inc.; the GNU C Library is free software,\n")
         f.write(" * distributed under the GNU Lesser General Public License, version 2.1 or (at your option) any later\n")
         f.write(" * version; these tables are data of that library, reproduced bit for bit. See avp_glibc_libm.h. */\n")
@@ -105,6 +108,7 @@ def main():
         emit(f, "uint64_t", "AVP_G_XFG", "[186 * 4]", xfg, 4, False)
         emit(f, "uint64_t", "AVP_G_POWLOG_TAB", "[128 * 4]", powlog_tab, 4, False)
         emit(f, "uint64_t", "AVP_G_EXP_TAB", "[256]", exp_tab, 4, False)
+        emit(f, "uint64_t", "AVP_G_TOVERP", "[75]", toverp, 5, False)
         f.write("#endif\n")
     print("wrote", out)
 

@@ -18,7 +18,7 @@ static inline double uni(uint64_t* s, double a, double b) { return a + (b - a) *
 static inline double logu(uint64_t* s, int elo, int ehi) { const double m = 1.0 + u01(s); const int e = elo + (int)(splitmix(s) % (uint64_t)(ehi - elo + 1)); const double v = ldexp(m, e); return (splitmix(s) & 1) ? -v : v; }
 static inline double anybits(uint64_t* s) { return avpg_from_bits(splitmix(s)); }
 static inline int same(double a, double b) { return avpg_bits(a) == avpg_bits(b) || (a != a && b != b); }
-static double tan_both(double x) { double r; if (avpg_tan_try(x, &r)) return r; return tan(x); }
+static double tan_both(double x) { double r; avpg_tan_try(x, &r); return r; }
 
 typedef struct { const char* name; int nargs; int dist; } job_t;
 static long run(const char* fn, const char* dname, int dist, long n)
@@ -58,6 +58,7 @@ static long run(const char* fn, const char* dname, int dist, long n)
                 case 2: x = logu(&s, -40, 26); break;
                 case 3: { const double k = (double)(int)uni(&s, -16, 16); x = k * 0x1.921fb54442d18p+0 + ldexp(uni(&s, -1, 1), -(int)(splitmix(&s) % 40)); break; }
                 case 4: x = uni(&s, -1.05e8, 1.05e8); break;
+                case 5: x = logu(&s, 26, 1023); break;                                      /* Payne-Hanek range (__branred) */
                 default: x = anybits(&s); break;
                 }
                 a = tan_both(x); b = tan(x);
@@ -93,12 +94,12 @@ int main(int argc, char** argv)
     long bad = 0;
     static const char* an[] = { "box10", "log40", "logfull", "2_over_u", "r_over_m2", "polar", "anybits", "edges" };
     static const char* sn[] = { "uniform", "small", "near1", "sqrt_range", "anybits" };
-    static const char* tn[] = { "pm2pi", "pm25", "log", "near_kpi2", "pm1e8", "anybits" };
+    static const char* tn[] = { "pm2pi", "pm25", "log", "near_kpi2", "pm1e8", "huge", "anybits" };
     static const char* pn[] = { "pm100", "log30", "logfull", "near1", "anybits" };
     if (!*only || !strcmp(only, "atan2")) for (int d = 0; d < 8; ++d) bad += run("atan2", an[d], d, n);
     if (!*only || !strcmp(only, "asin")) for (int d = 0; d < 5; ++d) bad += run("asin", sn[d], d, n);
     if (!*only || !strcmp(only, "acos")) for (int d = 0; d < 5; ++d) bad += run("acos", sn[d], d, n);
-    if (!*only || !strcmp(only, "tan")) for (int d = 0; d < 6; ++d) bad += run("tan", tn[d], d, n);
+    if (!*only || !strcmp(only, "tan")) for (int d = 0; d < 7; ++d) bad += run("tan", tn[d], d, n);
     if (!*only || !strcmp(only, "pow2")) for (int d = 0; d < 5; ++d) bad += run("pow2", pn[d], d, n);
     printf("total mismatches %ld\n", bad);
     return bad != 0;

@@ -219,3 +219,27 @@ def test_time_slicing_soak(vehicle, cfg):
     for k in range(25):
         got_d, _ = digest(on)
         assert on.last_time_sliced and got_d == want, k
+
+
+def test_default_time_slicing_gives_way_when_memory_is_short(vehicle, cfg):
+    """time_slice=None is opportunistic: it wants a workspace slot per problem (2.6 MB each at 16 384 nodes), takes it only
+    when that fits half of the free device memory, and plans unsliced otherwise -- here a co-tenant tensor leaves 6 GB free,
+    4 096 problems would want 11 GB of slots: same results as with the memory to itself, last_time_sliced False."""
+    import torch
+    from automatedvaletparking_amd import _native, path_planner, workloads
+    cap = 60
+    dm = _native.DeviceMap(case_map_from_gold(1), vehicle, cfg, max_pops=cap)
+    m, st, go = workloads.case1_pairs(cfg, lambda mm: dm.check_batch, 4096)
+    ref = path_planner.BatchPlanner(dm, max_nodes=16384, mode=2, time_slice=True).plan(st, go)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (6 << 30), 1 << 20), dtype=torch.uint8, device="cuda")
+    try:
+        bp = path_planner.BatchPlanner(dm, max_nodes=16384, mode=2)            # time_slice=None
+        got = bp.plan(st, go)
+        assert bp.last_time_sliced is False
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert all(a.status == b.status and a.n_pops == b.n_pops and np.array_equal(a.final_path, b.final_path) for a, b in zip(ref, got))
