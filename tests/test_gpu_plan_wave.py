@@ -222,23 +222,29 @@ def test_time_slicing_soak(vehicle, cfg):
 
 
 def test_default_time_slicing_gives_way_when_memory_is_short(vehicle, cfg):
-    """time_slice=None is opportunistic: it wants a workspace slot per problem (2.6 MB each at 16 384 nodes), takes it only
-    when that fits half of the free device memory, and plans unsliced otherwise -- here a co-tenant tensor leaves 6 GB free,
-    4 096 problems would want 11 GB of slots: same results as with the memory to itself, last_time_sliced False."""
+    """time_slice=None is opportunistic: it wants a workspace slot per problem (2.8 MB each at 16 384 nodes), takes them only
+    when they fit half of the free device memory, and plans unsliced otherwise -- here a co-tenant tensor leaves 20 GB free;
+    8 192 problems in the wave form want 23 GB of slots sliced, 11.5 GB (one slot per group: 4 096) unsliced: the launch goes
+    unsliced, last_time_sliced says so, and the results are those of the sliced launch with the memory to itself."""
     import torch
     from automatedvaletparking_amd import _native, path_planner, workloads
     cap = 60
     dm = _native.DeviceMap(case_map_from_gold(1), vehicle, cfg, max_pops=cap)
     m, st, go = workloads.case1_pairs(cfg, lambda mm: dm.check_batch, 4096)
-    ref = path_planner.BatchPlanner(dm, max_nodes=16384, mode=2, time_slice=True).plan(st, go)
+    st, go = np.concatenate([st, st]), np.concatenate([go, np.roll(go, 7, axis=0)])
+    ref_bp = path_planner.BatchPlanner(dm, max_nodes=16384, mode=2, time_slice=True)
+    ref = ref_bp.plan(st, go)
+    assert ref_bp.last_time_sliced is True
+    del ref_bp
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    hog = torch.empty(max(free - (6 << 30), 1 << 20), dtype=torch.uint8, device="cuda")
+    hog = torch.empty(max(free - (20 << 30), 1 << 20), dtype=torch.uint8, device="cuda")
     try:
         bp = path_planner.BatchPlanner(dm, max_nodes=16384, mode=2)            # time_slice=None
         got = bp.plan(st, go)
         assert bp.last_time_sliced is False
+        del bp
     finally:
         del hog
         torch.cuda.empty_cache()
