@@ -400,6 +400,7 @@ struct PlShared {
     int32_t E;                        // buckets [0, E) are expanded
     uint32_t qcount[PL_NQ], qbase[PL_NQ];   // pushes so far / entries consumed so far, per rotating bucket queue
     int32_t qover;
+    static constexpr bool RELAX_PRECHECK = false;       // (pl_hquery_miss: the sweep of this form is latency bound)
     uint32_t dF; int64_t idF;         // key of the last miss (closed frontier)
     int32_t hasF;
     int64_t h_cells, h_misses;
@@ -849,12 +850,17 @@ AVP_D void pl_hquery_miss(const DevMap& m, const PlanWs& w, S& s, int64_t id)
                     atomicMin(&w.aliasKey[slot], key);
                 }
             }
-#if PL_RELAX_PRECHECK
+            // The pre-check load settles the relaxations that cannot lower a distance without an atomic (about half of a
+            // ring's go backwards or sideways). It pays where sixteen searches share a CU and the atomics are what is scarce
+            // (group forms: the sweep 15 % shorter); in plan_kernel a bucket is a chain of cold memory round trips -- ~3.3 k
+            // cycles each on the bench workload -- and the pre-check is one of them: without it the sweep takes 0.85 x the
+            // time (S::RELAX_PRECHECK; round-4 A/B in DESIGN.md section 9).
+            if constexpr (PL_RELAX_PRECHECK && S::RELAX_PRECHECK) {
 #pragma unroll
-            for (int k = 0; k < PL_SWEEP_U; k++) cur[k] = v[k] ? w.dist[nid[k]] : 0u;
+                for (int k = 0; k < PL_SWEEP_U; k++) cur[k] = v[k] ? w.dist[nid[k]] : 0u;
 #pragma unroll
-            for (int k = 0; k < PL_SWEEP_U; k++) v[k] = v[k] && !(cur[k] <= nd[k]);
-#endif
+                for (int k = 0; k < PL_SWEEP_U; k++) v[k] = v[k] && !(cur[k] <= nd[k]);
+            }
 #pragma unroll
             for (int k = 0; k < PL_SWEEP_U; k++) if (v[k]) cur[k] = atomicMin(&w.dist[nid[k]], nd[k]);
 #pragma unroll

@@ -204,6 +204,7 @@ struct PwSharedT {
     int32_t E;
     uint32_t qcount[PL_NQ], qbase[PL_NQ];
     int32_t qover;
+    static constexpr bool RELAX_PRECHECK = true;        // (pl_hquery_miss: sixteen searches per CU, the pre-check load saves atomics)
     uint32_t dF; int64_t idF;
     int32_t hasF;
     int64_t h_cells, h_misses;
