@@ -54,6 +54,7 @@ struct avp_map {
     // planner scratch owned by the handle (problem queue counter etc.)
     void* counters;
     int32_t slice_pops;  // time slice of the group forms in pops (0 = never park a search); avp_plan_set_slice_pops
+    int32_t last_sliced, last_mode;   // what the last planner call on this handle did: time-sliced? which kernel form (avp_plan_last_launch)
 };
 
 extern "C" {
@@ -153,6 +154,7 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
     d.occ = (const uint8_t*)(base + oOcc);
     m->counters = base + oCnt;
     m->slice_pops = PW_SLICE_POPS;
+    m->last_sliced = 0; m->last_mode = 0;
     *out = m;
     return AVP_OK;
 }

@@ -134,6 +134,9 @@ __global__ __launch_bounds__(64 * CHK_WAVES) void check_distance_kernel(DevMap m
     avp_lds_tables_fill<false>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ avp_params sP;                       // the called set-up reads the vehicle constants here
+    // (the host's LDS budget, AVP_LDS_TABLE_BYTES in avp_capi.hip, covers this kernel's STATIC LDS: the sin / cos table + sP)
+    static_assert(sizeof(AVP_SINCOS_TAB) + ((sizeof(avp_params) + 15) & ~(size_t)15) + 16 <= AVP_LDS_TABLE_BYTES,
+                  "check_distance_kernel: static LDS (sincos table + avp_params) exceeds the AVP_LDS_TABLE_BYTES the host budgets for it");
     // carve: [bitmap words][X][Y][per-wave: footprint records 64 * CHK_FPW doubles | queue | hit flags]
     // STAGE: map tables live in LDS; otherwise (map too large for 160 KB) they are read through L1/L2
     uint64_t* lBits = (uint64_t*)smem;

@@ -183,13 +183,19 @@ def deal_slice(n: int, rank: int, world: int):
     return np.concatenate([idx, -np.ones(per - len(idx), np.int64)]), per
 
 
-PAD_POSE = (0.0, 0.0, 0.0)         # padding problem: start == goal, ends at once with status RS_ERROR (rs_curve.py:153)
+PAD_POSE = (0.0, 0.0, 0.0)         # padding of an EMPTY problem list only (nothing to borrow a pose from)
 
 
 def take_padded(starts, goals, idx):
-    """Problems idx (-1 = padding: a start == goal problem, which ends at once with status RS_ERROR)."""
+    """Problems idx (-1 = padding: a start == goal problem, which ends at its first pop with status RS_ERROR,
+    rs_curve.py:153). The padding pose is the list's first goal -- a pose INSIDE the map: the heuristic sweep's lattice
+    set-up walks from the goal to the map's borders before the start == goal shortcut is reached, so a pose far outside
+    (the origin, for a map in UTM-like coordinates) would cost millions of iterations and end as LATTICE instead. Padding
+    results are discarded either way."""
     idx = np.asarray(idx, dtype=np.int64)
-    s_l = np.tile(np.array(PAD_POSE, dtype=np.float64), (len(idx), 1))
+    goals_a = np.asarray(goals, dtype=np.float64).reshape(-1, 3)
+    pad = goals_a[0] if len(goals_a) else np.array(PAD_POSE, dtype=np.float64)
+    s_l = np.tile(pad, (len(idx), 1))
     g_l = s_l.copy()
     keep = idx >= 0
     if keep.any():

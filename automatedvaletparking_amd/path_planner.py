@@ -215,6 +215,9 @@ class BatchPlanner:
             trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
             self.last_lookahead = False
             self.last_time_sliced = False
+            # (the staged stages never park a search; its non-staged fall-back inside the library -- more children than the
+            #  group forms hold -- must not inherit the slice length the handle's previous user left)
+            _native.chk(L.avp_plan_set_slice_pops(self.dm.h, C.c_int32(0)), "avp_plan_set_slice_pops")
             _native.chk(L.avp_plan_batch_staged(self.dm.h, C.c_void_p(starts_t.data_ptr()), C.c_void_p(goals_t.data_ptr()), C.c_int64(n), C.c_int32(slots),
                                                 C.c_int32(self.max_nodes), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()),
                                                 C.c_void_p(paths.data_ptr()) if paths is not None else None, C.c_int32(self.max_path),
@@ -247,8 +250,6 @@ class BatchPlanner:
             if sliced or (self.n_slots and self.time_slice is True):
                 pops = -1 if self.slice_pops is None else int(self.slice_pops)
             _native.chk(L.avp_plan_set_slice_pops(self.dm.h, C.c_int32(pops)), "avp_plan_set_slice_pops")
-        self.last_time_sliced = bool(mode >= 2 and not profile and pops != 0 and slots >= n
-                                     and n > int(L.avp_plan_slots(self.dm.h, C.c_int32(mode))))
         res = self.dm.empty((max(n, 1), C.sizeof(AvpPlanResult)), torch.uint8)
         paths = self.dm.empty((max(n, 1), self.max_path, 4), torch.float64) if want_paths else None
         trace = self.dm.zeros((max(n, 1), max_trace, 11), torch.float64) if max_trace > 0 else None
@@ -269,6 +270,7 @@ class BatchPlanner:
                                             C.c_void_p(look.data_ptr()) if look is not None else None, C.c_int64(look.numel() if look is not None else 0),
                                             C.c_void_p(order.data_ptr()) if order is not None else None), "avp_plan_batch_ex")
         self._keep = (look, order)                          # (alive until the next call: the launch is asynchronous)
+        self.last_time_sliced = bool(int(L.avp_plan_last_launch(self.dm.h)) & 1)      # the library's own report, not a re-derivation
         return res, paths, trace
 
     def plan(self, starts, goals, max_trace: int = 0) -> List[PlanResult]:

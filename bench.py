@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 
 N_SIMD = 256 * 4                # SIMDs on the chip
 CLOCK_GHZ = 2.4                 # max shader clock
 FP64_PEAK_TFLOPS = 78.6         # vector fp64: 256 CUs x 128 flop/clk x 2.4 GHz
-PMC_FILE = "r04_pmc_summary.json"
+PMC_FILE = "r05_pmc_summary.json"
 CASES = os.path.join(ROOT, "data", "BenchmarkCases")
 # the reference's own wall-clock per case (unmodified reference imported in the build container,
 # one Python thread): seconds for PathPlanner() + a_star_plan(); None = did not finish / raises
@@ -477,12 +477,13 @@ def main():
               "frac_hbm_note": "SURVEY 8(d)'s algorithmic bytes (what the REFERENCE formulation reads) per launch time: a throughput-equivalence figure. "
                                "The kernel keeps the map in LDS and replaces the list scans by a pose hash; its physical HBM traffic is `traffic`, "
                                "its bound is fp64 VALU issue (`frac`, `fp64_flops_frac`)",
-              "bound": "valu", "unit": "G SIMD-cycles/s", "peak": N_SIMD * CLOCK_GHZ, "achieved": None, "frac": None, "traffic": None}
+              "hbm_roofline": "n/a (LDS-resident map): `frac` = `frac_valu_busy`, the share of SIMD cycles with a VALU instruction active; the SURVEY 8(d) byte figure is `frac_hbm_algorithmic`",
+              "bound": "valu", "unit": "G SIMD-cycles/s", "peak": N_SIMD * CLOCK_GHZ, "achieved": None, "frac": None, "frac_valu_busy": None, "traffic": None}
         if pmc and not pmc.get("stale") and workload == "c2" and "plan_kernel" in pmc:
             pk = pmc["plan_kernel"]
             # VALU-busy SIMD cycles per launch (SQ_ACTIVE_INST_VALU counts quad-cycles) over THIS run's launch time
             rl["achieved"] = pk["valu_active_simd_cycles_per_launch"] / (kernel_ms * 1e-3) / 1e9
-            rl["frac"] = rl["achieved"] / rl["peak"]
+            rl["frac"] = rl["frac_valu_busy"] = rl["achieved"] / rl["peak"]
             rl["traffic"] = pk.get("hbm_bytes_per_launch_corrected")
             rl["wait_frac"] = pk.get("wait_any_frac")
             if pk.get("f64_valu_wave_insts_per_launch"):
@@ -709,11 +710,12 @@ def main():
                   "hbm_algorithmic_GBps": n_chk * B_cc / (cms * 1e-3) / 1e9,
                   "note": "the reference formulation reads every obstacle point per check (16P+25 B); the kernel keeps the map in LDS and moves 25 B/check of HBM, so its bound is VALU/LDS issue, not HBM",
                   "hbm_traffic_GBps": n_chk * 25 / (cms * 1e-3) / 1e9, "frac_hbm_traffic": n_chk * 25 / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                  "bound": "valu", "unit": "G SIMD-cycles/s", "peak": N_SIMD * CLOCK_GHZ, "achieved": None, "frac": None, "traffic": None}
+                  "hbm_roofline": "n/a (LDS-resident map)",
+                  "bound": "valu", "unit": "G SIMD-cycles/s", "peak": N_SIMD * CLOCK_GHZ, "achieved": None, "frac": None, "frac_valu_busy": None, "traffic": None}
             if pmc and not pmc.get("stale") and "check_distance_kernel" in pmc:
                 ck = pmc["check_distance_kernel"]
                 rc["achieved"] = ck["valu_active_simd_cycles_per_launch"] / (cms * 1e-3) / 1e9
-                rc["frac"] = rc["achieved"] / rc["peak"]
+                rc["frac"] = rc["frac_valu_busy"] = rc["achieved"] / rc["peak"]
                 rc["traffic"] = ck.get("hbm_bytes_per_launch_corrected")
                 rc["lds_busy_frac"] = ck.get("lds_busy_frac")
                 rc["lds_bank_conflict_frac"] = ck.get("lds_bank_conflict_frac")
@@ -739,37 +741,29 @@ def main():
                 out["cpu_baseline"] = {"value": done_cpu / tc, "unit": "plans/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
                                        "sample": f"the first {nb} problems of the headline workload, {passes_cpu} passes, pop cap {cap}, C restatement (oracle/avp_oracle.c, glibc libm), {tc:.1f} s; completed searches only, like `value`",
                                        "all_problems_per_s": n_cpu / tc, "expansions_per_s": pops_cpu / tc}
-                # all host cores, steady state: a work queue over the same problems (shuffled once, cycled) keeps every thread
-                # busy for >= 12 s; in-flight plans are finished and counted, the clock stops when the last one ends
-                import itertools
-                import threading
+                # all host cores, steady state, NO Python in the loop: orc_plan_batch (oracle/avp_oracle.c) -- pthreads, one problem
+                # per thread from an atomic ticket counter cycling over the same problems (shuffled once); in-flight plans are
+                # finished and counted, the clock stops when the last one ends. The same loop on ONE thread gives the scaling.
                 ncore = os.cpu_count() or 1
-                order = np.random.default_rng(0).permutation(nb)
-                feed = itertools.cycle(order.tolist())
-                lock = threading.Lock()
-                tally = {"done": 0, "all": 0, "pops": 0}
-                t2 = time.perf_counter()
-                deadline = t2 + 12.0
-
-                def worker():
-                    while True:
-                        with lock:
-                            if time.perf_counter() >= deadline:
-                                return
-                            i = next(feed)
-                        w = o.plan(g0.starts[i], g0.goals[i], max_trace=1)
-                        with lock:
-                            tally["all"] += 1
-                            tally["done"] += w["status"] in (0, 1)
-                            tally["pops"] += w["n_pops"]
-
-                ths = [threading.Thread(target=worker) for _ in range(ncore)]
-                [t.start() for t in ths]
-                [t.join() for t in ths]
-                tm = time.perf_counter() - t2
-                out["cpu_baseline_all_cores"] = {"value": tally["done"] / tm, "unit": "plans/s", "cores": ncore, "kind": "port", "cpu_model": cpu_model(),
-                                                 "all_problems_per_s": tally["all"] / tm, "expansions_per_s": tally["pops"] / tm,
-                                                 "sample": f"the same {nb} problems, shuffled and cycled through a work queue by {ncore} threads for {tm:.1f} s ({tally['all']} plans): steady state"}
+                order = np.random.default_rng(0).permutation(nb).astype(np.int32)
+                one = o.plan_batch(g0.starts[:nb], g0.goals[:nb], threads=1, min_seconds=5.0, order=order)
+                per_thread = {}
+                for nt, secs in ((ncore, 10.0), (max(1, ncore // 2), 6.0)):
+                    if nt in per_thread:
+                        continue
+                    bb = o.plan_batch(g0.starts[:nb], g0.goals[:nb], threads=nt, min_seconds=secs, order=order)
+                    per_thread[nt] = {"plans_per_s": bb["completed"] / bb["seconds"], "all_problems_per_s": bb["plans"] / bb["seconds"],
+                                      "expansions_per_s": bb["pops"] / bb["seconds"], "seconds": bb["seconds"], "plans": bb["plans"]}
+                best_nt = max(per_thread, key=lambda k: per_thread[k]["expansions_per_s"])
+                bt = per_thread[best_nt]
+                one_exp = one["pops"] / one["seconds"]
+                out["cpu_baseline_all_cores"] = {"value": bt["plans_per_s"], "unit": "plans/s", "cores": best_nt, "kind": "port", "cpu_model": cpu_model(),
+                                                 "all_problems_per_s": bt["all_problems_per_s"], "expansions_per_s": bt["expansions_per_s"],
+                                                 "one_thread_same_loop": {"plans_per_s": one["completed"] / one["seconds"], "expansions_per_s": one_exp, "seconds": one["seconds"]},
+                                                 "scaling_vs_1core": bt["expansions_per_s"] / one_exp if one_exp else None,
+                                                 "by_thread_count": {str(k): v for k, v in per_thread.items()},
+                                                 "gpu_over_cpu_all_cores_expansions": head["expansions_per_s"] / bt["expansions_per_s"] if bt["expansions_per_s"] else None,
+                                                 "sample": f"the same {nb} problems, shuffled once and cycled by an atomic ticket counter over {best_nt} pthreads (orc_plan_batch, no Python in the loop) for {bt['seconds']:.1f} s ({bt['plans']} plans): steady state; hardware threads on the host: {ncore}"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

@@ -240,6 +240,10 @@ int32_t avp_plan_slots(avp_map* map, int32_t mode);
  */
 #define AVP_PLAN_UNFINISHED (-1)
 int32_t avp_plan_set_slice_pops(avp_map* map, int32_t pops);
+/* What the last planner call on this handle launched (the library's own decision -- mode 0 may fall back to the workgroup
+ * form, a group-form launch slices only under the conditions above): bit 0 = the group-form launch time-sliced its
+ * searches, bits 8 .. 15 = the kernel form that ran (1 .. 4; 16 = the staged call). No reference counterpart. */
+int32_t avp_plan_last_launch(avp_map* map);
 int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the kernel form: slot counts are multiples of it (mode 1: 1) */
 
 /*

@@ -1425,3 +1425,100 @@ ORC_API int orc_rasterize_edges(const double *xs, const double *ys, int nx, int 
     }
     return multi;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* All-core CPU baseline (bench.py's cpu_baseline_all_cores leg; tests/test_oracle_batch.py): the same orc_plan, one     */
+/* problem per thread drawn from an atomic ticket counter, no Python in the loop. Two modes:                            */
+/*   min_seconds <= 0 : ONE pass over the n problems; status[i] / pops[i] of every problem are written.                 */
+/*   min_seconds  > 0 : steady state -- tickets cycle over the problems (ticket % n, in the caller's `order` when given) */
+/*                      until the deadline; plans in flight are finished and counted, the clock stops when the last one  */
+/*                      ends; status / pops hold the LAST result of each problem that was planned.                       */
+/* totals = { plans, completed (status 0 or 1), pops }; *elapsed = wall seconds from the first ticket to the last plan.  */
+/* orc_plan keeps no mutable global state (g_restated / g_dij_reheap are read only while it runs), so the threads share  */
+/* nothing but the read-only context, the counter and glibc's per-thread malloc arenas.                                  */
+#include <pthread.h>
+#include <stdatomic.h>
+#include <time.h>
+
+typedef struct {
+    const orc_ctx *c; const double *starts, *goals; const int32_t *order;
+    int64_t n; double deadline; int steady;
+    atomic_llong ticket; atomic_llong plans, completed, pops;
+    int32_t *status; int64_t *pops_out;
+} orc_batch_t;
+
+static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+static void *orc_batch_worker(void *arg)
+{
+    orc_batch_t *b = (orc_batch_t *)arg;
+    enum { MAXP = 1024 };
+    double *ap = malloc(sizeof(double) * MAXP * 3), *rp = malloc(sizeof(double) * MAXP * 3), *fp = malloc(sizeof(double) * MAXP * 3);
+    int8_t *rd = malloc(MAXP);
+    for (;;) {
+        if (b->steady && orc_now() >= b->deadline) break;
+        const long long t = atomic_fetch_add(&b->ticket, 1);
+        if (!b->steady && t >= b->n) break;
+        int64_t i = t % b->n;
+        if (b->order) i = b->order[i];
+        orc_plan_out out;
+        orc_plan(b->c, b->starts + 3 * i, b->goals + 3 * i, &out, NULL, 0, ap, rp, rd, fp, MAXP, NULL, NULL, 0);
+        if (b->status) b->status[i] = out.status;
+        if (b->pops_out) b->pops_out[i] = out.n_pops;
+        atomic_fetch_add(&b->plans, 1);
+        atomic_fetch_add(&b->completed, (out.status == 0 || out.status == 1) ? 1 : 0);
+        atomic_fetch_add(&b->pops, out.n_pops);
+    }
+    free(ap); free(rp); free(fp); free(rd);
+    return NULL;
+}
+
+ORC_API int32_t orc_plan_batch(const orc_ctx *c, const double *starts, const double *goals, int64_t n, int32_t threads,
+                               double min_seconds, const int32_t *order, int32_t *status, int64_t *pops,
+                               int64_t totals[3], double *elapsed)
+{
+    if (!c || n <= 0 || threads <= 0 || !starts || !goals) return -1;
+    orc_batch_t b;
+    b.c = c; b.starts = starts; b.goals = goals; b.order = order; b.n = n;
+    b.steady = min_seconds > 0.0; b.status = status; b.pops_out = pops;
+    atomic_init(&b.ticket, 0); atomic_init(&b.plans, 0); atomic_init(&b.completed, 0); atomic_init(&b.pops, 0);
+    pthread_t *th = malloc(sizeof(pthread_t) * (size_t)threads);
+    const double t0 = orc_now();
+    b.deadline = t0 + min_seconds;
+    int started = 0;
+    for (int k = 0; k < threads; k++) { if (pthread_create(&th[k], NULL, orc_batch_worker, &b) != 0) break; started++; }
+    for (int k = 0; k < started; k++) pthread_join(th[k], NULL);
+    const double t1 = orc_now();
+    free(th);
+    if (totals) { totals[0] = atomic_load(&b.plans); totals[1] = atomic_load(&b.completed); totals[2] = atomic_load(&b.pops); }
+    if (elapsed) *elapsed = t1 - t0;
+    return started;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Is this host's libm the one the device restates (glibc 2.35, x86-64 FMA variants)? Compares the platform's atan2 /     */
+/* asin / acos / tan / pow(v, 2) with include/avp_libm.h on n pseudo-random arguments each (the Reeds-Shepp argument      */
+/* shapes) and returns the number of results that differ in any bit. oracle.device_arithmetic() runs it once per process: */
+/* on a host with another glibc the GPU parity tests must compare against the RESTATED mode, which is what the device     */
+/* implements by specification, instead of failing although the device follows its spec.                                  */
+ORC_API int64_t orc_libm_selfcheck(int64_t n, uint64_t seed)
+{
+    uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ULL;
+    int64_t bad = 0;
+    #define ORC_RND() (s ^= s << 13, s ^= s >> 7, s ^= s << 17, (double)(s >> 11) * (1.0 / 9007199254740992.0))
+    #define ORC_NE(a, b) (memcmp(&(double){ a }, &(double){ b }, 8) != 0 && !((a) != (a) && (b) != (b)))
+    for (int64_t i = 0; i < n; i++) {
+        const double u = 20.0 * ORC_RND() - 10.0, v = 20.0 * ORC_RND() - 10.0, w = 2.0 * ORC_RND() - 1.0;
+        const double t = 4.0 * 3.14159265358979323846 * ORC_RND() - 2.0 * 3.14159265358979323846;
+        double a, b;
+        a = atan2(u, v); b = avp_atan2(u, v); bad += ORC_NE(a, b);
+        a = atan2(2.0, u); b = avp_atan2(2.0, u); bad += ORC_NE(a, b);
+        a = asin(w); b = avp_asin(w); bad += ORC_NE(a, b);
+        a = acos(w); b = avp_acos(w); bad += ORC_NE(a, b);
+        a = tan(t); b = avp_tan(t); bad += ORC_NE(a, b);
+        a = pow(u, 2.0); b = avp_pow2(u); bad += ORC_NE(a, b);
+    }
+    #undef ORC_RND
+    #undef ORC_NE
+    return bad;
+}

@@ -1,7 +1,8 @@
 // Cost of the scalar libm calls of the Reeds-Shepp words under load: every lane runs a chain of dependent calls on
 // lane-varying arguments, WAVES waves per CU on every CU; reports wave-nanoseconds per call (= time x waves / calls).
 // Variants of where glibc's uatan.tbl rows live (compile-time, -DVAR=k):
-//   0 old double-double atan2 (rounds 1-3)     1 glibc, table in global memory, 7-word rows
+//   (0: the rounds-1-3 double-double atan2 -- removed with its header in round 5; its figures are in profiles/r04_libm_microbench.txt)
+//   1 glibc, table in global memory, 7-word rows
 //   2 glibc, table in LDS, 7-word rows         3 glibc, global, rows padded to 8 words (64 B, dwordx4 loads)
 //   4 glibc, LDS, rows padded to 8 words
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DVAR=1 -I include scripts/microbench/libm_variants.hip -o /tmp/lv1
@@ -12,14 +13,7 @@
 #define VAR 1
 #endif
 #if VAR == 0
-#define AVP_LIBM_TAB static __device__ const
-#define AVP_LIBM_FN __device__ static inline
-#include "old/avp_libm_old.h"
-#define F_ATAN2 old_atan2
-#define F_ASIN old_asin
-#define F_ACOS old_acos
-#define F_TAN old_tan
-#define F_POW2(v) ((v) * (v))
+#error "VAR 0 (the rounds-1-3 libm) was removed in round 5"
 #else
 #if VAR == 2
 __shared__ uint64_t CIJ_LDS[241 * 7];
@@ -52,9 +46,7 @@ __global__ void fill_pad()
 template <int WHICH>
 __global__ void probe(double seed, double* sink)
 {
-#if VAR == 0 && defined(__HIP_DEVICE_COMPILE__)
-    for (int i = threadIdx.x; i < 130; i += blockDim.x) (&OLD_ATAN_LDS[0][0])[i] = (&AVP_ATAN_TAB[0][0])[i];
-#elif VAR == 2
+#if VAR == 2
     for (int i = threadIdx.x; i < 241 * 7; i += blockDim.x) CIJ_LDS[i] = AVP_G_CIJ[i];
 #elif VAR == 4
     for (int i = threadIdx.x; i < 241 * 7; i += blockDim.x) CIJ_LDS8[i / 7].w[i % 7] = AVP_G_CIJ[i];

@@ -74,6 +74,34 @@ def c4_poses(m, n=4096):
     return poses, rng
 
 
+def c4_stress_poses(m, o, n=4096, seed=44):
+    """A second config[3] pose set that stresses the checkers instead of their early exit: the spec'd sampler (c4_poses,
+    kept for the bench line) draws 99.5 % colliding poses on this map. Here, from 16 n uniform candidates classified by the
+    ORACLE's distance checker (collision flag + number of obstacle points under the footprint's AABB,
+    collision_check.py:55-69): 15 % near misses (collision free with the most near points: every one of them goes through
+    the exact point test and none ends the pose early), 30 % other collision-free poses, 55 % colliding ones, shuffled.
+    -> (poses, dict of the fractions)."""
+    rng = np.random.default_rng(seed)
+    k = 16 * n
+    cand = np.stack([rng.uniform(m.boundary[0] + 1, m.boundary[1] - 1, k), rng.uniform(m.boundary[2] + 1, m.boundary[3] - 1, k),
+                     rng.uniform(-np.pi, np.pi, k)], 1)
+    hit, near = o.check_batch(cand, kind=0, want_near=True)
+    hit = np.asarray(hit).astype(bool)
+    free_idx = np.where(~hit)[0]
+    n_nm, n_free = (15 * n) // 100, (30 * n) // 100
+    assert len(free_idx) >= n_nm + n_free, "not enough collision-free candidates"
+    by_near = free_idx[np.argsort(-near[free_idx], kind="stable")]
+    nm = by_near[:n_nm]
+    rest = by_near[n_nm:]
+    other = rest[rng.permutation(len(rest))[:n_free]]
+    coll = np.where(hit)[0][:n - n_nm - n_free]
+    sel = np.concatenate([nm, other, coll])
+    sel = sel[rng.permutation(len(sel))]
+    info = dict(free_frac=float((~hit[sel]).mean()), near_miss_frac=n_nm / len(sel), near_miss_min_near_points=int(near[nm].min()),
+                near_miss_mean_near_points=float(near[nm].mean()), colliding_frac=float(hit[sel].mean()))
+    return cand[sel], info
+
+
 def c5_problems(cfg, n=1024):
     """C5: parking lot (2 x 60 cars, one empty bay = goal), n starts in the aisle (seed 5), flag_radius 1e9 so that
     the Reeds-Shepp shot runs at every pop."""

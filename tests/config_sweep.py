@@ -76,6 +76,15 @@ def main():
             w = np.asarray(o.check_batch(poses, kind=kind)).astype(bool)
             out[name + "_identical"] = int((g == w).sum())
             out[name + "_colliding"] = int(g.sum())
+            out[name + "_colliding_frac"] = float(g.mean())
+        # the stress set (tests/_configs.c4_stress_poses): >= 30 % collision-free, 15 % near misses
+        stress, sinfo = _configs.c4_stress_poses(m, o, 4096)
+        for kind, name in ((0, "distance"), (1, "circle")):
+            g = np.asarray(dm.check_batch(stress, kind=kind)).astype(bool)
+            w = np.asarray(o.check_batch(stress, kind=kind)).astype(bool)
+            out["stress_" + name + "_identical"] = int((g == w).sum())
+            out["stress_" + name + "_colliding_frac"] = float(g.mean())
+        out["stress_set"] = sinfo
         st, go = free_pairs(m, dm, 256, rng)
         res, ok, tg, tc = plan_and_compare(m, veh, cfg, st, go, a.cap, a.threads)
         print(json.dumps(dict(config="C4: synthetic %dx%d grid, %d polygons (P=%d points), 4096-pose check batch + 256 plans" %

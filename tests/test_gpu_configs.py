@@ -39,6 +39,15 @@ def test_c4_full(vehicle, cfg):
         w = np.asarray(o.check_batch(poses, kind=kind)).astype(bool)
         assert np.array_equal(g, w), (kind, int((g != w).sum()))
         assert 0 < g.sum() < len(g)
+    # the spec'd sampler collides 99.5 % of its poses on this map (an early-exit test): a second set with >= 30 % collision-free
+    # and >= 10 % near-miss poses (free, with the most obstacle points under the footprint's AABB) for both checkers
+    stress, info = C.c4_stress_poses(m, o, 4096)
+    assert len(stress) == 4096 and info["free_frac"] >= 0.30 and info["near_miss_frac"] >= 0.10 and info["near_miss_min_near_points"] >= 8, info
+    for kind in (0, 1):
+        g = np.asarray(dm.check_batch(stress, kind=kind)).astype(bool)
+        w = np.asarray(o.check_batch(stress, kind=kind)).astype(bool)
+        assert np.array_equal(g, w), ("stress", kind, int((g != w).sum()))
+    assert abs(float(np.asarray(dm.check_batch(stress, kind=0)).astype(bool).mean()) - info["colliding_frac"]) < 1e-12
     st, go = C.free_pairs(m, dm, 256, rng)
     res, bad, _, _ = C.plan_and_compare(m, vehicle, cfg, st, go)
     assert len(res) == 256 and not bad, (len(bad), bad[:8])
