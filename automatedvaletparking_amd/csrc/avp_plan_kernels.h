@@ -269,7 +269,7 @@ struct PlChkEnv {
     double b0, dx, b2, dy;
     double fp_xr, fp_xf, fp_yr, fp_yl;                // inflated footprint (map/costmap.py:97-101)
     double circ_rd, circ_cf, circ_cr;                 // two-circle model (collision_check.py:92-98)
-    uint32_t lX, lY, lBits, pad;                      // LDS addresses of the staged tables (STAGE)
+    uint32_t lX, lY, lBits, maybe_wide;               // LDS addresses of the staged tables (STAGE); maybe_wide: a footprint's AABB can span > 64 map columns or > 2 bitmap words of rows on this map
     const double* gX; const double* gY; const uint64_t* gBits;   // ... or the tables in HBM / L2
 };
 // the map tables as a collision pass reads them: LDS copies (STAGE) or through L1 / L2
@@ -289,7 +289,13 @@ __device__ __forceinline__ void pl_chk_env_fill(PlChkEnv& e, const DevMap& m, co
     e.fp_xr = p.fp_xr; e.fp_xf = p.fp_xf; e.fp_yr = p.fp_yr; e.fp_yl = p.fp_yl;
     e.circ_rd = p.circ_rd; e.circ_cf = p.circ_cf; e.circ_cr = p.circ_cr;
     e.lX = lX ? (uint32_t)(uintptr_t)(AVP_LDS const void*)lX : 0u; e.lY = lY ? (uint32_t)(uintptr_t)(AVP_LDS const void*)lY : 0u;
-    e.lBits = lBits ? (uint32_t)(uintptr_t)(AVP_LDS const void*)lBits : 0u; e.pad = 0;
+    e.lBits = lBits ? (uint32_t)(uintptr_t)(AVP_LDS const void*)lBits : 0u;
+    {
+        // an AABB is at most the inflated rectangle's diagonal wide and tall (+ 1 node for the inclusive ends, + 1 for the grid's
+        // phase): below 62 cells on both axes no pose of this map ever needs more than 64 columns or two 64-row bitmap words
+        const double diag = sqrt((p.fp_xf - p.fp_xr) * (p.fp_xf - p.fp_xr) + (p.fp_yl - p.fp_yr) * (p.fp_yl - p.fp_yr));
+        e.maybe_wide = (diag / m.dx + 3.0 < 64.0 && diag / m.dy + 3.0 < 64.0) ? 0u : 1u;
+    }
     e.gX = m.X; e.gY = m.Y; e.gBits = m.colBits;
 }
 
@@ -387,7 +393,7 @@ struct PlWaveChkT {
     uint32_t hit[PL_WPOSE];
     double pose[PL_WPOSE][5];         // x, y, theta, cos, sin of the poses of the pass (staged by the caller)
     int32_t qn, over;
-    uint32_t q[QCAP];                 // pose << 24 | ix << 12 | iy   (nx, ny < 4096 on this path)
+    uint32_t q[QCAP];                 // pose << 26 | ix << 13 | iy   (PL_WPOSE <= 8 poses; nx, ny <= 8191: avp_map_create's limit)
 };
 typedef PlWaveChkT<PL_WQCAP> PlWaveChk;
 
@@ -425,6 +431,7 @@ struct PlShared {
     DevMap km; avp_params kp; PlanDims kdims; PlanWs kw; PlLook klook;
     const double* k_starts; const double* k_goals; avp_plan_result_dev* k_results; double* k_paths; int32_t k_max_path, k_pad;
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
+    double cn_th; int32_t cn_forward, cn_index;   // the popped node as the called resolution reads it (plk_resolve_fast)
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
@@ -1184,6 +1191,69 @@ AVP_D int pl_rs_sample_book(S& s, const avp_params& p)
     s.smp_hi = hi;
     return 0;
 }
+// The same bookkeeping by a WHOLE WAVE (plan_kernel's wave 0, round 5). The chain pd += d is serial -- repeated floating-point
+// addition does not parallelise bit for bit -- but what the one-lane loop above spends per entry is mostly not the addition:
+// an address, two LDS stores, a compare and a branch per sample (9.1 k cycles for <= 76 samples on the critical path of a
+// long pop, profiles/r04_plan_kernel_phase_cycles.json). Here every lane runs the chain in registers, EIGHT steps per trip:
+// eight dependent additions, eight independent compares, the eight values stored at once behind one address (values past
+// the segment's end land on indices that a LATER write of this function overwrites, or beyond smp_hi, which nobody reads:
+// generate_local_course's own "later writes win" order), and smp_seg is not written in the loop at all -- segment j
+// always starts writing at the index segment j - 1 ended on, so the owner of index i is the number of segment starts
+// a_1 .. a_{n-1} that are <= i, filled in by all lanes afterwards. Same smp_l / smp_seg / smp_hi / smp_point_num.
+#ifndef PL_BOOK_WAVE
+#define PL_BOOK_WAVE 1
+#endif
+template <class S>
+AVP_D int pl_rs_sample_book_wave(S& s, const avp_params& p)
+{
+    const int lane = threadIdx.x & 63;
+    const double step = 0.5 * p.maxc;
+    const int n = s.rs.n;
+    double lr[AVP_RS_MAXSEG];
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) lr[i] = s.rs.l[i];
+    const int point_num = (int)(s.rs.L / step) + n + 3;
+    if (lane == 0) { s.smp_point_num = point_num; s.smp_hi = 0; }
+    if (point_num > S::RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) return 5;
+    int ind = 1, hi = 0;
+    double d = lr[0] > 0.0 ? step : -step;
+    double pd = d, ll = 0.0;
+    int a1 = 0x7fffffff, a2 = 0x7fffffff, a3 = 0x7fffffff, a4 = 0x7fffffff;      // first index written by segments 1 .. 4
+#pragma unroll
+    for (int i = 0; i < AVP_RS_MAXSEG; i++) {
+        if (i < n) {
+            const double l = lr[i], al = fabs(l);
+            d = l > 0.0 ? step : -step;
+            ind -= 1;
+            if (i >= 1 && (lr[i >= 1 ? i - 1 : 0] * l) > 0) pd = -d - ll; else pd = d - ll;
+            if (i == 1) a1 = ind + 1; else if (i == 2) a2 = ind + 1; else if (i == 3) a3 = ind + 1; else if (i == 4) a4 = ind + 1;
+            for (;;) {
+                const double p1 = pd, p2 = p1 + d, p3 = p2 + d, p4 = p3 + d, p5 = p4 + d, p6 = p5 + d, p7 = p6 + d, p8 = p7 + d;
+                const bool o1 = fabs(p1) <= al, o2 = o1 && fabs(p2) <= al, o3 = o2 && fabs(p3) <= al, o4 = o3 && fabs(p4) <= al,
+                           o5 = o4 && fabs(p5) <= al, o6 = o5 && fabs(p6) <= al, o7 = o6 && fabs(p7) <= al, o8 = o7 && fabs(p8) <= al;
+                const int c = (int)o1 + (int)o2 + (int)o3 + (int)o4 + (int)o5 + (int)o6 + (int)o7 + (int)o8;
+                if (lane == 0) {
+                    double* q = &s.smp_l[ind + 1];
+                    if (ind + 8 < S::RS_CAP) { q[0] = p1; q[1] = p2; q[2] = p3; q[3] = p4; q[4] = p5; q[5] = p6; q[6] = p7; q[7] = p8; }
+                    else {                                  // (the end of the buffer: the entries that count, no more)
+                        if (o1) q[0] = p1; if (o2) q[1] = p2; if (o3) q[2] = p3; if (o4) q[3] = p4;
+                        if (o5) q[4] = p5; if (o6) q[5] = p6; if (o7) q[6] = p7; if (o8) q[7] = p8;
+                    }
+                }
+                ind += c;
+                if (!o8) { pd = !o1 ? p1 : !o2 ? p2 : !o3 ? p3 : !o4 ? p4 : !o5 ? p5 : !o6 ? p6 : !o7 ? p7 : p8; break; }
+                pd = p8 + d;
+            }
+            ll = l - pd - d;
+            ind += 1;
+            if (lane == 0) s.smp_l[ind] = l;
+            if (ind > hi) hi = ind;
+        }
+    }
+    for (int i = lane; i <= hi; i += 64) s.smp_seg[i] = (int8_t)((int)(i >= a1) + (int)(i >= a2) + (int)(i >= a3) + (int)(i >= a4));
+    if (lane == 0) s.smp_hi = hi;
+    return 0;
+}
 template <class S>
 AVP_D void pl_rs_sample_origins(S& s, const avp_params& p)
 {
@@ -1269,10 +1339,57 @@ __device__ __noinline__ void pl_check_narrow(AVP_LDS const PlChkEnv* envp, AVP_L
     const int qn = wcp->qn;
     for (int e = lane; e < qn; e += 64) {
         const uint32_t ent = wcp->q[e];
-        const int i = ent >> 24, ix = (ent >> 12) & 0xfff, iy = ent & 0xfff;
+        const int i = ent >> 26, ix = (ent >> 13) & 0x1fff, iy = ent & 0x1fff;
         if (wcp->hit[i]) continue;
         const bool h = FAST ? avp_footprint_point_hit(wcp->fp[i], mt.X[ix], mt.Y[iy]) : avp_footprint_point_hit_exact(wcp->fp[i], mt.X[ix], mt.Y[iy]);
         if (h) wcp->hit[i] = 1;
+    }
+}
+
+// The gather of a pass whose footprints span more than 64 map columns or more than two bitmap words of rows (fine maps:
+// map_discrete_size 0.05 -> a diagonal of 107 cells; the default maps never come here). A called function of its own: its
+// loops' registers stay out of pl_check_pass. Lane c owns columns ixlo + c, ixlo + c + 64, ... of every pose of the range
+// [lo, hi), all words of the row range; the same two walks (count, reserve queue room with one atomic, write), the same
+// queue order within a (pose, column).
+template <bool STAGE, int QCAP>
+__device__ __noinline__ void pl_check_gather_wide(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp, int lo, int hi)
+{
+    const PlChkEnv& env = *(const PlChkEnv*)envp;
+    PlWaveChkT<QCAP>& wc = *(PlWaveChkT<QCAP>*)wcp;
+    const PlTabs<STAGE> mt(env);
+    const int lane = threadIdx.x & 63;
+    const int wpc = env.wpc;
+    int tot = 0;
+#pragma nounroll
+    for (int i = lo; i < hi; i++) {
+        const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
+        if (iylo > iyhi) continue;
+        const int w0 = iylo >> 6, w1 = iyhi >> 6;
+        for (int ix = ixlo + lane; ix <= ixhi; ix += 64)
+            for (int w = w0; w <= w1; w++) {
+                uint64_t b = mt.bits[(size_t)ix * wpc + w];
+                if (w == w0) b &= ~0ull << (iylo & 63);
+                if (w == w1) b &= ~0ull >> (63 - (iyhi & 63));
+                tot += __popcll(b);
+            }
+    }
+    int pos = tot ? atomicAdd(&wc.qn, tot) : 0;
+    if (pos + tot > QCAP) { if (tot) wc.over = 1; return; }
+    if (!tot) return;
+#pragma nounroll
+    for (int i = lo; i < hi; i++) {
+        const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
+        if (iylo > iyhi) continue;
+        const int w0 = iylo >> 6, w1 = iyhi >> 6;
+        for (int ix = ixlo + lane; ix <= ixhi; ix += 64) {
+            const uint32_t tag = ((uint32_t)i << 26) | ((uint32_t)ix << 13);
+            for (int w = w0; w <= w1; w++) {
+                uint64_t b = mt.bits[(size_t)ix * wpc + w];
+                if (w == w0) b &= ~0ull << (iylo & 63);
+                if (w == w1) b &= ~0ull >> (63 - (iyhi & 63));
+                while (b) { const int bpos = __ffsll((unsigned long long)b) - 1; b &= b - 1; wc.q[pos++] = tag | (uint32_t)((w << 6) + bpos); }
+            }
+        }
     }
 }
 
@@ -1346,22 +1463,31 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
     // room for them with ONE atomic, then walks the words again and writes them -- one atomic per range instead of
     // one per pose, and no per-pose words kept in registers between the two walks. The range is the whole pass; when
     // its candidates do not fit the queue it is halved (dense clutter), down to single poses.
+    // (uniform: the ranges come from LDS) does a pose of the pass span more than 64 map columns or more than two bitmap
+    // words of rows? Then the pass takes the general walk below: any number of column chunks and words per pose -- fine maps
+    // (map_discrete_size 0.05: the footprint's diagonal spans 107 cells) and tall footprints. The default maps never do.
+    bool wide = false;
+    if (env.maybe_wide) {                                 // (a per-map constant: the default maps never look)
+        int wide_v = 0;
+#pragma nounroll
+        for (int i = 0; i < count; i++)
+            if (wc.rng[i][2] <= wc.rng[i][3] && (wc.rng[i][1] - wc.rng[i][0] >= 64 || (wc.rng[i][3] >> 6) - (wc.rng[i][2] >> 6) > 1)) wide_v = 1;
+        wide = __builtin_amdgcn_readfirstlane(wide_v) != 0;
+    }
     const int wpc = env.wpc;
     int lo = 0, span = count;
     while (lo < count) {
         const int hi = min(lo + span, count);
         if (lane == 0) { wc.qn = 0; wc.over = 0; }
         wave_sync();
-        {
+        if (!wide) {
             int tot = 0;
-            bool wide = false;
 #pragma unroll
             for (int i = 0; i < PL_WPOSE; i++) {
                 if (i >= lo && i < hi) {
                     const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
                     if (iylo <= iyhi && lane <= ixhi - ixlo) {
                         const int ix = ixlo + lane, w0 = iylo >> 6, w1 = iyhi >> 6;
-                        if (w1 - w0 > 1) wide = true;                 // (cannot happen under avp_plan_batch's guard; handled by the fallback)
                         uint64_t x0 = mt.bits[(size_t)ix * wpc + w0] & (~0ull << (iylo & 63));
                         if (w1 == w0) x0 &= ~0ull >> (63 - (iyhi & 63));
                         const uint64_t x1 = w1 > w0 ? (mt.bits[(size_t)ix * wpc + w1] & (~0ull >> (63 - (iyhi & 63)))) : 0ull;
@@ -1370,7 +1496,7 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
                 }
             }
             int pos = tot ? atomicAdd(&wc.qn, tot) : 0;
-            if (wide || pos + tot > QCAP) { if (tot || wide) wc.over = 1; }
+            if (pos + tot > QCAP) { if (tot) wc.over = 1; }
             else if (tot) {
 #pragma nounroll
                 for (int i = lo; i < hi; i++) {
@@ -1379,14 +1505,14 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
                         const int ix = ixlo + lane, w0 = iylo >> 6, w1 = iyhi >> 6;
                         uint64_t bits = mt.bits[(size_t)ix * wpc + w0] & (~0ull << (iylo & 63));
                         if (w1 == w0) bits &= ~0ull >> (63 - (iyhi & 63));
-                        const uint32_t tag = ((uint32_t)i << 24) | ((uint32_t)ix << 12);
+                        const uint32_t tag = ((uint32_t)i << 26) | ((uint32_t)ix << 13);
                         while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)((w0 << 6) + bpos); }
                         bits = w1 > w0 ? (mt.bits[(size_t)ix * wpc + w1] & (~0ull >> (63 - (iyhi & 63)))) : 0ull;
                         while (bits) { const int bpos = __ffsll((unsigned long long)bits) - 1; bits &= bits - 1; wc.q[pos++] = tag | (uint32_t)(((w0 + 1) << 6) + bpos); }
                     }
                 }
             }
-        }
+        } else pl_check_gather_wide<STAGE, QCAP>(envp, wcp, lo, hi);
         wave_sync();
         if (wc.over) {
             if (hi - lo > 1) { span = (hi - lo + 1) >> 1; continue; }
@@ -1919,6 +2045,202 @@ __device__ __noinline__ void plk_write_result(AVP_LDS PlShared* sp, int64_t pid,
     pl_write_result<PROFILE>(s.kp, s.kw, s, s.k_travel_ddt, s.k_dth_ddt, s.k_results, s.k_paths, s.k_max_path, pid, n_pops, slot, t_fin);
 }
 
+// the child resolution on wave 0 and its writer wave as CALLED functions (round 5): inlined -- the resolution at two sites -- they
+// held the lookahead instantiation at 256 VGPRs with two dozen spill slots. They read the popped node's three fields the
+// resolution needs (heading, gear, index) and every kernel argument through PlShared's LDS copies.
+#ifndef PL_RESOLVE_CALL
+#define PL_RESOLVE_CALL 1
+#endif
+template <bool PROFILE>
+__device__ __noinline__ void plk_resolve_fast(AVP_LDS PlShared* sp, int nchild, int pop_ahead, int split)
+{
+    PlShared& s = *(PlShared*)sp;
+    PlNode cn;
+    cn.th = s.cn_th; cn.forward = (int8_t)s.cn_forward; cn.index = s.cn_index;
+    pl_resolve_fast_wave<PROFILE>(s.km, s.kp, s.kw, s, s.kdims, cn, nchild, pop_ahead != 0, split != 0);
+}
+__device__ __noinline__ void plk_resolve_writer(AVP_LDS PlShared* sp, int nchild)
+{
+    PlShared& s = *(PlShared*)sp;
+    PlNode cn;
+    cn.index = s.cn_index;
+    pl_resolve_writer_wave(s.kp, s.kw, s, s.kdims, cn, nchild);
+}
+// one step of the SLOW path of the child resolution (expand_node :153-232 in child order, ONE thread; it stops where a
+// heuristic query misses the closed frontier and the workgroup has to extend the sweep). A called function: the rare path's
+// registers stay out of the pop loop.
+__device__ __noinline__ void plk_resolve_slow_step(AVP_LDS PlShared* sp, int nchild, int32_t maxNodes)
+{
+    PlShared& s = *(PlShared*)sp;
+    const DevMap& m = s.km;
+    const avp_params& p = s.kp;
+    const PlanWs& w = s.kw;
+    const PlanDims& dims = s.kdims;
+    PlNode cn;
+    cn.th = s.cn_th; cn.forward = (int8_t)s.cn_forward; cn.index = s.cn_index;
+    s.need_sweep = 0;
+    int i = s.next_child;
+    for (; i < nchild && s.status == 0; i++) {
+        const PlChild c = s.child[i];
+        const int si = i % p.n_steer;
+        const int is_forward = i < p.n_steer ? 1 : 0;
+        const bool found_closed = c.found >= 0 && c.found_state == 2;
+        if (s.closed_nonempty && (found_closed || c.oob)) continue;          // :155-165
+        const bool found_open = c.found >= 0 && c.found_state == 1;
+        if (!found_open && c.first_coll != 0x7fffffff) {
+            s.n_checks += c.first_coll + 1;
+            if (s.nnodes >= maxNodes) { s.status = 5; break; }
+            const int32_t pos = s.nnodes++;
+            PlNode& nd = w.nodes[pos];
+            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = 0; nd.h = 0; nd.f = 0;
+            nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+            nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
+            pl_hash_put(w, dims.hashCap, pos);
+            s.nclosed++; s.closed_nonempty = 1;
+            continue;
+        }
+        // heuristic query (hit: answered here; miss: hand over to the workgroup)
+        uint32_t hd;
+        if (s.have_d) { hd = s.hq_d; s.have_d = 0; }
+        else if (!pl_hquery_hit(m, s, c.id, c.pre_d, hd)) { s.pending_id = c.id; s.need_sweep = 1; break; }
+        if (hd == PL_UNSEEN) { if (!found_open) s.n_checks += p.n_sub; s.status = s.qover ? 5 : 2; break; }
+        s.n_rs += 1;
+        if (c.rs_err) { s.status = c.rs_err == 4 ? 5 : 3; break; }
+        const double hv1 = (double)hd / 100, hv2 = c.L;
+        const double hval = hv2 > hv1 ? hv2 : hv1;
+        if (!found_open) {
+            s.n_checks += p.n_sub;
+            if (s.nnodes >= maxNodes) { s.status = 5; break; }
+            const double g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
+            const int32_t pos = s.nnodes++;
+            PlNode& nd = w.nodes[pos];
+            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = g; nd.h = hval; nd.f = g + hval;
+            nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
+            nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
+            pl_heap_push(w, s, (uint32_t)pos, g + hval);
+            pl_hash_put(w, dims.hashCap, pos);
+        } else {
+            PlNode& ch = w.nodes[c.found];
+            const double new_g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
+            const double new_f = hval + new_g;
+            if (new_f < ch.f) {
+                ch.f = new_f; ch.g = new_g; ch.h = hval;
+                pl_heap_set_key(w, s, PlShared::HEAP_POS ? ch.heap_pos : pl_heap_find(w, s, s.nheap, (uint32_t)c.found), new_f);
+                ch.parent_index = cn.index; ch.parent_pos = s.cur;
+                ch.forward = (int8_t)is_forward; ch.steer_i = (int8_t)si;
+            }
+        }
+    }
+    s.next_child = i;
+}
+// a helper publishes its half of an expansion record: payload, then the half's ready bit (one wave; a called function)
+__device__ __noinline__ void plk_look_publish(AVP_LDS PlShared* sp, int32_t maxNodes, int nchild, int hS, int in_radius)
+{
+    PlShared& s = *(PlShared*)sp;
+    const PlLook& look = s.klook;
+    const int lane = threadIdx.x & 63;
+    const bool hC = !hS;
+    const unsigned long long j0 = s.job[0];
+    const size_t ri = pl_look_idx(PL_JOB_PID(j0), maxNodes, PL_JOB_NODE(j0), PL_JOB_SLOT(j0));
+    unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
+    if (hC && lane < nchild) {
+        const PlChild& c = s.child[lane];
+        pl_st64(rp + lane, pl_bits(c.x)); pl_st64(rp + 16 + lane, pl_bits(c.y)); pl_st64(rp + 32 + lane, pl_bits(c.th));
+        pl_st64(rp + 48 + lane, pl_bits(c.L));
+        pl_st64(rp + 64 + lane, (unsigned long long)(uint32_t)c.first_coll | ((unsigned long long)(uint8_t)c.rs_err << 32));
+    }
+    if (lane == 63) {
+        // (the key words are written by both halves, with the same values)
+        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, pl_look_key3(PL_JOB_PID(j0), pl_unbits(s.job[6])));
+        pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
+        if (hS) {
+            pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
+            pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
+        }
+    }
+    PL_LOOK_DRAIN();
+    wave_sync();
+    if (lane == 0) { PL_FLAG_OR32(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
+    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
+}
+// a record pop's first step: the helper's expansion record (s.recb[s.rec_cur]) unpacked into the per-child state the resolution
+// reads (whole workgroup; a called function)
+__device__ __noinline__ void plk_rec_unpack(AVP_LDS PlShared* sp, int nchild, int in_radius)
+{
+    PlShared& s = *(PlShared*)sp;
+    const DevMap& m = s.km;
+    const PlanWs& w = s.kw;
+    const PlanDims& dims = s.kdims;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long* rec = s.recb[s.rec_cur];
+    const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
+    if (wave == 2 && lane < nchild) {
+        // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
+        const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
+        s.child[lane].pre_d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
+    }
+    if (tid == 0) {
+        const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
+        s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
+        s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
+        if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
+    }
+    if (tid < nchild) {
+        PlChild& c = s.child[tid];
+        c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
+        c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
+        if (nf) { c.found = s.nf_found[tid]; c.found_state = s.nf_state[tid]; }
+        else {
+            c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
+            c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
+        }
+        c.id = avp_pos_to_index(m, c.x, c.y);
+        c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
+        c.rs_err = (int8_t)(rec[64 + tid] >> 32);
+        c.L = pl_unbits(rec[48 + tid]);
+    }
+}
+// set_path + arg-min of the Reeds-Shepp queries of a pop as called functions (their unrolled type groups -- kept[4][5] -- and the
+// fold's winner stay out of the pop loop's registers): the shot's query on wave 0, the children's on the other waves, up to
+// two queries per wave at a time (lanes 0..19 / 32..51 run the type groups of one each).
+__device__ __noinline__ int plk_shot_accept_fold(AVP_LDS PlShared* sp)
+{
+    PlShared& s = *(PlShared*)sp;
+    const int lane = threadIdx.x & 63;
+    if (lane < 20) pl_rs_accept_group(s, s.kp, 0, lane);
+    wave_sync();
+    RsPath rp;
+    const int st = pl_rs_fold_wave(s, 0, rp);
+    if (lane == 0 && !st) s.rs = rp;
+    return st;
+}
+__device__ __noinline__ void plk_children_fold(AVP_LDS PlShared* sp, int base, int cnt, int q_first, int qoff)
+{
+    PlShared& s = *(PlShared*)sp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int nwave = PL_THREADS / 64;
+    const double maxc = s.kp.maxc;
+    for (int q = q_first + (wave - 1); q < cnt; q += 2 * (nwave - 1)) {
+        const int q2 = q + (nwave - 1);
+        const int half = lane >> 5, gl = lane & 31;
+        const int qa = half ? q2 : q;
+        if (gl < 20 && qa < cnt) pl_rs_accept_group(s, s.kp, qa, gl);
+        wave_sync();
+        for (int k = 0; k < 2; k++) {
+            const int qq = k ? q2 : q;
+            if (qq >= cnt) break;
+            RsPath rp;
+            const int st = pl_rs_fold_wave(s, qq, rp);
+            if (lane == 0) { const int g = base + qq; s.child[g - qoff].rs_err = (int8_t)st; s.child[g - qoff].L = st ? 0.0 : rp.L / maxc; }
+        }
+    }
+}
+// the sampler's index bookkeeping by one wave (a called function: its chain of eight-step trips stays out of the pop loop's registers)
+__device__ __noinline__ int plk_book_wave(AVP_LDS PlShared* sp)
+{
+    PlShared& s = *(PlShared*)sp;
+    return pl_rs_sample_book_wave(s, s.kp);
+}
 // the owner side of the lookahead (one wave each), as called functions: five call sites in the pop loop
 __device__ __noinline__ void plk_look_post(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, uint32_t node, int kids,
                                            double cnx, double cny, double cnth, int cn_forward, int cn_steer)
@@ -2076,6 +2398,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 cn.x = pl_unbits(s.job[1]); cn.y = pl_unbits(s.job[2]); cn.th = pl_unbits(s.job[3]);
                 cn.g = 0; cn.h = 0; cn.f = 0; cn.index = 0; cn.parent_index = -1; cn.parent_pos = -1; cn.forward = 1; cn.steer_i = -1; cn.state = 3; cn.heap_pos = -1;
             }
+            if (PL_RESOLVE_CALL && tid == 0) { s.cn_th = cn.th; s.cn_forward = cn.forward; s.cn_index = cn.index; }      // (read behind the next workgroup barrier)
             const bool use_rec = LOOK && !helper && s.use_rec;
 #ifndef PL_PH_LONG
 #define PL_PH_LONG 0
@@ -2108,32 +2431,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
                 const unsigned long long* rec = s.recb[s.rec_cur];
                 if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s);      // (its record is fetched beside the resolution)
-                const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
-                if (wave == 2 && lane < nchild) {
-                    // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
-                    const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
-                    s.child[lane].pre_d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
-                }
-                if (tid == 0) {
-                    const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
-                    s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
-                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
-                    if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
-                }
-                if (tid < nchild) {
-                    PlChild& c = s.child[tid];
-                    c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
-                    c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
-                    if (nf) { c.found = s.nf_found[tid]; c.found_state = s.nf_state[tid]; }
-                    else {
-                        c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
-                        c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
-                    }
-                    c.id = avp_pos_to_index(m, c.x, c.y);
-                    c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
-                    c.rs_err = (int8_t)(rec[64 + tid] >> 32);
-                    c.L = pl_unbits(rec[48 + tid]);
-                }
+                plk_rec_unpack((AVP_LDS PlShared*)&s, nchild, in_radius ? 1 : 0);
                 PH_MARK(0);
                 __syncthreads();
                 can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
@@ -2218,38 +2516,29 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     if (wave == 0) {
                         if (base == 0 && !hC) {
                             const long long t_a0 = PH_NOW();
-                            if (lane < 20) pl_rs_accept_group(s, p, 0, lane);
-                            wave_sync();
-                            if (PROFILE && lane == 0) PH_X(3, t_a0);
-                            RsPath rp;
-                            const int st = pl_rs_fold_wave(s, 0, rp);
-                            if (PROFILE && lane == 0) PH_X(4, t_a0);
+                            const int st = plk_shot_accept_fold((AVP_LDS PlShared*)&s);      // (s.rs holds the path when st == 0)
+                            if (PROFILE && lane == 0) { PH_X(3, t_a0); PH_X(4, t_a0); }
+                            const bool shot = in_radius && !st;            // (st: the fold's result, the same in every lane)
                             if (lane == 0) {
                                 s.rs_status = in_radius ? st : 0;
-                                const bool shot = in_radius && !st;
-                                if (!st) s.rs = rp;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 *(volatile int32_t*)&s.shot_ready = shot ? 1 : 2;
+#if !PL_BOOK_WAVE
                                 if (shot) { s.n_rs += 1; const int bs = pl_rs_sample_book(s, p); if (bs) s.rs_status = bs; }
                                 if (PROFILE) PH_X(5, t_a0);
+#endif
                             }
+#if PL_BOOK_WAVE
+                            if (shot) {
+                                wave_sync();                                // (s.rs, written by lane 0, as every lane reads it)
+                                const int bs = plk_book_wave((AVP_LDS PlShared*)&s);
+                                if (lane == 0) { s.n_rs += 1; if (bs) s.rs_status = bs; }
+                            }
+                            if (PROFILE && lane == 0) PH_X(5, t_a0);
+#endif
                         }
                     } else {
-                        // up to two queries per wave at a time: lanes 0..19 / 32..51 run the type groups of one each
-                        for (int q = q_first + (wave - 1); q < cnt; q += 2 * (nwave - 1)) {
-                            const int q2 = q + (nwave - 1);
-                            const int half = lane >> 5, gl = lane & 31;
-                            const int qa = half ? q2 : q;
-                            if (gl < 20 && qa < cnt) pl_rs_accept_group(s, p, qa, gl);
-                            wave_sync();
-                            for (int k = 0; k < 2; k++) {
-                                const int qq = k ? q2 : q;
-                                if (qq >= cnt) break;
-                                RsPath rp;
-                                const int st = pl_rs_fold_wave(s, qq, rp);
-                                if (lane == 0) { const int g = base + qq; s.child[g - qoff].rs_err = (int8_t)st; s.child[g - qoff].L = st ? 0.0 : rp.L / p.maxc; }
-                            }
-                        }
+                        plk_children_fold((AVP_LDS PlShared*)&s, base, cnt, q_first, qoff);      // set_path + arg-min of this wave's child queries
                         if (wave == nwave - 1 && base == 0 && !hC) {
                             if (lane == 0) while (*(volatile int32_t*)&s.shot_ready == 0) __builtin_amdgcn_s_sleep(1);
                             wave_sync();
@@ -2285,7 +2574,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     }
                     wave_sync();
                     if (can_fast) {
+#if PL_RESOLVE_CALL
+                        plk_resolve_fast<PROFILE>((AVP_LDS PlShared*)&s, nchild, n_pops < max_pops ? 1 : 0, 0);
+#else
                         pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
+#endif
                         if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0); }
                     }
                 }
@@ -2352,31 +2645,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             t_f = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
             if constexpr (LOOK) if (helper) {
-                // publish this half of the record: payload, then the half's ready bit
-                if (wave == 0) {
-                    const unsigned long long j0 = s.job[0];
-                    const size_t ri = pl_look_idx(PL_JOB_PID(j0), maxNodes, PL_JOB_NODE(j0), PL_JOB_SLOT(j0));
-                    unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
-                    if (hC && lane < nchild) {
-                        const PlChild& c = s.child[lane];
-                        pl_st64(rp + lane, pl_bits(c.x)); pl_st64(rp + 16 + lane, pl_bits(c.y)); pl_st64(rp + 32 + lane, pl_bits(c.th));
-                        pl_st64(rp + 48 + lane, pl_bits(c.L));
-                        pl_st64(rp + 64 + lane, (unsigned long long)(uint32_t)c.first_coll | ((unsigned long long)(uint8_t)c.rs_err << 32));
-                    }
-                    if (lane == 63) {
-                        // (the key words are written by both halves, with the same values)
-                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, pl_look_key3(PL_JOB_PID(j0), pl_unbits(s.job[6])));
-                        pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
-                        if (hS) {
-                            pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
-                            pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
-                        }
-                    }
-                    PL_LOOK_DRAIN();
-                    wave_sync();
-                    if (lane == 0) { PL_FLAG_OR32(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
-                    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
-                }
+                if (wave == 0) plk_look_publish((AVP_LDS PlShared*)&s, maxNodes, nchild, hS ? 1 : 0, in_radius ? 1 : 0);      // this half of the record: payload, then its ready bit
                 continue;
             }
             if (s.status != 0 || s.done) break;
@@ -2390,7 +2659,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             __syncthreads();
             if (!tried && can_fast) {
                 if (wave == 0) {
+#if PL_RESOLVE_CALL
+                    plk_resolve_fast<PROFILE>((AVP_LDS PlShared*)&s, nchild, n_pops < max_pops ? 1 : 0, (LOOK && use_rec) ? 1 : 0);
+#else
                     pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops, LOOK && use_rec);
+#endif
                     if constexpr (LOOK) if (look.on) {
                         wave_sync();
                         if (use_rec) {       // (resolution left early / nothing popped ahead: release the writer and the fetcher)
@@ -2410,7 +2683,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (*(volatile int32_t*)&s.fetch_go == 1) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.fetch_nheap, nchild, 1);
                     }
                 } else if (LOOK && use_rec && wave == 2) {
+#if PL_RESOLVE_CALL
+                    plk_resolve_writer((AVP_LDS PlShared*)&s, nchild);
+#else
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
+#endif
                 } else if (LOOK && use_rec && wave == nwave - 1) {
                     if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
                 }
@@ -2422,6 +2699,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             } else
             for (;;) {
                 if (tid == 0) {
+#if PL_RESOLVE_CALL
+                    plk_resolve_slow_step((AVP_LDS PlShared*)&s, nchild, maxNodes);
+#else
                     s.need_sweep = 0;
                     int i = s.next_child;
                     for (; i < nchild && s.status == 0; i++) {
@@ -2476,6 +2756,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         }
                     }
                     s.next_child = i;
+#endif
                 }
                 __syncthreads();
                 if (!s.need_sweep) break;

@@ -19,6 +19,8 @@ ap.add_argument("--no-profile", action="store_true")
 ap.add_argument("--big-mode", type=int, default=0)
 ap.add_argument("--slice", choices=["auto", "on", "off"], default="auto", help="time slicing of the group forms for the big batch")
 ap.add_argument("--slice-pops", type=int, default=None)
+ap.add_argument("--cap", type=int, default=1000, help="pop cap of every search")
+ap.add_argument("--no-big", action="store_true", help="skip the saturating batch")
 a = ap.parse_args()
 if a.lib:
     os.environ["AVP_HIP_LIB"] = os.path.abspath(a.lib)
@@ -31,7 +33,7 @@ from automatedvaletparking_amd import costmap, config, sampling, _native, path_p
 cfg = config.default_config()
 veh = costmap.Vehicle()
 m = costmap.Map(file=os.path.join(ROOT, "data", "BenchmarkCases", "Case1.csv"), discrete_size=cfg["map_discrete_size"])
-dm = _native.DeviceMap(m, veh, cfg, max_pops=1000)
+dm = _native.DeviceMap(m, veh, cfg, max_pops=a.cap)
 bp = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256)
 rng = np.random.default_rng(20260927)
 free = []
@@ -66,21 +68,22 @@ for i in range(256):
     h.update(np.ascontiguousarray(pa[i, :int(rec["n_final"][i]), :]).tobytes())
 out = {"lib": os.path.basename(_native.LIB_PATH), "c2_ms": round(ms, 3), "c2_plans_per_s": round(256 / ms * 1e3, 1),
        "c2_expansions_per_s": round(float(rec["n_pops"].sum()) / ms * 1e3), "solved": int((rec["status"] == 0).sum()),
-       "capped": int((rec["status"] == 4).sum()), "digest": h.hexdigest()[:16]}
-# saturating batch: the 256 starts against rolled goals
-rep = a.big // 256
-bs = torch.cat([st] * rep).contiguous()
-bg = torch.cat([go.roll(k, 0) for k in range(rep)]).contiguous()
-bp_big = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=a.big_mode, time_slice={"auto": None, "on": True, "off": False}[a.slice], slice_pops=a.slice_pops)
-bp_save, bp = bp, bp_big
-msb, resb, _ = timed(bs, bg, 2)
-bp = bp_save
-recb = resb.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:a.big]
-hb = hashlib.sha256()
-for k in ("status", "n_pops", "n_astar", "n_final", "n_checks", "n_rs", "n_closed", "n_open", "h_cells", "global_index", "n_nodes", "rs_L"):
-    hb.update(np.ascontiguousarray(recb[k]).tobytes())
-out.update({"big_digest": hb.hexdigest()[:16], "big_mode": a.big_mode, "time_sliced": bp_big.last_time_sliced, "slice_pops": a.slice_pops, "big_n": a.big, "big_ms": round(msb, 3), "big_plans_per_s": round(a.big / msb * 1e3, 1),
-            "big_expansions_per_s": round(float(recb["n_pops"].sum()) / msb * 1e3), "big_solved": int((recb["status"] == 0).sum())})
+       "capped": int((rec["status"] == 4).sum()), "digest": h.hexdigest()[:16], "cap": a.cap}
+if not a.no_big:
+    # saturating batch: the 256 starts against rolled goals
+    rep = a.big // 256
+    bs = torch.cat([st] * rep).contiguous()
+    bg = torch.cat([go.roll(k, 0) for k in range(rep)]).contiguous()
+    bp_big = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=a.big_mode, time_slice={"auto": None, "on": True, "off": False}[a.slice], slice_pops=a.slice_pops)
+    bp_save, bp = bp, bp_big
+    msb, resb, _ = timed(bs, bg, 2)
+    bp = bp_save
+    recb = resb.cpu().numpy().view(path_planner.RESULT_DTYPE).reshape(-1)[:a.big]
+    hb = hashlib.sha256()
+    for k in ("status", "n_pops", "n_astar", "n_final", "n_checks", "n_rs", "n_closed", "n_open", "h_cells", "global_index", "n_nodes", "rs_L"):
+        hb.update(np.ascontiguousarray(recb[k]).tobytes())
+    out.update({"big_digest": hb.hexdigest()[:16], "big_mode": a.big_mode, "time_sliced": bp_big.last_time_sliced, "slice_pops": a.slice_pops, "big_n": a.big, "big_ms": round(msb, 3), "big_plans_per_s": round(a.big / msb * 1e3, 1),
+                "big_expansions_per_s": round(float(recb["n_pops"].sum()) / msb * 1e3), "big_solved": int((recb["status"] == 0).sum())})
 if not a.no_profile and hasattr(_native.lib(), "avp_plan_batch_profile"):
     try:
         resp, _, _ = bp.plan_dev(st, go, profile=True)

@@ -58,6 +58,7 @@ def test_golden_collision_vectors(k, vehicle, cfg):
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), g3[f"c{k}_dist"])
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), g3[f"c{k}_dist"])
     assert np.array_equal(dm.check_batch(poses, kind=1), g3[f"c{k}_circ"])
+    assert np.array_equal(dm.check_batch(poses, kind=1, variant=1), g3[f"c{k}_circ"])      # the lane-per-pose walk (cross-check)
 
 
 @pytest.mark.parametrize("k", [1, 19])
@@ -74,7 +75,8 @@ def test_random_poses_vs_oracle(k, vehicle, cfg):
     want = o.check_batch(poses, kind=0)
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), want)
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), want)
-    assert np.array_equal(dm.check_batch(poses, kind=1), o.check_batch(poses, kind=1))
+    wc = o.check_batch(poses, kind=1)
+    assert np.array_equal(dm.check_batch(poses, kind=1), wc) and np.array_equal(dm.check_batch(poses, kind=1, variant=1), wc)
 
 
 def test_edge_inputs(vehicle, cfg):

@@ -1,7 +1,7 @@
 """The limits the device planner has and the reference does not (include/avp.h): every one is a status code or a raised
-error, never a wrong answer, and each is shown here -- together with what still works on the same input (the footprint
-kernels have wider limits and fall back to the all-points kernel beyond them) and, for the one DATA-dependent limit, what
-the reference does (golden G11)."""
+error, never a wrong answer, and each is shown here -- together with what still works on the same input and, for the one
+DATA-dependent limit, what the reference does (golden G11). Two limits of rounds 1 - 4 are gone and their tests are parity
+tests now: map_discrete_size below 0.088 m (a footprint wider than 64 map columns) and maps of more than 4 095 nodes per axis."""
 import os
 
 import numpy as np
@@ -62,41 +62,88 @@ def test_too_many_motion_primitives_is_an_error(over, what, vehicle, cfg):
     assert _plan_one(case_map_from_gold(1), vehicle, ok)[0].status in (0, 4)
 
 
-def test_footprint_wider_than_the_collision_pass_is_an_error_but_checks_still_work(vehicle, cfg, tmp_path):
-    """discrete_size 0.05 m: the inflated rectangle's diagonal spans 107 cells (limit: < 61, the planner's collision pass
-    walks <= 64 map columns per pose). avp_plan_batch refuses; check_batch answers through the all-points kernel."""
-    from automatedvaletparking_amd import costmap, _native
+def _pairs(m, dm, n, seed):
+    from automatedvaletparking_amd import workloads
+    return workloads.sample_pairs(m, dm.check_batch, n, np.random.default_rng(seed), chunk=8 * n)
+
+
+def test_fine_map_footprint_wider_than_64_columns_plans_like_the_reference(vehicle, cfg):
+    """map_discrete_size 0.05 m (config/config.yaml:6 takes any value; the default is 0.1): the inflated rectangle's
+    diagonal spans 107 cells, so a footprint's AABB covers up to 107 map columns and 2 - 3 bitmap words of rows. Until
+    round 4 avp_plan_batch refused such a map ("footprint diagonal < 61 cells": the planner's collision pass walked
+    <= 64 columns per pose); the pass now walks any number of column chunks and words (pl_check_pass, the general walk).
+    Every kernel form against the pinned oracle: Case1's own problem run to the end and 48 random pairs, every observable
+    field; both checkers on 3 000 random poses."""
+    import _parity
+    from automatedvaletparking_amd import costmap, _native, path_planner
     from oracle import oracle
     m = costmap.Map(file=os.path.join(CASES, "Case1.csv"), discrete_size=0.05)
     assert m.cost_map.shape[0] > 500
-    with pytest.raises(RuntimeError, match="footprint diagonal"):
-        _plan_one(m, vehicle, cfg)
-    dm = _native.DeviceMap(m, vehicle, cfg)
+    cap = 200
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
+    o = oracle.Oracle(m, vehicle, cfg, max_pops=cap)
     rng = np.random.default_rng(5)
     b = m.boundary
     poses = np.stack([rng.uniform(b[0] + 3, b[1] - 3, 3000), rng.uniform(b[2] + 3, b[3] - 3, 3000), rng.uniform(-np.pi, np.pi, 3000)], 1)
-    want = oracle.Oracle(m, vehicle, cfg).check_batch(poses, kind=0)
-    assert np.array_equal(dm.check_batch(poses, kind=0), want) and 0 < want.sum() < len(want)
+    for kind in (0, 1):
+        want = o.check_batch(poses, kind=kind)
+        assert np.array_equal(dm.check_batch(poses, kind=kind), want) and 0 < want.sum() < len(want)
+    c = m.case
+    st, go = _pairs(m, dm, 48, 11)
+    st = np.concatenate([[[c.x0, c.y0, c.theta0]], st])
+    go = np.concatenate([[[c.xf, c.yf, c.thetaf]], go])
+    ref = None
+    for mode in (1, 2, 3, 4):
+        res = path_planner.BatchPlanner(dm, max_nodes=8192, mode=mode, n_slots=64 if mode > 1 else None).plan(st, go, max_trace=cap)
+        bad, _ = _parity.compare_pinned(o, res, st, go, cap)
+        assert not bad, (mode, len(bad), bad[:6])
+        sig = [(r.status, r.n_pops, r.counters["n_checks"]) for r in res]
+        assert ref is None or sig == ref, mode
+        ref = sig
+    assert sum(r.status == 0 for r in res) >= 10 and max(r.n_pops for r in res) >= 50
+    # the two-circle checker inside the planner on the same map
+    c2 = dict(cfg)
+    c2["collision_check"] = "circle"
+    dm2 = _native.DeviceMap(m, vehicle, c2, max_pops=cap)
+    res = path_planner.BatchPlanner(dm2, max_nodes=8192).plan(st[:16], go[:16], max_trace=cap)
+    bad, _ = _parity.compare_pinned(oracle.Oracle(m, vehicle, c2, max_pops=cap), res, st[:16], go[:16], cap)
+    assert not bad, bad[:6]
 
 
-def test_map_wider_than_4095_nodes_is_an_error_but_checks_still_work(vehicle, cfg, tmp_path):
-    """A 430 m x 30 m strip at the default 0.1 m: 4 300 x 300 nodes (limit of the planner: 4 095 per axis, its collision
-    queue packs cell indices in 12 bits; the check kernel's limit is 8 191)."""
-    from automatedvaletparking_amd import costmap, sampling, _native
+def test_map_wider_than_4095_nodes_plans_like_the_reference(vehicle, cfg, tmp_path):
+    """A 430 m x 30 m strip at the default 0.1 m: 4 300 x 300 nodes. Until round 4 the planner's collision queue packed cell
+    indices in 12 bits (nx, ny <= 4095); it now packs 13 (8 191, the limit of avp_map_create and of the check kernel). The
+    strip's own problem (405 m: capped) and 32 random pairs against the pinned oracle in the workgroup and the wave form."""
+    import _parity
+    from automatedvaletparking_amd import costmap, sampling, _native, path_planner
     from oracle import oracle
     rng = np.random.default_rng(2)
-    polys = [np.array([[x, y], [x + 2.0, y], [x + 2.0, y + 1.5], [x, y + 1.5]]) for x, y in zip(rng.uniform(15, 400, 60), rng.uniform(12, 16, 60))]
+    polys = [np.array([[x, y], [x + 2.0, y], [x + 2.0, y + 1.5], [x, y + 1.5]]) for x, y in zip(rng.uniform(15, 422, 70), rng.uniform(6, 22, 70))]
     csv = tmp_path / "strip.csv"
     sampling.write_tpcap_csv(str(csv), (12.5, 14.0, 0.0), (417.5, 14.0, 0.0), polys)
     m = costmap.Map(file=str(csv), discrete_size=cfg["map_discrete_size"])
     assert m.cost_map.shape[0] > 4095
-    with pytest.raises(RuntimeError, match="nx, ny <= 4095"):
-        _plan_one(m, vehicle, cfg)
-    dm = _native.DeviceMap(m, vehicle, cfg)
+    cap = 120
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
+    o = oracle.Oracle(m, vehicle, cfg, max_pops=cap)
     b = m.boundary
-    poses = np.stack([rng.uniform(b[0] + 3, b[1] - 3, 3000), rng.uniform(b[2] + 3, b[3] - 3, 3000), rng.uniform(-np.pi, np.pi, 3000)], 1)
-    want = oracle.Oracle(m, vehicle, cfg).check_batch(poses, kind=0)
+    # poses in the last 44 m of the strip: starts left of x = 400 m, goals right of x = 411 m -- beyond column 4 095, where a
+    # 12-bit index would have wrapped
+    n = 6000
+    poses = np.stack([rng.uniform(b[0] + 385, b[1] - 3, n), rng.uniform(b[2] + 3, b[3] - 3, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    want = o.check_batch(poses, kind=0)
     assert np.array_equal(dm.check_batch(poses, kind=0), want) and 0 < want.sum() < len(want)
+    free = np.array([p for p, h in zip(poses, want) if not h and sampling.pose_is_free(p[0], p[1], p[2], m.case.obs)])
+    far, near = free[free[:, 0] > b[0] + 411.0], free[free[:, 0] < b[0] + 400.0]
+    assert len(far) >= 32 and len(near) >= 32
+    c = m.case
+    st = np.concatenate([[[c.x0, c.y0, c.theta0]], near[:32]])
+    go = np.concatenate([[[c.xf, c.yf, c.thetaf]], far[:32]])
+    for mode in (1, 2):
+        res = path_planner.BatchPlanner(dm, max_nodes=4096, mode=mode, n_slots=64 if mode > 1 else None).plan(st, go, max_trace=cap)
+        bad, _ = _parity.compare_pinned(o, res, st, go, cap)
+        assert not bad, (mode, len(bad), bad[:6])
+    assert sum(r.status == 0 for r in res) >= 10 and sum(r.status == 4 for r in res) >= 2 and max(r.n_pops for r in res if r.status == 0) >= 50
 
 
 def test_goal_on_a_cell_border_irregular_lattice(vehicle, cfg):
