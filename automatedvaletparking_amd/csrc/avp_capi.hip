@@ -192,28 +192,20 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
     AVP_ON_DEVICE(map->device);
     const DevMap& d = map->dev;
     if (kind == 1) {
-        // the production kernel walks at most two 64-row bitmap words per column: the two discs' AABB is at most
-        // 2 Rd + |cf - cr| tall; beyond that (very fine maps), and as variant 1 (the on-device cross-check), the lane-per-pose walk
-        const double tall = 2.0 * map->params.circ_rd + fabs(map->params.circ_cf - map->params.circ_cr);
-        if (variant == 1 || !(tall / d.dy + 3.0 < 64.0)) {
+        if (variant == 1) {
+            // the plain lane-per-pose walk (the on-device cross-check)
             const int64_t blocks = (n + 255) / 256;
             hipLaunchKernelGGL(check_circle_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
         } else {
-            int waves = CIR_WAVES;
-            while (waves > 8 && check_circle_lds_bytes(d, true, waves) + AVP_LDS_TABLE_BYTES > 160 * 1024) waves--;
-            const bool stage = check_circle_lds_bytes(d, true, waves) + AVP_LDS_TABLE_BYTES <= 160 * 1024;     // static LDS: the trig tables
-            if (!stage) waves = CIR_WAVES;
-            const size_t lds = check_circle_lds_bytes(d, stage, waves);
+            // lane per pose with refill: persistent waves over strided 64-pose tiles, ~4 waves per SIMD; a wave wants a few hundred
+            // poses of its own (the refill runs dry at the end of a wave's share), so small batches launch fewer waves
             const int64_t tiles = (n + 63) / 64;
-            int64_t blocks = (tiles + waves - 1) / waves;
-            if (blocks > (int64_t)map->n_cu) blocks = map->n_cu;
-            if (stage) {
-                HIPCHK(hipFuncSetAttribute((const void*)check_circle_compact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(check_circle_compact_kernel<true>, dim3((unsigned)blocks), dim3(64 * waves), lds, map->stream, d, map->params, x, y, th, n, out);
-            } else {
-                HIPCHK(hipFuncSetAttribute((const void*)check_circle_compact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(check_circle_compact_kernel<false>, dim3((unsigned)blocks), dim3(64 * waves), lds, map->stream, d, map->params, x, y, th, n, out);
-            }
+            int64_t waves = tiles / 4;                       // >= 256 poses per wave
+            const int64_t cap = (int64_t)map->n_cu * 16;     // 4 waves per SIMD
+            if (waves > cap) waves = cap;
+            if (waves < 1) waves = 1;
+            const int64_t blocks = (waves + 3) / 4;
+            hipLaunchKernelGGL(check_circle_refill_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
         }
     } else if (kind == 0) {
         // the production kernel assumes the footprint AABB spans at most two 64-row bitmap words

@@ -298,181 +298,86 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
     out[i] = hit ? 1 : 0;
 }
 
-// ---- two-circle checker, production kernel (round 5): the distance kernel's skeleton ---------------------------------
-// The lane-per-pose walk above keeps 19 % of its issued lanes live (rocprofv3, round 4): poses differ in how many map
-// columns and near points they have, and a colliding pose (56 % of a random set) leaves its lane idle for the rest of the
-// tile. Here, as in check_distance_kernel: map tables staged in LDS once per workgroup, one lane = one pose for the set-up
-// (sin / cos, the two disc centres, the EXCLUSIVE AABB filter of collision_check.py:100-128), a broad phase of CIR_COLS
-// map columns per step whose surviving bits -- exactly the reference's near points, in its order -- are compacted into a
-// per-wave LDS queue by ONE wave prefix sum, and a narrow phase of one lane per (pose, point) candidate: the two
-// sqrt(pow(dx, 2) + pow(dy, 2)) <= Rd tests (avp_circle_hit). A pose's record is its two centres (4 doubles, odd stride);
-// the per-wave LDS area is 5 KB, so sixteen waves share a CU next to the Case1 tables. Same booleans as variant 1 and as
-// the oracle (tests/test_gpu_check.py kind = 1, golden G3).
-#define CIR_WAVES 16
-#define CIR_QCAP 1024
-#define CIR_QDRAIN 512          // the queue is drained as soon as it holds more: at the top of a broad-phase step it has room for CIR_QCAP - CIR_QDRAIN entries
-#define CIR_COLS 8
-#define CIR_RECW 5              // record stride in doubles (fx, fy, rx, ry + 1: odd)
-// the two ends of a tile as CALLED functions (as in check_distance_kernel): the set-up's sin / cos and index searches and the
-// drain's two threshold tests keep their registers out of the broad-phase loop (inlined: 128 VGPRs + 19 spilled at 16 waves per CU)
-template <bool STAGE>
-__device__ __noinline__ uint64_t cir_setup(double px, double py, double pt, int valid, double cf, double cr, double Rd, AVP_LDS double* r,
-                                           typename ChkTabs<STAGE>::D sX, typename ChkTabs<STAGE>::D sY, int nx, int ny, double b0, double dx, double b2, double dy)
-{
-    double cs, sn;
-    avp_sincos(pt, sn, cs);
-    const double fx = px + cf * cs, fy = py + cf * sn;
-    const double rx = px + cr * cs, ry = py + cr * sn;
-    double right, left, upper, down;
-    if (fx >= rx) { right = fx + Rd; left = rx - Rd; } else { right = rx + Rd; left = fx - Rd; }
-    if (fy >= ry) { upper = fy + Rd; down = ry - Rd; } else { upper = ry + Rd; down = fy - Rd; }
-    int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
-    if (valid) {
-        ixlo = avp_first_gt(sX, nx, b0, dx, left); ixhi = avp_last_lt(sX, nx, b0, dx, right);
-        iylo = avp_first_gt(sY, ny, b2, dy, down); iyhi = avp_last_lt(sY, ny, b2, dy, upper);
-        if (iylo > iyhi) ixhi = ixlo - 1;
-    }
-    r[0] = fx; r[1] = fy; r[2] = rx; r[3] = ry;
-    return (uint64_t)(uint16_t)ixlo | ((uint64_t)(uint16_t)ixhi << 16) | ((uint64_t)(uint16_t)iylo << 32) | ((uint64_t)(uint16_t)iyhi << 48);
-}
-template <bool STAGE>
-__device__ __noinline__ void cir_drain(AVP_LDS const double* sRec, AVP_LDS const uint32_t* sQ, AVP_LDS volatile uint8_t* sHit, int qtail, double Rd,
-                                       typename ChkTabs<STAGE>::D sX, typename ChkTabs<STAGE>::D sY)
-{
-    const int lane = threadIdx.x & 63;
-    for (int base = 0; base < qtail; base += 64) {
-        const int e = base + lane;
-        if (e < qtail) {
-            const uint32_t ent = sQ[e];
-            const int pl = ent >> 26, ix = (ent >> 13) & 0x1fff, iy = ent & 0x1fff;
-            if (!sHit[pl]) {
-                const AVP_LDS double* r = sRec + (size_t)pl * CIR_RECW;
-                const double qx = sX[ix], qy = sY[iy];
-                if (avp_circle_hit(qx - r[0], qy - r[1], Rd) || avp_circle_hit(qx - r[2], qy - r[3], Rd)) sHit[pl] = 1;
-            }
-        }
-    }
-}
-template <bool STAGE>
-__global__ __launch_bounds__(64 * CIR_WAVES) void check_circle_compact_kernel(DevMap m, avp_params p, const double* __restrict__ x,
-                                                                               const double* __restrict__ y, const double* __restrict__ th,
-                                                                               int64_t n, uint8_t* __restrict__ out)
+// ---- two-circle checker, production kernel (round 5): lane per pose WITH REFILL ------------------------------------------
+// The walk above keeps 19 % of its issued lanes live (rocprofv3, round 4): poses differ in how many map columns and near
+// points they have, and a colliding pose (56 % of a random set) leaves its lane idle until the slowest pose of its wave is
+// done. The distance kernel's answer -- compact the (pose, point) candidates of a wave into an LDS queue, one lane per
+// candidate -- was built and measured for this checker in round 5 and LOST: 1.97 against 4.03 G checks/s (the point test
+// here is two squared distances, cheaper than the prefix sum and the queue traffic that feed it). What the cheap test wants
+// is full lanes on the WALK itself: a wave owns a strided set of 64-pose tiles and a cursor into them; a lane that finishes
+// its pose (hit, or last column) goes idle, and as soon as half the wave is idle -- or nothing is left to walk -- the idle
+// lanes take the next poses off the cursor and run the set-up (sin / cos, the two disc centres, the exclusive AABB filter
+// of collision_check.py:100-128, four index searches) together. Then every lane with a pose does ONE map column per trip:
+// the same words, the same masks, the same per-point test in the same order as the walk above -- the same booleans
+// (tests/test_gpu_check.py kind = 1 against variant 1, the oracle and golden G3). At least half the lanes are live on
+// every trip by construction.
+#define CIR_REFILL_AT 32            // idle lanes that trigger a refill
+__global__ __launch_bounds__(256) void check_circle_refill_kernel(DevMap m, avp_params p, const double* __restrict__ x,
+                                                                  const double* __restrict__ y, const double* __restrict__ th,
+                                                                  int64_t n, uint8_t* __restrict__ out)
 {
     avp_lds_tables_fill<false>();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* lBits = (uint64_t*)smem;
-    double* lX = (double*)(lBits + (STAGE ? (size_t)m.nx * m.wpc : 0));
-    double* lY = lX + (STAGE ? m.nx : 0);
-    double* sWave = lY + (STAGE ? m.ny : 0);
-    typedef typename ChkTabs<STAGE>::D TD;
-    typedef typename ChkTabs<STAGE>::B TB;
-    TB sBits; TD sX, sY;
-    if constexpr (STAGE) { sBits = (TB)lBits; sX = (TD)lX; sY = (TD)lY; } else { sBits = m.colBits; sX = m.X; sY = m.Y; }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t perWave = 64 * CIR_RECW + CIR_QCAP / 2 + 8;   // in doubles
-    AVP_LDS double* sRec = (AVP_LDS double*)(sWave + (size_t)wave * perWave);
-    AVP_LDS uint32_t* sQ = (AVP_LDS uint32_t*)(sRec + 64 * CIR_RECW);
-    AVP_LDS volatile uint8_t* sHit = (AVP_LDS volatile uint8_t*)(sQ + CIR_QCAP);
-    if (STAGE) {
-        for (int i = threadIdx.x; i < m.nx * m.wpc; i += blockDim.x) lBits[i] = m.colBits[i];
-        for (int i = threadIdx.x; i < m.nx; i += blockDim.x) lX[i] = m.X[i];
-        for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
-    }
-    __syncthreads();
-    const double Rd = p.circ_rd;
+    const int lane = threadIdx.x & 63;
+    const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);                 // waves of the launch
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t tiles = (n + 63) / 64;
-    const int nwaves = (int)(blockDim.x >> 6);
-    const int wpc = m.wpc;
-    for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < tiles; tile += (int64_t)gridDim.x * nwaves) {
-        const int64_t i = tile * 64 + lane;
-        const bool valid = i < n;
-        const uint64_t rg = cir_setup<STAGE>(valid ? x[i] : 0.0, valid ? y[i] : 0.0, valid ? th[i] : 0.0, valid ? 1 : 0, p.circ_cf, p.circ_cr, Rd,
-                                             sRec + (size_t)lane * CIR_RECW, sX, sY, m.nx, m.ny, m.b0, m.dx, m.b2, m.dy);
-        const int ixlo = (int16_t)(rg & 0xffff), ixhi = (int16_t)((rg >> 16) & 0xffff), iylo = (int16_t)((rg >> 32) & 0xffff), iyhi = (int16_t)(rg >> 48);
-        sHit[lane] = 0;
-        wave_sync();
-        int ncol = ixhi - ixlo + 1;
-        if (ncol < 0) ncol = 0;
-        int maxcol = ncol;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) maxcol = max(maxcol, __shfl_xor(maxcol, d, 64));
-        int qtail = 0;
-        const int w0 = iylo >> 6, w1 = iyhi >> 6;   // at most 2 words (the host's guard)
-        auto drain = [&]() {
-            wave_sync();
-            cir_drain<STAGE>(sRec, sQ, sHit, qtail, Rd, sX, sY);
-            qtail = 0;
-            wave_sync();
-        };
-        for (int c0 = 0; c0 < maxcol; c0 += CIR_COLS) {
-            uint64_t b0[CIR_COLS], b1[CIR_COLS];
-            int cnt = 0;
-            const bool live = !sHit[lane];
-#pragma unroll
-            for (int k = 0; k < CIR_COLS; k++) {
-                uint64_t bits0 = 0, bits1 = 0;
-                const int c = c0 + k;
-                if (c < ncol && live) {
-                    const TB col = sBits + (size_t)(ixlo + c) * wpc;
-                    bits0 = col[w0] & (~0ull << (iylo & 63));
-                    if (w1 == w0) bits0 &= ~0ull >> (63 - (iyhi & 63));
-                    else bits1 = col[w1] & (~0ull >> (63 - (iyhi & 63)));
-                }
-                b0[k] = bits0; b1[k] = bits1;
-                cnt += __popcll(bits0) + __popcll(bits1);
-            }
-            int total;
-            const int pre = wave_prefix_excl(cnt, lane, total);
-            if (total == 0) continue;
-            if (total <= CIR_QCAP - CIR_QDRAIN) {
-                // (qtail <= CIR_QDRAIN here: no drain -- no call -- between the count and the write, so the step's bitmap words
-                //  are never live across a call)
-                int off = qtail + pre;
-#pragma unroll
-                for (int k = 0; k < CIR_COLS; k++) {
-                    const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)(ixlo + c0 + k) << 13);
-                    uint64_t bits0 = b0[k], bits1 = b1[k];
-                    while (bits0) { const int bpos = __ffsll((unsigned long long)bits0) - 1; bits0 &= bits0 - 1; sQ[off++] = tag | (uint32_t)((w0 << 6) + bpos); }
-                    while (bits1) { const int bpos = __ffsll((unsigned long long)bits1) - 1; bits1 &= bits1 - 1; sQ[off++] = tag | (uint32_t)((w1 << 6) + bpos); }
-                }
-                qtail += total;
-                if (qtail > CIR_QDRAIN) drain();
-            } else {
-                // more candidates in these columns than the queue has room for (dense clutter): one column at a time, a group of
-                // GL lanes at a time (a lane's column holds <= 128 rows), the words read again (nothing kept across the drains)
-                constexpr int GL = (CIR_QCAP - CIR_QDRAIN) / 128;
-#pragma nounroll
-                for (int k = 0; k < CIR_COLS; k++) {
-                    for (int g0 = 0; g0 < 64; g0 += GL) {
-                        const bool mine = lane >= g0 && lane < g0 + GL && c0 + k < ncol && live;
-                        uint64_t bits0 = 0, bits1 = 0;
-                        if (mine) {
-                            const TB col = sBits + (size_t)(ixlo + c0 + k) * wpc;
-                            bits0 = col[w0] & (~0ull << (iylo & 63));
-                            if (w1 == w0) bits0 &= ~0ull >> (63 - (iyhi & 63));
-                            else bits1 = col[w1] & (~0ull >> (63 - (iyhi & 63)));
-                        }
-                        int totk;
-                        const int prek = wave_prefix_excl(__popcll(bits0) + __popcll(bits1), lane, totk);
-                        if (totk == 0) continue;
-                        int off = qtail + prek;
-                        const uint32_t tag = ((uint32_t)lane << 26) | ((uint32_t)(ixlo + c0 + k) << 13);
-                        while (bits0) { const int bpos = __ffsll((unsigned long long)bits0) - 1; bits0 &= bits0 - 1; sQ[off++] = tag | (uint32_t)((w0 << 6) + bpos); }
-                        while (bits1) { const int bpos = __ffsll((unsigned long long)bits1) - 1; bits1 &= bits1 - 1; sQ[off++] = tag | (uint32_t)((w1 << 6) + bpos); }
-                        qtail += totk;
-                        if (qtail > CIR_QDRAIN) drain();
-                    }
+    // this wave's poses, in its own order: position q -> tile gw + (q >> 6) * W, pose (tile << 6) + (q & 63)
+    const int64_t my_tiles = gw < tiles ? (tiles - gw + W - 1) / W : 0;
+    const int64_t qend = my_tiles * 64;
+    int64_t q = 0;                                                            // (uniform) next position to hand out
+    const double Rd = p.circ_rd;
+    bool has = false, hit = false;
+    int64_t idx = 0;
+    double fx = 0.0, fy = 0.0, rx = 0.0, ry = 0.0;
+    int ix = 0, ixhi = -1, iylo = 0, iyhi = -1;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const int nidle = __popcll(idle);
+        if (q < qend && (nidle >= CIR_REFILL_AT || nidle == 64)) {
+            // the idle lanes take the next positions, in lane order
+            const int64_t mine = q + __popcll(idle & ((1ull << lane) - 1ull));
+            if (!has && mine < qend) {
+                idx = ((gw + (mine >> 6) * W) << 6) + (mine & 63);
+                if (idx < n) {
+                    const double px = x[idx], py = y[idx];
+                    double cs, sn;
+                    avp_sincos(th[idx], sn, cs);
+                    fx = px + p.circ_cf * cs; fy = py + p.circ_cf * sn;
+                    rx = px + p.circ_cr * cs; ry = py + p.circ_cr * sn;
+                    double right, left, upper, down;
+                    if (fx >= rx) { right = fx + Rd; left = rx - Rd; } else { right = rx + Rd; left = fx - Rd; }
+                    if (fy >= ry) { upper = fy + Rd; down = ry - Rd; } else { upper = ry + Rd; down = fy - Rd; }
+                    ix = avp_first_gt(m.X, m.nx, m.b0, m.dx, left); ixhi = avp_last_lt(m.X, m.nx, m.b0, m.dx, right);
+                    iylo = avp_first_gt(m.Y, m.ny, m.b2, m.dy, down); iyhi = avp_last_lt(m.Y, m.ny, m.b2, m.dy, upper);
+                    hit = false;
+                    if (iylo <= iyhi && ix <= ixhi) has = true;
+                    else out[idx] = 0;                                         // no near point at all
                 }
             }
+            q += nidle;                                                       // (positions past qend or past n hand out nothing)
+            continue;
         }
-        drain();
-        if (valid) out[i] = sHit[lane];
+        if (nidle == 64) break;                                               // nothing walking, nothing left
+        if (has) {
+            // one map column (the walk of check_circle_kernel, one trip of its outer loop)
+            const double px = m.X[ix];
+            for (int w = iylo >> 6; w <= (iyhi >> 6) && !hit; w++) {
+                uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+                if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
+                if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
+                while (bits && !hit) {
+                    const int bpos = __ffsll((unsigned long long)bits) - 1;
+                    bits &= bits - 1;
+                    const double py = m.Y[(w << 6) + bpos];
+                    const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
+                    if (avp_circle_hit(d0x, d0y, Rd)) hit = true;
+                    else if (avp_circle_hit(d1x, d1y, Rd)) hit = true;
+                }
+            }
+            ix++;
+            if (hit || ix > ixhi) { out[idx] = hit ? 1 : 0; has = false; }
+        }
     }
-}
-static inline size_t check_circle_lds_bytes(const DevMap& m, bool stage, int waves)
-{
-    const size_t perWave = 64 * CIR_RECW + CIR_QCAP / 2 + 8;
-    return ((stage ? (size_t)m.nx * m.wpc + m.nx + m.ny : 0) + (size_t)waves * perWave) * 8;
 }
 
 // ---- corridor bounds (path_opti.compute_collision_H, optimization/path_optimazition.py:221-409) -------

@@ -748,7 +748,7 @@ def main():
                 order = np.random.default_rng(0).permutation(nb).astype(np.int32)
                 one = o.plan_batch(g0.starts[:nb], g0.goals[:nb], threads=1, min_seconds=5.0, order=order)
                 per_thread = {}
-                for nt, secs in ((ncore, 10.0), (max(1, ncore // 2), 6.0)):
+                for nt, secs in ((ncore, 8.0), (max(1, ncore // 2), 6.0), (max(1, ncore // 4), 4.0), (max(1, ncore // 8), 3.0), (max(1, ncore // 16), 3.0)):
                     if nt in per_thread:
                         continue
                     bb = o.plan_batch(g0.starts[:nb], g0.goals[:nb], threads=nt, min_seconds=secs, order=order)

@@ -1439,6 +1439,7 @@ ORC_API int orc_rasterize_edges(const double *xs, const double *ys, int nx, int 
 #include <pthread.h>
 #include <stdatomic.h>
 #include <time.h>
+#include <malloc.h>
 
 typedef struct {
     const orc_ctx *c; const double *starts, *goals; const int32_t *order;
@@ -1478,6 +1479,13 @@ ORC_API int32_t orc_plan_batch(const orc_ctx *c, const double *starts, const dou
                                int64_t totals[3], double *elapsed)
 {
     if (!c || n <= 0 || threads <= 0 || !starts || !goals) return -1;
+    /* orc_plan allocates its Dijkstra pool, heaps and hash maps per call (3 - 20 MB, grown by realloc): with glibc's defaults every
+     * one of them is an mmap / munmap pair, and a hundred threads then queue on the process's address-space lock (measured on the
+     * GPU box's 128 cores before this: 11 x one core). Keep freed memory in the per-thread arenas instead: no mmap for blocks
+     * below 32 MB, no trimming. Allocation strategy only -- nothing orc_plan computes depends on it. */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 16 << 20);
     orc_batch_t b;
     b.c = c; b.starts = starts; b.goals = goals; b.order = order; b.n = n;
     b.steady = min_seconds > 0.0; b.status = status; b.pops_out = pops;
