@@ -192,20 +192,33 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
     AVP_ON_DEVICE(map->device);
     const DevMap& d = map->dev;
     if (kind == 1) {
-        if (variant == 1) {
-            // the plain lane-per-pose walk (the on-device cross-check)
+        // variant 1: the plain lane-per-pose walk, one launch block per 256 poses (the on-device cross-check);
+        // variants 2 .. 5 (measurement): persistent tiles -- 2 walk / L1-L2, 3 walk / LDS tables, 4 refill / L1-L2, 5 refill / LDS tables;
+        // variant 0: the production choice among them (CIR_PRODUCTION)
+        int v = variant == 0 ? CIR_PRODUCTION : variant;
+        const size_t tab = check_circle_lds_bytes(d);
+        if ((v == 3 || v == 5) && tab + AVP_LDS_TABLE_BYTES > 64 * 1024) v -= 1;        // (tables too large to stage with several workgroups per CU)
+        if (v == 1) {
             const int64_t blocks = (n + 255) / 256;
             hipLaunchKernelGGL(check_circle_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
         } else {
-            // lane per pose with refill: persistent waves over strided 64-pose tiles, ~4 waves per SIMD; a wave wants a few hundred
-            // poses of its own (the refill runs dry at the end of a wave's share), so small batches launch fewer waves
+            // persistent waves over strided 64-pose tiles; a refilling wave wants a few hundred poses of its own (the refill runs dry at
+            // the end of its share), so small batches launch fewer waves
+            const bool refill = v >= 4, stage = v == 3 || v == 5;
             const int64_t tiles = (n + 63) / 64;
-            int64_t waves = tiles / 4;                       // >= 256 poses per wave
-            const int64_t cap = (int64_t)map->n_cu * 16;     // 4 waves per SIMD
+            int64_t waves = refill ? tiles / 4 : tiles;
+            int64_t per_cu = stage ? (int64_t)((160 * 1024 - 4096) / (tab + AVP_LDS_TABLE_BYTES)) * 4 : 28;     // waves per CU: LDS copies of the tables, <= 7 per SIMD
+            if (per_cu > 28) per_cu = 28;
+            if (refill && per_cu > 16) per_cu = 16;
+            const int64_t cap = (int64_t)map->n_cu * per_cu;
             if (waves > cap) waves = cap;
             if (waves < 1) waves = 1;
             const int64_t blocks = (waves + 3) / 4;
-            hipLaunchKernelGGL(check_circle_refill_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
+            const size_t lds = stage ? tab : 0;
+            auto kern = stage ? (refill ? check_circle_tiles_kernel<true, true> : check_circle_tiles_kernel<true, false>)
+                              : (refill ? check_circle_tiles_kernel<false, true> : check_circle_tiles_kernel<false, false>);
+            if (stage) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, map->stream, d, map->params, x, y, th, n, out);
         }
     } else if (kind == 0) {
         // the production kernel assumes the footprint AABB spans at most two 64-row bitmap words

@@ -312,12 +312,33 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
 // (tests/test_gpu_check.py kind = 1 against variant 1, the oracle and golden G3). At least half the lanes are live on
 // every trip by construction.
 #define CIR_REFILL_AT 32            // idle lanes that trigger a refill
-__global__ __launch_bounds__(256) void check_circle_refill_kernel(DevMap m, avp_params p, const double* __restrict__ x,
-                                                                  const double* __restrict__ y, const double* __restrict__ th,
-                                                                  int64_t n, uint8_t* __restrict__ out)
+#ifndef CIR_PRODUCTION
+#define CIR_PRODUCTION 1             // avp_check_batch(kind = 1, variant = 0) runs this variant (see avp_capi.hip; chosen by measurement)
+#endif
+// REFILL: the scheme above; !REFILL: the plain walk of check_circle_kernel, a wave per 64-pose tile, persistent. STAGE: the column
+// bitmaps and node coordinates staged in LDS once per workgroup (as in check_distance_kernel), else read through L1 / L2.
+template <bool STAGE, bool REFILL>
+__global__ __launch_bounds__(256) void check_circle_tiles_kernel(DevMap m, avp_params p, const double* __restrict__ x,
+                                                                 const double* __restrict__ y, const double* __restrict__ th,
+                                                                 int64_t n, uint8_t* __restrict__ out)
 {
     avp_lds_tables_fill<false>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename ChkTabs<STAGE>::D TD;
+    typedef typename ChkTabs<STAGE>::B TB;
+    TB sBits; TD sX, sY;
+    if constexpr (STAGE) {
+        uint64_t* lBits = (uint64_t*)smem;
+        double* lX = (double*)(lBits + (size_t)m.nx * m.wpc);
+        double* lY = lX + m.nx;
+        for (int i = threadIdx.x; i < m.nx * m.wpc; i += blockDim.x) lBits[i] = m.colBits[i];
+        for (int i = threadIdx.x; i < m.nx; i += blockDim.x) lX[i] = m.X[i];
+        for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
+        __syncthreads();
+        sBits = (TB)lBits; sX = (TD)lX; sY = (TD)lY;
+    } else { sBits = m.colBits; sX = m.X; sY = m.Y; }
     const int lane = threadIdx.x & 63;
+    const int wpc = m.wpc;
     const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);                 // waves of the launch
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t tiles = (n + 63) / 64;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(256) void check_circle_refill_kernel(DevMap m, avp_
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const int nidle = __popcll(idle);
-        if (q < qend && (nidle >= CIR_REFILL_AT || nidle == 64)) {
+        if (q < qend && (REFILL ? (nidle >= CIR_REFILL_AT || nidle == 64) : nidle == 64)) {
             // the idle lanes take the next positions, in lane order
             const int64_t mine = q + __popcll(idle & ((1ull << lane) - 1ull));
             if (!has && mine < qend) {
@@ -347,8 +368,8 @@ __global__ __launch_bounds__(256) void check_circle_refill_kernel(DevMap m, avp_
                     double right, left, upper, down;
                     if (fx >= rx) { right = fx + Rd; left = rx - Rd; } else { right = rx + Rd; left = fx - Rd; }
                     if (fy >= ry) { upper = fy + Rd; down = ry - Rd; } else { upper = ry + Rd; down = fy - Rd; }
-                    ix = avp_first_gt(m.X, m.nx, m.b0, m.dx, left); ixhi = avp_last_lt(m.X, m.nx, m.b0, m.dx, right);
-                    iylo = avp_first_gt(m.Y, m.ny, m.b2, m.dy, down); iyhi = avp_last_lt(m.Y, m.ny, m.b2, m.dy, upper);
+                    ix = avp_first_gt(sX, m.nx, m.b0, m.dx, left); ixhi = avp_last_lt(sX, m.nx, m.b0, m.dx, right);
+                    iylo = avp_first_gt(sY, m.ny, m.b2, m.dy, down); iyhi = avp_last_lt(sY, m.ny, m.b2, m.dy, upper);
                     hit = false;
                     if (iylo <= iyhi && ix <= ixhi) has = true;
                     else out[idx] = 0;                                         // no near point at all
@@ -360,15 +381,15 @@ __global__ __launch_bounds__(256) void check_circle_refill_kernel(DevMap m, avp_
         if (nidle == 64) break;                                               // nothing walking, nothing left
         if (has) {
             // one map column (the walk of check_circle_kernel, one trip of its outer loop)
-            const double px = m.X[ix];
+            const double px = sX[ix];
             for (int w = iylo >> 6; w <= (iyhi >> 6) && !hit; w++) {
-                uint64_t bits = m.colBits[(size_t)ix * m.wpc + w];
+                uint64_t bits = sBits[(size_t)ix * wpc + w];
                 if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
                 if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
                 while (bits && !hit) {
                     const int bpos = __ffsll((unsigned long long)bits) - 1;
                     bits &= bits - 1;
-                    const double py = m.Y[(w << 6) + bpos];
+                    const double py = sY[(w << 6) + bpos];
                     const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
                     if (avp_circle_hit(d0x, d0y, Rd)) hit = true;
                     else if (avp_circle_hit(d1x, d1y, Rd)) hit = true;
@@ -379,6 +400,7 @@ __global__ __launch_bounds__(256) void check_circle_refill_kernel(DevMap m, avp_
         }
     }
 }
+static inline size_t check_circle_lds_bytes(const DevMap& m) { return ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8; }
 
 // ---- corridor bounds (path_opti.compute_collision_H, optimization/path_optimazition.py:221-409) -------
 // One lane = one way-point. Near points = obstacle cells inside the footprint AABB grown by expand_dis

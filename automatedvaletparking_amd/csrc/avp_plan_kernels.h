@@ -104,6 +104,16 @@ struct PlHeapEnt { double f; uint32_t node; uint32_t pad; };
 #define PL_HEAP_POS 1
 #endif
 
+// PL_FUSE (round 5): a record pop spent six workgroup barriers and a dependent global load of its node around ~20 k cycles of
+// work. With it a pop whose resolution takes the fast path on wave 0 runs on three: the loop-top barrier goes (nothing is read
+// between the end of a pop and its pop section by a wave other than wave 0), the barrier between the record's unpacking and
+// the resolution goes (thread 0 presets the resolution's flags before the barrier behind the unpacking), the pop's closing
+// bookkeeping is done by lane 0 of wave 0 behind its resolution, ahead of the barrier that ends it, and the popped node's record
+// comes from an LDS copy made by the wave that fetched its expansion record. Same results (tests/test_gpu_lookahead.py).
+#ifndef PL_FUSE
+#define PL_FUSE 1
+#endif
+static_assert(sizeof(PlNode) == 72, "PlNode is nine 64-bit words (PlShared::cn_w)");
 struct PlanWs {                       // per-slot workspace carve (device pointers)
     uint32_t* dist;                   // [idCap]
     uint8_t* flags;                   // [idCap]
@@ -431,7 +441,7 @@ struct PlShared {
     DevMap km; avp_params kp; PlanDims kdims; PlanWs kw; PlLook klook;
     const double* k_starts; const double* k_goals; avp_plan_result_dev* k_results; double* k_paths; int32_t k_max_path, k_pad;
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
-    double cn_th; int32_t cn_forward, cn_index;   // the popped node as the called resolution reads it (plk_resolve_fast)
+    unsigned long long cn_w[9]; int32_t cn_node, bk_done;   // PL_FUSE: the next pop's node record, copied beside its expansion record (plk_look_fetch); the pop's closing bookkeeping is done
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
@@ -1191,69 +1201,6 @@ AVP_D int pl_rs_sample_book(S& s, const avp_params& p)
     s.smp_hi = hi;
     return 0;
 }
-// The same bookkeeping by a WHOLE WAVE (plan_kernel's wave 0, round 5). The chain pd += d is serial -- repeated floating-point
-// addition does not parallelise bit for bit -- but what the one-lane loop above spends per entry is mostly not the addition:
-// an address, two LDS stores, a compare and a branch per sample (9.1 k cycles for <= 76 samples on the critical path of a
-// long pop, profiles/r04_plan_kernel_phase_cycles.json). Here every lane runs the chain in registers, EIGHT steps per trip:
-// eight dependent additions, eight independent compares, the eight values stored at once behind one address (values past
-// the segment's end land on indices that a LATER write of this function overwrites, or beyond smp_hi, which nobody reads:
-// generate_local_course's own "later writes win" order), and smp_seg is not written in the loop at all -- segment j
-// always starts writing at the index segment j - 1 ended on, so the owner of index i is the number of segment starts
-// a_1 .. a_{n-1} that are <= i, filled in by all lanes afterwards. Same smp_l / smp_seg / smp_hi / smp_point_num.
-#ifndef PL_BOOK_WAVE
-#define PL_BOOK_WAVE 1
-#endif
-template <class S>
-AVP_D int pl_rs_sample_book_wave(S& s, const avp_params& p)
-{
-    const int lane = threadIdx.x & 63;
-    const double step = 0.5 * p.maxc;
-    const int n = s.rs.n;
-    double lr[AVP_RS_MAXSEG];
-#pragma unroll
-    for (int i = 0; i < AVP_RS_MAXSEG; i++) lr[i] = s.rs.l[i];
-    const int point_num = (int)(s.rs.L / step) + n + 3;
-    if (lane == 0) { s.smp_point_num = point_num; s.smp_hi = 0; }
-    if (point_num > S::RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) return 5;
-    int ind = 1, hi = 0;
-    double d = lr[0] > 0.0 ? step : -step;
-    double pd = d, ll = 0.0;
-    int a1 = 0x7fffffff, a2 = 0x7fffffff, a3 = 0x7fffffff, a4 = 0x7fffffff;      // first index written by segments 1 .. 4
-#pragma unroll
-    for (int i = 0; i < AVP_RS_MAXSEG; i++) {
-        if (i < n) {
-            const double l = lr[i], al = fabs(l);
-            d = l > 0.0 ? step : -step;
-            ind -= 1;
-            if (i >= 1 && (lr[i >= 1 ? i - 1 : 0] * l) > 0) pd = -d - ll; else pd = d - ll;
-            if (i == 1) a1 = ind + 1; else if (i == 2) a2 = ind + 1; else if (i == 3) a3 = ind + 1; else if (i == 4) a4 = ind + 1;
-            for (;;) {
-                const double p1 = pd, p2 = p1 + d, p3 = p2 + d, p4 = p3 + d, p5 = p4 + d, p6 = p5 + d, p7 = p6 + d, p8 = p7 + d;
-                const bool o1 = fabs(p1) <= al, o2 = o1 && fabs(p2) <= al, o3 = o2 && fabs(p3) <= al, o4 = o3 && fabs(p4) <= al,
-                           o5 = o4 && fabs(p5) <= al, o6 = o5 && fabs(p6) <= al, o7 = o6 && fabs(p7) <= al, o8 = o7 && fabs(p8) <= al;
-                const int c = (int)o1 + (int)o2 + (int)o3 + (int)o4 + (int)o5 + (int)o6 + (int)o7 + (int)o8;
-                if (lane == 0) {
-                    double* q = &s.smp_l[ind + 1];
-                    if (ind + 8 < S::RS_CAP) { q[0] = p1; q[1] = p2; q[2] = p3; q[3] = p4; q[4] = p5; q[5] = p6; q[6] = p7; q[7] = p8; }
-                    else {                                  // (the end of the buffer: the entries that count, no more)
-                        if (o1) q[0] = p1; if (o2) q[1] = p2; if (o3) q[2] = p3; if (o4) q[3] = p4;
-                        if (o5) q[4] = p5; if (o6) q[5] = p6; if (o7) q[6] = p7; if (o8) q[7] = p8;
-                    }
-                }
-                ind += c;
-                if (!o8) { pd = !o1 ? p1 : !o2 ? p2 : !o3 ? p3 : !o4 ? p4 : !o5 ? p5 : !o6 ? p6 : !o7 ? p7 : p8; break; }
-                pd = p8 + d;
-            }
-            ll = l - pd - d;
-            ind += 1;
-            if (lane == 0) s.smp_l[ind] = l;
-            if (ind > hi) hi = ind;
-        }
-    }
-    for (int i = lane; i <= hi; i += 64) s.smp_seg[i] = (int8_t)((int)(i >= a1) + (int)(i >= a2) + (int)(i >= a3) + (int)(i >= a4));
-    if (lane == 0) s.smp_hi = hi;
-    return 0;
-}
 template <class S>
 AVP_D void pl_rs_sample_origins(S& s, const avp_params& p)
 {
@@ -1870,6 +1817,12 @@ __device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& 
                                               int64_t hashCap = 0, int nchild = 0, bool lookups = false)
 {
     int ok = 0;
+#if PL_FUSE
+    // the node record of the pop that follows, for every wave of that pop (its fields are final once it is the popped root;
+    // state / heap_pos, which the pop-ahead may still be writing, are not read from this copy)
+    if (node >= 0 && lane < 9) s.cn_w[lane] = ((const unsigned long long*)&w.nodes[node])[lane];
+    if (lane == 0) s.cn_node = node;
+#endif
     if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
         if (node == s.pre_node && s.pre_ok) ok = 1;
         else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true);
@@ -2045,202 +1998,6 @@ __device__ __noinline__ void plk_write_result(AVP_LDS PlShared* sp, int64_t pid,
     pl_write_result<PROFILE>(s.kp, s.kw, s, s.k_travel_ddt, s.k_dth_ddt, s.k_results, s.k_paths, s.k_max_path, pid, n_pops, slot, t_fin);
 }
 
-// the child resolution on wave 0 and its writer wave as CALLED functions (round 5): inlined -- the resolution at two sites -- they
-// held the lookahead instantiation at 256 VGPRs with two dozen spill slots. They read the popped node's three fields the
-// resolution needs (heading, gear, index) and every kernel argument through PlShared's LDS copies.
-#ifndef PL_RESOLVE_CALL
-#define PL_RESOLVE_CALL 1
-#endif
-template <bool PROFILE>
-__device__ __noinline__ void plk_resolve_fast(AVP_LDS PlShared* sp, int nchild, int pop_ahead, int split)
-{
-    PlShared& s = *(PlShared*)sp;
-    PlNode cn;
-    cn.th = s.cn_th; cn.forward = (int8_t)s.cn_forward; cn.index = s.cn_index;
-    pl_resolve_fast_wave<PROFILE>(s.km, s.kp, s.kw, s, s.kdims, cn, nchild, pop_ahead != 0, split != 0);
-}
-__device__ __noinline__ void plk_resolve_writer(AVP_LDS PlShared* sp, int nchild)
-{
-    PlShared& s = *(PlShared*)sp;
-    PlNode cn;
-    cn.index = s.cn_index;
-    pl_resolve_writer_wave(s.kp, s.kw, s, s.kdims, cn, nchild);
-}
-// one step of the SLOW path of the child resolution (expand_node :153-232 in child order, ONE thread; it stops where a
-// heuristic query misses the closed frontier and the workgroup has to extend the sweep). A called function: the rare path's
-// registers stay out of the pop loop.
-__device__ __noinline__ void plk_resolve_slow_step(AVP_LDS PlShared* sp, int nchild, int32_t maxNodes)
-{
-    PlShared& s = *(PlShared*)sp;
-    const DevMap& m = s.km;
-    const avp_params& p = s.kp;
-    const PlanWs& w = s.kw;
-    const PlanDims& dims = s.kdims;
-    PlNode cn;
-    cn.th = s.cn_th; cn.forward = (int8_t)s.cn_forward; cn.index = s.cn_index;
-    s.need_sweep = 0;
-    int i = s.next_child;
-    for (; i < nchild && s.status == 0; i++) {
-        const PlChild c = s.child[i];
-        const int si = i % p.n_steer;
-        const int is_forward = i < p.n_steer ? 1 : 0;
-        const bool found_closed = c.found >= 0 && c.found_state == 2;
-        if (s.closed_nonempty && (found_closed || c.oob)) continue;          // :155-165
-        const bool found_open = c.found >= 0 && c.found_state == 1;
-        if (!found_open && c.first_coll != 0x7fffffff) {
-            s.n_checks += c.first_coll + 1;
-            if (s.nnodes >= maxNodes) { s.status = 5; break; }
-            const int32_t pos = s.nnodes++;
-            PlNode& nd = w.nodes[pos];
-            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = 0; nd.h = 0; nd.f = 0;
-            nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
-            nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 2; nd.heap_pos = -1;
-            pl_hash_put(w, dims.hashCap, pos);
-            s.nclosed++; s.closed_nonempty = 1;
-            continue;
-        }
-        // heuristic query (hit: answered here; miss: hand over to the workgroup)
-        uint32_t hd;
-        if (s.have_d) { hd = s.hq_d; s.have_d = 0; }
-        else if (!pl_hquery_hit(m, s, c.id, c.pre_d, hd)) { s.pending_id = c.id; s.need_sweep = 1; break; }
-        if (hd == PL_UNSEEN) { if (!found_open) s.n_checks += p.n_sub; s.status = s.qover ? 5 : 2; break; }
-        s.n_rs += 1;
-        if (c.rs_err) { s.status = c.rs_err == 4 ? 5 : 3; break; }
-        const double hv1 = (double)hd / 100, hv2 = c.L;
-        const double hval = hv2 > hv1 ? hv2 : hv1;
-        if (!found_open) {
-            s.n_checks += p.n_sub;
-            if (s.nnodes >= maxNodes) { s.status = 5; break; }
-            const double g = pl_node_cost(p, is_forward, c.th, cn.th, cn.forward);
-            const int32_t pos = s.nnodes++;
-            PlNode& nd = w.nodes[pos];
-            nd.x = c.x; nd.y = c.y; nd.th = c.th; nd.g = g; nd.h = hval; nd.f = g + hval;
-            nd.index = (int32_t)(s.global_index + i + 1); nd.parent_index = cn.index; nd.parent_pos = s.cur;
-            nd.forward = (int8_t)is_forward; nd.steer_i = (int8_t)si; nd.state = 1;
-            pl_heap_push(w, s, (uint32_t)pos, g + hval);
-            pl_hash_put(w, dims.hashCap, pos);
-        } else {
-            PlNode& ch = w.nodes[c.found];
-            const double new_g = pl_node_cost(p, ch.forward, ch.th, cn.th, cn.forward);
-            const double new_f = hval + new_g;
-            if (new_f < ch.f) {
-                ch.f = new_f; ch.g = new_g; ch.h = hval;
-                pl_heap_set_key(w, s, PlShared::HEAP_POS ? ch.heap_pos : pl_heap_find(w, s, s.nheap, (uint32_t)c.found), new_f);
-                ch.parent_index = cn.index; ch.parent_pos = s.cur;
-                ch.forward = (int8_t)is_forward; ch.steer_i = (int8_t)si;
-            }
-        }
-    }
-    s.next_child = i;
-}
-// a helper publishes its half of an expansion record: payload, then the half's ready bit (one wave; a called function)
-__device__ __noinline__ void plk_look_publish(AVP_LDS PlShared* sp, int32_t maxNodes, int nchild, int hS, int in_radius)
-{
-    PlShared& s = *(PlShared*)sp;
-    const PlLook& look = s.klook;
-    const int lane = threadIdx.x & 63;
-    const bool hC = !hS;
-    const unsigned long long j0 = s.job[0];
-    const size_t ri = pl_look_idx(PL_JOB_PID(j0), maxNodes, PL_JOB_NODE(j0), PL_JOB_SLOT(j0));
-    unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
-    if (hC && lane < nchild) {
-        const PlChild& c = s.child[lane];
-        pl_st64(rp + lane, pl_bits(c.x)); pl_st64(rp + 16 + lane, pl_bits(c.y)); pl_st64(rp + 32 + lane, pl_bits(c.th));
-        pl_st64(rp + 48 + lane, pl_bits(c.L));
-        pl_st64(rp + 64 + lane, (unsigned long long)(uint32_t)c.first_coll | ((unsigned long long)(uint8_t)c.rs_err << 32));
-    }
-    if (lane == 63) {
-        // (the key words are written by both halves, with the same values)
-        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, pl_look_key3(PL_JOB_PID(j0), pl_unbits(s.job[6])));
-        pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
-        if (hS) {
-            pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
-            pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
-        }
-    }
-    PL_LOOK_DRAIN();
-    wave_sync();
-    if (lane == 0) { PL_FLAG_OR32(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
-    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
-}
-// a record pop's first step: the helper's expansion record (s.recb[s.rec_cur]) unpacked into the per-child state the resolution
-// reads (whole workgroup; a called function)
-__device__ __noinline__ void plk_rec_unpack(AVP_LDS PlShared* sp, int nchild, int in_radius)
-{
-    PlShared& s = *(PlShared*)sp;
-    const DevMap& m = s.km;
-    const PlanWs& w = s.kw;
-    const PlanDims& dims = s.kdims;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const unsigned long long* rec = s.recb[s.rec_cur];
-    const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
-    if (wave == 2 && lane < nchild) {
-        // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
-        const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
-        s.child[lane].pre_d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
-    }
-    if (tid == 0) {
-        const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
-        s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
-        s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
-        if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
-    }
-    if (tid < nchild) {
-        PlChild& c = s.child[tid];
-        c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
-        c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
-        if (nf) { c.found = s.nf_found[tid]; c.found_state = s.nf_state[tid]; }
-        else {
-            c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
-            c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
-        }
-        c.id = avp_pos_to_index(m, c.x, c.y);
-        c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
-        c.rs_err = (int8_t)(rec[64 + tid] >> 32);
-        c.L = pl_unbits(rec[48 + tid]);
-    }
-}
-// set_path + arg-min of the Reeds-Shepp queries of a pop as called functions (their unrolled type groups -- kept[4][5] -- and the
-// fold's winner stay out of the pop loop's registers): the shot's query on wave 0, the children's on the other waves, up to
-// two queries per wave at a time (lanes 0..19 / 32..51 run the type groups of one each).
-__device__ __noinline__ int plk_shot_accept_fold(AVP_LDS PlShared* sp)
-{
-    PlShared& s = *(PlShared*)sp;
-    const int lane = threadIdx.x & 63;
-    if (lane < 20) pl_rs_accept_group(s, s.kp, 0, lane);
-    wave_sync();
-    RsPath rp;
-    const int st = pl_rs_fold_wave(s, 0, rp);
-    if (lane == 0 && !st) s.rs = rp;
-    return st;
-}
-__device__ __noinline__ void plk_children_fold(AVP_LDS PlShared* sp, int base, int cnt, int q_first, int qoff)
-{
-    PlShared& s = *(PlShared*)sp;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int nwave = PL_THREADS / 64;
-    const double maxc = s.kp.maxc;
-    for (int q = q_first + (wave - 1); q < cnt; q += 2 * (nwave - 1)) {
-        const int q2 = q + (nwave - 1);
-        const int half = lane >> 5, gl = lane & 31;
-        const int qa = half ? q2 : q;
-        if (gl < 20 && qa < cnt) pl_rs_accept_group(s, s.kp, qa, gl);
-        wave_sync();
-        for (int k = 0; k < 2; k++) {
-            const int qq = k ? q2 : q;
-            if (qq >= cnt) break;
-            RsPath rp;
-            const int st = pl_rs_fold_wave(s, qq, rp);
-            if (lane == 0) { const int g = base + qq; s.child[g - qoff].rs_err = (int8_t)st; s.child[g - qoff].L = st ? 0.0 : rp.L / maxc; }
-        }
-    }
-}
-// the sampler's index bookkeeping by one wave (a called function: its chain of eight-step trips stays out of the pop loop's registers)
-__device__ __noinline__ int plk_book_wave(AVP_LDS PlShared* sp)
-{
-    PlShared& s = *(PlShared*)sp;
-    return pl_rs_sample_book_wave(s, s.kp);
-}
 // the owner side of the lookahead (one wave each), as called functions: five call sites in the pop loop
 __device__ __noinline__ void plk_look_post(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, uint32_t node, int kids,
                                            double cnx, double cny, double cnth, int cn_forward, int cn_steer)
@@ -2346,12 +2103,24 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         const int nwave = PL_THREADS / 64;
         int64_t n_pops = 0;
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
+#if PL_FUSE
+        bool first_pop = true;
+        if (tid == 0) { s.cn_node = -1; s.bk_done = 0; }
+        if (s.status == 0 && !s.done) for (;;) {
+            // (owners: between the barrier that ends a pop and the one behind the pop section no wave but wave 0 reads anything the
+            //  pop section writes, so the loop-top barrier is needed on the first trip only -- the entry test above -- and by the
+            //  helpers, whose `continue`s come here straight from reading s.job_skip)
+            if (first_pop || helper) __syncthreads();
+            first_pop = false;
+#else
         while (s.status == 0 && !s.done) {
             __syncthreads();
+#endif
             { const long long t_pop = PH_NOW();
             const int ahead = s.have_next;
             if (tid == 0 && !helper) {
-                if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }     // popped ahead by wave 0 (n_pops < max_pops held there)
+                if (PL_FUSE && s.status != 0) { }                              // (set by the slow path of the pop before: leave behind the barrier below)
+                else if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }     // popped ahead by wave 0 (n_pops < max_pops held there)
                 else if (s.nheap == 0) { s.status = 1; }
                 else if (n_pops >= max_pops) { s.status = 4; }
                 else {
@@ -2393,12 +2162,20 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (s.status != 0) break;
             if constexpr (LOOK) if (helper) { if (s.done) break; if (s.job_skip) continue; }
             PlNode cn;
+#if PL_FUSE
+            if (!helper && LOOK && s.cn_node == s.cur) {
+                const unsigned long long* cw = s.cn_w;
+                cn.x = pl_unbits(cw[0]); cn.y = pl_unbits(cw[1]); cn.th = pl_unbits(cw[2]); cn.g = pl_unbits(cw[3]); cn.h = pl_unbits(cw[4]); cn.f = pl_unbits(cw[5]);
+                cn.index = (int32_t)(uint32_t)cw[6]; cn.parent_index = (int32_t)(uint32_t)(cw[6] >> 32);
+                cn.parent_pos = (int32_t)(uint32_t)cw[7]; cn.heap_pos = (int32_t)(uint32_t)(cw[7] >> 32);
+                cn.forward = (int8_t)(cw[8] & 0xff); cn.steer_i = (int8_t)((cw[8] >> 8) & 0xff); cn.state = 3; cn.pad0 = 0; cn.pad1 = 0;
+            } else
+#endif
             if (!helper) cn = w.nodes[s.cur];
             else {
                 cn.x = pl_unbits(s.job[1]); cn.y = pl_unbits(s.job[2]); cn.th = pl_unbits(s.job[3]);
                 cn.g = 0; cn.h = 0; cn.f = 0; cn.index = 0; cn.parent_index = -1; cn.parent_pos = -1; cn.forward = 1; cn.steer_i = -1; cn.state = 3; cn.heap_pos = -1;
             }
-            if (PL_RESOLVE_CALL && tid == 0) { s.cn_th = cn.th; s.cn_forward = cn.forward; s.cn_index = cn.index; }      // (read behind the next workgroup barrier)
             const bool use_rec = LOOK && !helper && s.use_rec;
 #ifndef PL_PH_LONG
 #define PL_PH_LONG 0
@@ -2431,7 +2208,37 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
                 const unsigned long long* rec = s.recb[s.rec_cur];
                 if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s);      // (its record is fetched beside the resolution)
-                plk_rec_unpack((AVP_LDS PlShared*)&s, nchild, in_radius ? 1 : 0);
+                const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
+                if (wave == 2 && lane < nchild) {
+                    // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
+                    const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
+                    s.child[lane].pre_d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
+                }
+                if (tid == 0) {
+                    const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
+                    s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
+                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
+                    if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
+#if PL_FUSE
+                    // (what the block ahead of the resolution sets: with can_fast -- stable since the pop before ended -- the resolution
+                    //  starts right behind the barrier below)
+                    s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = (s.closed_nonempty && (s.nnodes + nchild <= maxNodes)) ? 1 : 0; s.bk_done = 0;
+#endif
+                }
+                if (tid < nchild) {
+                    PlChild& c = s.child[tid];
+                    c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
+                    c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
+                    if (nf) { c.found = s.nf_found[tid]; c.found_state = s.nf_state[tid]; }
+                    else {
+                        c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
+                        c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
+                    }
+                    c.id = avp_pos_to_index(m, c.x, c.y);
+                    c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
+                    c.rs_err = (int8_t)(rec[64 + tid] >> 32);
+                    c.L = pl_unbits(rec[48 + tid]);
+                }
                 PH_MARK(0);
                 __syncthreads();
                 can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
@@ -2516,29 +2323,38 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     if (wave == 0) {
                         if (base == 0 && !hC) {
                             const long long t_a0 = PH_NOW();
-                            const int st = plk_shot_accept_fold((AVP_LDS PlShared*)&s);      // (s.rs holds the path when st == 0)
-                            if (PROFILE && lane == 0) { PH_X(3, t_a0); PH_X(4, t_a0); }
-                            const bool shot = in_radius && !st;            // (st: the fold's result, the same in every lane)
+                            if (lane < 20) pl_rs_accept_group(s, p, 0, lane);
+                            wave_sync();
+                            if (PROFILE && lane == 0) PH_X(3, t_a0);
+                            RsPath rp;
+                            const int st = pl_rs_fold_wave(s, 0, rp);
+                            if (PROFILE && lane == 0) PH_X(4, t_a0);
                             if (lane == 0) {
                                 s.rs_status = in_radius ? st : 0;
+                                const bool shot = in_radius && !st;
+                                if (!st) s.rs = rp;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 *(volatile int32_t*)&s.shot_ready = shot ? 1 : 2;
-#if !PL_BOOK_WAVE
                                 if (shot) { s.n_rs += 1; const int bs = pl_rs_sample_book(s, p); if (bs) s.rs_status = bs; }
                                 if (PROFILE) PH_X(5, t_a0);
-#endif
                             }
-#if PL_BOOK_WAVE
-                            if (shot) {
-                                wave_sync();                                // (s.rs, written by lane 0, as every lane reads it)
-                                const int bs = plk_book_wave((AVP_LDS PlShared*)&s);
-                                if (lane == 0) { s.n_rs += 1; if (bs) s.rs_status = bs; }
-                            }
-                            if (PROFILE && lane == 0) PH_X(5, t_a0);
-#endif
                         }
                     } else {
-                        plk_children_fold((AVP_LDS PlShared*)&s, base, cnt, q_first, qoff);      // set_path + arg-min of this wave's child queries
+                        // up to two queries per wave at a time: lanes 0..19 / 32..51 run the type groups of one each
+                        for (int q = q_first + (wave - 1); q < cnt; q += 2 * (nwave - 1)) {
+                            const int q2 = q + (nwave - 1);
+                            const int half = lane >> 5, gl = lane & 31;
+                            const int qa = half ? q2 : q;
+                            if (gl < 20 && qa < cnt) pl_rs_accept_group(s, p, qa, gl);
+                            wave_sync();
+                            for (int k = 0; k < 2; k++) {
+                                const int qq = k ? q2 : q;
+                                if (qq >= cnt) break;
+                                RsPath rp;
+                                const int st = pl_rs_fold_wave(s, qq, rp);
+                                if (lane == 0) { const int g = base + qq; s.child[g - qoff].rs_err = (int8_t)st; s.child[g - qoff].L = st ? 0.0 : rp.L / p.maxc; }
+                            }
+                        }
                         if (wave == nwave - 1 && base == 0 && !hC) {
                             if (lane == 0) while (*(volatile int32_t*)&s.shot_ready == 0) __builtin_amdgcn_s_sleep(1);
                             wave_sync();
@@ -2574,11 +2390,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     }
                     wave_sync();
                     if (can_fast) {
-#if PL_RESOLVE_CALL
-                        plk_resolve_fast<PROFILE>((AVP_LDS PlShared*)&s, nchild, n_pops < max_pops ? 1 : 0, 0);
-#else
                         pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
-#endif
                         if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0); }
                     }
                 }
@@ -2645,7 +2457,31 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             t_f = PH_NOW();
             if (PROFILE && tid == 0) s.phase[PH_SHOT_CHECK] += t_f - t_g;
             if constexpr (LOOK) if (helper) {
-                if (wave == 0) plk_look_publish((AVP_LDS PlShared*)&s, maxNodes, nchild, hS ? 1 : 0, in_radius ? 1 : 0);      // this half of the record: payload, then its ready bit
+                // publish this half of the record: payload, then the half's ready bit
+                if (wave == 0) {
+                    const unsigned long long j0 = s.job[0];
+                    const size_t ri = pl_look_idx(PL_JOB_PID(j0), maxNodes, PL_JOB_NODE(j0), PL_JOB_SLOT(j0));
+                    unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
+                    if (hC && lane < nchild) {
+                        const PlChild& c = s.child[lane];
+                        pl_st64(rp + lane, pl_bits(c.x)); pl_st64(rp + 16 + lane, pl_bits(c.y)); pl_st64(rp + 32 + lane, pl_bits(c.th));
+                        pl_st64(rp + 48 + lane, pl_bits(c.L));
+                        pl_st64(rp + 64 + lane, (unsigned long long)(uint32_t)c.first_coll | ((unsigned long long)(uint8_t)c.rs_err << 32));
+                    }
+                    if (lane == 63) {
+                        // (the key words are written by both halves, with the same values)
+                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, pl_look_key3(PL_JOB_PID(j0), pl_unbits(s.job[6])));
+                        pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
+                        if (hS) {
+                            pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
+                            pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
+                        }
+                    }
+                    PL_LOOK_DRAIN();
+                    wave_sync();
+                    if (lane == 0) { PL_FLAG_OR32(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
+                    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
+                }
                 continue;
             }
             if (s.status != 0 || s.done) break;
@@ -2654,16 +2490,15 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
             // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
             const bool tried = !use_rec && in_radius && can_fast;   // the speculative attempt above
-            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; if (!tried) s.fast = can_fast ? 1 : 0; }
+            const bool preset = PL_FUSE && use_rec && can_fast;     // (record pop: thread 0 did this ahead of the barrier behind the unpacking)
+            if (!preset) {
+            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; if (!tried) s.fast = can_fast ? 1 : 0; if (PL_FUSE) s.bk_done = 0; }
             if (!can_fast && tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
+            }
             if (!tried && can_fast) {
                 if (wave == 0) {
-#if PL_RESOLVE_CALL
-                    plk_resolve_fast<PROFILE>((AVP_LDS PlShared*)&s, nchild, n_pops < max_pops ? 1 : 0, (LOOK && use_rec) ? 1 : 0);
-#else
                     pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops, LOOK && use_rec);
-#endif
                     if constexpr (LOOK) if (look.on) {
                         wave_sync();
                         if (use_rec) {       // (resolution left early / nothing popped ahead: release the writer and the fetcher)
@@ -2672,6 +2507,18 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         }
                         else if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0);
                     }
+#if PL_FUSE
+                    // the pop's closing bookkeeping, here instead of between two more barriers: the resolution took the fast path,
+                    // nothing else of this pop reads these (the writer wave, which reads global_index, is done: wr_done)
+                    wave_sync();
+                    if (lane == 0 && s.fast && s.status == 0) {
+                        w.nodes[s.cur].state = 2;
+                        s.nclosed++; s.closed_nonempty = 1;
+                        s.global_index += nchild;
+                        s.bk_done = 1;
+                        if (PROFILE) s.phase[PH_RESOLVE] += clock64() - t_f;
+                    }
+#endif
                 } else if (LOOK && use_rec && wave == 1) {
                     // record pop: the other waves are idle, so this one fetches the next node's record as soon as wave 0
                     // knows that node (before it sifts the heap), and does the bounded wait for a pending record
@@ -2683,11 +2530,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (*(volatile int32_t*)&s.fetch_go == 1) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.fetch_nheap, nchild, 1);
                     }
                 } else if (LOOK && use_rec && wave == 2) {
-#if PL_RESOLVE_CALL
-                    plk_resolve_writer((AVP_LDS PlShared*)&s, nchild);
-#else
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
-#endif
                 } else if (LOOK && use_rec && wave == nwave - 1) {
                     if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
                 }
@@ -2699,9 +2542,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             } else
             for (;;) {
                 if (tid == 0) {
-#if PL_RESOLVE_CALL
-                    plk_resolve_slow_step((AVP_LDS PlShared*)&s, nchild, maxNodes);
-#else
                     s.need_sweep = 0;
                     int i = s.next_child;
                     for (; i < nchild && s.status == 0; i++) {
@@ -2756,7 +2596,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         }
                     }
                     s.next_child = i;
-#endif
                 }
                 __syncthreads();
                 if (!s.need_sweep) break;
@@ -2765,6 +2604,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
                 __syncthreads();
             }
+            if (PL_FUSE && s.bk_done) { PH_MARK(4); continue; }      // (closed by wave 0 ahead of the barrier that ended its resolution)
             if (tid == 0) {
                 if (s.status == 0) {
                     w.nodes[s.cur].state = 2;
