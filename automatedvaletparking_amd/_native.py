@@ -22,7 +22,7 @@ EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
     "avp_check_batch", "avp_corridor_batch", "avp_corridor_batch_v", "avp_trig_batch", "avp_libm_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
     "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch", "avp_plan_batch_profile", "avp_plan_batch_mode", "avp_plan_batch_ex", "avp_plan_look_bytes", "avp_plan_pick_mode", "avp_plan_slots", "avp_plan_group", "avp_plan_batch_staged", "avp_plan_set_slice_pops", "avp_plan_last_launch",
-    "avp_hfield_id_capacity", "avp_hfield_queries", "avp_rasterize_edges",
+    "avp_hfield_id_capacity", "avp_hfield_queries", "avp_rasterize_edges", "avp_rasterize_edges_batch",
 ]
 
 
@@ -150,6 +150,41 @@ def rasterize_edges(xs: np.ndarray, ys: np.ndarray, edges: np.ndarray, device=No
                                       C.c_void_p(occ.data_ptr()), C.c_void_p(multi.data_ptr())), "avp_rasterize_edges")
         st.synchronize()        # d_e must outlive the launch
     return occ, int(multi.item())
+
+
+def rasterize_edges_batch(grids, edge_tables, device=None, stream=None):
+    """Batched device rasteriser (include/avp.h: avp_rasterize_edges_batch): grids = [(xs, ys)], edge_tables = [float64 [E_k, 6]], one per
+    map. ONE upload of the packed tables, ONE launch, ONE read-back: returns ([uint8 occupancy [nx_k, ny_k] numpy arrays], [multi_k])."""
+    torch = torch_cuda()
+    dev = torch.device(device if device is not None else "cuda")
+    n = len(grids)
+    if n == 0:
+        return [], []
+    nxs = np.array([len(g[0]) for g in grids], dtype=np.int32)
+    nys = np.array([len(g[1]) for g in grids], dtype=np.int32)
+    node_off = np.zeros(n, np.int64)
+    node_off[1:] = np.cumsum(nxs[:-1].astype(np.int64) + nys[:-1])
+    nodes = np.concatenate([np.concatenate([np.asarray(g[0], dtype=np.float64), np.asarray(g[1], dtype=np.float64)]) for g in grids])
+    geo = np.array([[g[0][0], g[0][1] - g[0][0], g[1][0], g[1][1] - g[1][0]] for g in grids], dtype=np.float64)
+    cells = nxs.astype(np.int64) * nys
+    occ_off = np.zeros(n, np.int64)
+    occ_off[1:] = np.cumsum(cells[:-1])
+    tabs = [np.ascontiguousarray(t, dtype=np.float64).reshape(-1, 6) for t in edge_tables]
+    edges = np.concatenate(tabs) if tabs else np.zeros((0, 6))
+    emap = np.concatenate([np.full(len(t), k, np.int32) for k, t in enumerate(tabs)]) if tabs else np.zeros(0, np.int32)
+    st = stream if stream is not None else torch.cuda.current_stream(dev)
+    d_nodes, d_edges, d_emap = torch.as_tensor(nodes, device=dev), torch.as_tensor(edges, device=dev), torch.as_tensor(emap, device=dev)
+    occ = torch.zeros(int(cells.sum()), dtype=torch.uint8, device=dev)
+    multi = torch.zeros(n, dtype=torch.int32, device=dev)
+    scratch = torch.empty(64 * n, dtype=torch.uint8, device=dev)
+    chk(lib().avp_rasterize_edges_batch(C.c_int32(dev.index if dev.index is not None else torch.cuda.current_device()), C.c_void_p(st.cuda_stream),
+                                        C.c_int32(n), C.c_void_p(d_nodes.data_ptr()), _vp(node_off), _vp(nxs), _vp(nys), _vp(np.ascontiguousarray(geo)), _vp(occ_off),
+                                        C.c_void_p(d_edges.data_ptr()), C.c_void_p(d_emap.data_ptr()), C.c_int64(len(edges)),
+                                        C.c_int32(int(edges[:, 5].max()) if len(edges) else 0), C.c_void_p(occ.data_ptr()), C.c_void_p(multi.data_ptr()),
+                                        C.c_void_p(scratch.data_ptr()), C.c_int64(scratch.numel())), "avp_rasterize_edges_batch")
+    occ_h = occ.cpu().numpy()                              # (the one synchronisation of the batch)
+    mult = multi.cpu().numpy()
+    return [occ_h[occ_off[k]:occ_off[k] + cells[k]].reshape(int(nxs[k]), int(nys[k])) for k in range(n)], [int(v) for v in mult]
 
 
 def torch_cuda():

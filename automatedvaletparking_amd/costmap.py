@@ -193,6 +193,34 @@ class Map:
         self.cost_map = occ.cpu().numpy().astype(np.float64)
         self._packed = None
 
+    @staticmethod
+    def load_batch(files, discrete_size: float = 0.1, device="cuda", cases=None):
+        """Batched TPCAP ingest (map/costmap.py:134-156 + 197-261 for a LIST of scenario files): every file parsed and its edge table
+        built on the host (numpy: the reference's own arithmetic), then ALL maps rasterised by one launch of the device rasteriser
+        with one upload and one read-back (include/avp.h: avp_rasterize_edges_batch) -- instead of one launch and one
+        synchronisation per map. The maps are those of `Map(file=f, discrete_size=..., device=device)`, cell for cell."""
+        from . import _native
+        maps = []
+        for k, f in enumerate(files):
+            m = Map.__new__(Map)
+            m.discrete_size = discrete_size
+            m.grid_index = None
+            m.cost_map = np.array([], dtype=np.float64)
+            m.map_position = np.array([], dtype=np.float64)
+            m.case = cases[k] if cases is not None else Case.read(f)
+            m.boundary = np.array([math.floor(m.case.xmin), math.floor(m.case.xmax), math.floor(m.case.ymin), math.floor(m.case.ymax)], dtype=np.float64)
+            m._discrete_x = 0
+            m._discrete_y = 0
+            m._packed = None
+            m.discrete_map()
+            maps.append(m)
+        occs, multis = _native.rasterize_edges_batch([m.map_position for m in maps], [m.edge_table() for m in maps], device=device)
+        for m, occ, multi in zip(maps, occs, multis):
+            if multi:
+                raise TypeError("only length-1 arrays can be converted to Python scalars")      # map/costmap.py:260
+            m.cost_map = occ.astype(np.float64)
+        return maps
+
     def convert_position_to_index(self, grid_x, grid_y):
         col = math.floor((grid_x - self.boundary[0]) / self._discrete_x)
         row = math.floor((self.boundary[3] - grid_y) / self._discrete_y)

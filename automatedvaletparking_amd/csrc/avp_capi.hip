@@ -192,34 +192,8 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
     AVP_ON_DEVICE(map->device);
     const DevMap& d = map->dev;
     if (kind == 1) {
-        // variant 1: the plain lane-per-pose walk, one launch block per 256 poses (the on-device cross-check);
-        // variants 2 .. 5 (measurement): persistent tiles -- 2 walk / L1-L2, 3 walk / LDS tables, 4 refill / L1-L2, 5 refill / LDS tables;
-        // variant 0: the production choice among them (CIR_PRODUCTION)
-        int v = variant == 0 ? CIR_PRODUCTION : variant;
-        const size_t tab = check_circle_lds_bytes(d);
-        if ((v == 3 || v == 5) && tab + AVP_LDS_TABLE_BYTES > 64 * 1024) v -= 1;        // (tables too large to stage with several workgroups per CU)
-        if (v == 1) {
-            const int64_t blocks = (n + 255) / 256;
-            hipLaunchKernelGGL(check_circle_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
-        } else {
-            // persistent waves over strided 64-pose tiles; a refilling wave wants a few hundred poses of its own (the refill runs dry at
-            // the end of its share), so small batches launch fewer waves
-            const bool refill = v >= 4, stage = v == 3 || v == 5;
-            const int64_t tiles = (n + 63) / 64;
-            int64_t waves = refill ? tiles / 4 : tiles;
-            int64_t per_cu = stage ? (int64_t)((160 * 1024 - 4096) / (tab + AVP_LDS_TABLE_BYTES)) * 4 : 28;     // waves per CU: LDS copies of the tables, <= 7 per SIMD
-            if (per_cu > 28) per_cu = 28;
-            if (refill && per_cu > 16) per_cu = 16;
-            const int64_t cap = (int64_t)map->n_cu * per_cu;
-            if (waves > cap) waves = cap;
-            if (waves < 1) waves = 1;
-            const int64_t blocks = (waves + 3) / 4;
-            const size_t lds = stage ? tab : 0;
-            auto kern = stage ? (refill ? check_circle_tiles_kernel<true, true> : check_circle_tiles_kernel<true, false>)
-                              : (refill ? check_circle_tiles_kernel<false, true> : check_circle_tiles_kernel<false, false>);
-            if (stage) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, map->stream, d, map->params, x, y, th, n, out);
-        }
+        const int64_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(check_circle_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
     } else if (kind == 0) {
         // the production kernel assumes the footprint AABB spans at most two 64-row bitmap words
         const double diag = sqrt((map->params.fp_xf - map->params.fp_xr) * (map->params.fp_xf - map->params.fp_xr) +
@@ -339,6 +313,40 @@ AVP_EXPORT int32_t avp_rasterize_edges(int32_t device, void* stream, const doubl
     g.X = xs; g.Y = ys; g.nx = nx; g.ny = ny; g.dx = dx; g.dy = dy; g.b0 = x0; g.b2 = y0;
     hipLaunchKernelGGL(rasterize_kernel, dim3((unsigned)((max_count + 63) / 64), (unsigned)n_edges), dim3(64), 0, (hipStream_t)stream,
                        g, edges, n_edges, occ, multi);
+    HIPCHK(hipGetLastError());
+    return AVP_OK;
+}
+
+// Batched form ("batched TPCAP CSV ingest"): the edge tables of n_maps maps in ONE launch. nodes: device buffer
+// holding every map's X then Y table back to back (map k: X at node_off[k], Y at node_off[k] + nx[k]); geo[k] = {x0, dx, y0, dy};
+// edges / edge_map: the concatenated tables and the map of every edge (device); occ: one zeroed device buffer, map k's nx*ny bytes at
+// occ_off[k]; multi: n_maps zeroed counters (device). The descriptors are built on the host and uploaded here (one small copy).
+AVP_EXPORT int32_t avp_rasterize_edges_batch(int32_t device, void* stream, int32_t n_maps, const double* nodes, const int64_t* node_off,
+                                             const int32_t* nx, const int32_t* ny, const double* geo, const int64_t* occ_off,
+                                             const double* edges, const int32_t* edge_map, int64_t n_edges, int32_t max_count,
+                                             uint8_t* occ, int32_t* multi, void* grid_scratch, int64_t grid_scratch_bytes)
+{
+    if (n_maps < 0 || n_edges < 0 || (n_maps > 0 && (!nodes || !node_off || !nx || !ny || !geo || !occ_off || !occ || !multi || !grid_scratch)) ||
+        (n_edges > 0 && (!edges || !edge_map)))
+        return set_err(AVP_ERR_ARG, "avp_rasterize_edges_batch: bad argument");
+    if (n_maps == 0 || n_edges == 0 || max_count <= 0) return AVP_OK;
+    if (grid_scratch_bytes < (int64_t)(n_maps * sizeof(RasterGridB))) return set_err(AVP_ERR_CAPACITY, "avp_rasterize_edges_batch: grid scratch too small");
+    if (n_edges > (int64_t)65535 * 65535) return set_err(AVP_ERR_ARG, "avp_rasterize_edges_batch: too many edges");
+    DeviceGuard guard_;
+    if (device >= 0) HIPCHK(guard_.enter(device));
+    std::vector<RasterGridB> h((size_t)n_maps);
+    for (int32_t k = 0; k < n_maps; k++) {
+        if (nx[k] < 2 || ny[k] < 2 || !(geo[4 * k + 1] > 0) || !(geo[4 * k + 3] > 0)) return set_err(AVP_ERR_ARG, "avp_rasterize_edges_batch: bad map geometry");
+        RasterGrid& g = h[k].g;
+        g.X = nodes + node_off[k]; g.Y = g.X + nx[k]; g.nx = nx[k]; g.ny = ny[k];
+        g.b0 = geo[4 * k]; g.dx = geo[4 * k + 1]; g.b2 = geo[4 * k + 2]; g.dy = geo[4 * k + 3];
+        h[k].occ_off = occ_off[k];
+    }
+    HIPCHK(hipMemcpyAsync(grid_scratch, h.data(), h.size() * sizeof(RasterGridB), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));        // (the pageable host vector goes out of scope)
+    const unsigned gy = (unsigned)(n_edges < 65535 ? n_edges : 65535), gz = (unsigned)((n_edges + 65534) / 65535);
+    hipLaunchKernelGGL(rasterize_batch_kernel, dim3((unsigned)((max_count + 63) / 64), gy, gz), dim3(64), 0, (hipStream_t)stream,
+                       (const RasterGridB*)grid_scratch, edges, edge_map, n_edges, occ, multi);
     HIPCHK(hipGetLastError());
     return AVP_OK;
 }

@@ -259,6 +259,13 @@ static inline size_t check_distance_lds_bytes(const DevMap& m, bool stage, int w
 }
 
 // ---- two-circle checker (collision_check.py:88-137): lane per pose, bitmap walk ---------------
+// Round 5 measured three other shapes for this kernel against this one on the 2^20 random Case1 poses (profiles/r05_circle_variants.jsonl):
+// the distance kernel's skeleton (candidates compacted into a per-wave LDS queue, one lane per (pose, point)) 1.97 G checks/s; persistent
+// waves with the lane-per-pose walk, tables through L1 / L2 or staged in LDS, 2.56 / 2.91; the same with idle lanes REFILLED with new
+// poses as soon as half a wave is idle 2.74 / 2.93 -- against 4.0 for this plain walk at 68 registers and seven waves per SIMD. The
+// point test is two squared distances: cheaper than any machinery that feeds it full waves, and what this kernel's issue slots go to
+// is the test itself at whatever lane count a column's bits leave (19 % live lanes). So the test got cheaper instead
+// (avp_circle_hit2: the square root only within 2^-40 of the radius).
 __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params p, const double* __restrict__ x,
                                                            const double* __restrict__ y, const double* __restrict__ th,
                                                            int64_t n, uint8_t* __restrict__ out)
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
     double cs, sn;
     avp_sincos(th[i], sn, cs);
     const double Rd = p.circ_rd;
+    const AvpRd2 rd2 = avp_circle_rd2(Rd);
     const double fx = x[i] + p.circ_cf * cs, fy = y[i] + p.circ_cf * sn;
     const double rx = x[i] + p.circ_cr * cs, ry = y[i] + p.circ_cr * sn;
     double right, left, upper, down;
@@ -289,118 +297,14 @@ __global__ __launch_bounds__(256) void check_circle_kernel(DevMap m, avp_params 
                     bits &= bits - 1;
                     const double py = m.Y[(w << 6) + bpos];
                     const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
-                    if (avp_circle_hit(d0x, d0y, Rd)) hit = true;
-                    else if (avp_circle_hit(d1x, d1y, Rd)) hit = true;
+                    if (avp_circle_hit2(d0x, d0y, Rd, rd2)) hit = true;
+                    else if (avp_circle_hit2(d1x, d1y, Rd, rd2)) hit = true;
                 }
             }
         }
     }
     out[i] = hit ? 1 : 0;
 }
-
-// ---- two-circle checker, production kernel (round 5): lane per pose WITH REFILL ------------------------------------------
-// The walk above keeps 19 % of its issued lanes live (rocprofv3, round 4): poses differ in how many map columns and near
-// points they have, and a colliding pose (56 % of a random set) leaves its lane idle until the slowest pose of its wave is
-// done. The distance kernel's answer -- compact the (pose, point) candidates of a wave into an LDS queue, one lane per
-// candidate -- was built and measured for this checker in round 5 and LOST: 1.97 against 4.03 G checks/s (the point test
-// here is two squared distances, cheaper than the prefix sum and the queue traffic that feed it). What the cheap test wants
-// is full lanes on the WALK itself: a wave owns a strided set of 64-pose tiles and a cursor into them; a lane that finishes
-// its pose (hit, or last column) goes idle, and as soon as half the wave is idle -- or nothing is left to walk -- the idle
-// lanes take the next poses off the cursor and run the set-up (sin / cos, the two disc centres, the exclusive AABB filter
-// of collision_check.py:100-128, four index searches) together. Then every lane with a pose does ONE map column per trip:
-// the same words, the same masks, the same per-point test in the same order as the walk above -- the same booleans
-// (tests/test_gpu_check.py kind = 1 against variant 1, the oracle and golden G3). At least half the lanes are live on
-// every trip by construction.
-#define CIR_REFILL_AT 32            // idle lanes that trigger a refill
-#ifndef CIR_PRODUCTION
-#define CIR_PRODUCTION 1             // avp_check_batch(kind = 1, variant = 0) runs this variant (see avp_capi.hip; chosen by measurement)
-#endif
-// REFILL: the scheme above; !REFILL: the plain walk of check_circle_kernel, a wave per 64-pose tile, persistent. STAGE: the column
-// bitmaps and node coordinates staged in LDS once per workgroup (as in check_distance_kernel), else read through L1 / L2.
-template <bool STAGE, bool REFILL>
-__global__ __launch_bounds__(256) void check_circle_tiles_kernel(DevMap m, avp_params p, const double* __restrict__ x,
-                                                                 const double* __restrict__ y, const double* __restrict__ th,
-                                                                 int64_t n, uint8_t* __restrict__ out)
-{
-    avp_lds_tables_fill<false>();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef typename ChkTabs<STAGE>::D TD;
-    typedef typename ChkTabs<STAGE>::B TB;
-    TB sBits; TD sX, sY;
-    if constexpr (STAGE) {
-        uint64_t* lBits = (uint64_t*)smem;
-        double* lX = (double*)(lBits + (size_t)m.nx * m.wpc);
-        double* lY = lX + m.nx;
-        for (int i = threadIdx.x; i < m.nx * m.wpc; i += blockDim.x) lBits[i] = m.colBits[i];
-        for (int i = threadIdx.x; i < m.nx; i += blockDim.x) lX[i] = m.X[i];
-        for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
-        __syncthreads();
-        sBits = (TB)lBits; sX = (TD)lX; sY = (TD)lY;
-    } else { sBits = m.colBits; sX = m.X; sY = m.Y; }
-    const int lane = threadIdx.x & 63;
-    const int wpc = m.wpc;
-    const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);                 // waves of the launch
-    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t tiles = (n + 63) / 64;
-    // this wave's poses, in its own order: position q -> tile gw + (q >> 6) * W, pose (tile << 6) + (q & 63)
-    const int64_t my_tiles = gw < tiles ? (tiles - gw + W - 1) / W : 0;
-    const int64_t qend = my_tiles * 64;
-    int64_t q = 0;                                                            // (uniform) next position to hand out
-    const double Rd = p.circ_rd;
-    bool has = false, hit = false;
-    int64_t idx = 0;
-    double fx = 0.0, fy = 0.0, rx = 0.0, ry = 0.0;
-    int ix = 0, ixhi = -1, iylo = 0, iyhi = -1;
-    for (;;) {
-        const unsigned long long idle = __ballot(!has);
-        const int nidle = __popcll(idle);
-        if (q < qend && (REFILL ? (nidle >= CIR_REFILL_AT || nidle == 64) : nidle == 64)) {
-            // the idle lanes take the next positions, in lane order
-            const int64_t mine = q + __popcll(idle & ((1ull << lane) - 1ull));
-            if (!has && mine < qend) {
-                idx = ((gw + (mine >> 6) * W) << 6) + (mine & 63);
-                if (idx < n) {
-                    const double px = x[idx], py = y[idx];
-                    double cs, sn;
-                    avp_sincos(th[idx], sn, cs);
-                    fx = px + p.circ_cf * cs; fy = py + p.circ_cf * sn;
-                    rx = px + p.circ_cr * cs; ry = py + p.circ_cr * sn;
-                    double right, left, upper, down;
-                    if (fx >= rx) { right = fx + Rd; left = rx - Rd; } else { right = rx + Rd; left = fx - Rd; }
-                    if (fy >= ry) { upper = fy + Rd; down = ry - Rd; } else { upper = ry + Rd; down = fy - Rd; }
-                    ix = avp_first_gt(sX, m.nx, m.b0, m.dx, left); ixhi = avp_last_lt(sX, m.nx, m.b0, m.dx, right);
-                    iylo = avp_first_gt(sY, m.ny, m.b2, m.dy, down); iyhi = avp_last_lt(sY, m.ny, m.b2, m.dy, upper);
-                    hit = false;
-                    if (iylo <= iyhi && ix <= ixhi) has = true;
-                    else out[idx] = 0;                                         // no near point at all
-                }
-            }
-            q += nidle;                                                       // (positions past qend or past n hand out nothing)
-            continue;
-        }
-        if (nidle == 64) break;                                               // nothing walking, nothing left
-        if (has) {
-            // one map column (the walk of check_circle_kernel, one trip of its outer loop)
-            const double px = sX[ix];
-            for (int w = iylo >> 6; w <= (iyhi >> 6) && !hit; w++) {
-                uint64_t bits = sBits[(size_t)ix * wpc + w];
-                if (w == (iylo >> 6)) bits &= ~0ull << (iylo & 63);
-                if (w == (iyhi >> 6)) bits &= ~0ull >> (63 - (iyhi & 63));
-                while (bits && !hit) {
-                    const int bpos = __ffsll((unsigned long long)bits) - 1;
-                    bits &= bits - 1;
-                    const double py = sY[(w << 6) + bpos];
-                    const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
-                    if (avp_circle_hit(d0x, d0y, Rd)) hit = true;
-                    else if (avp_circle_hit(d1x, d1y, Rd)) hit = true;
-                }
-            }
-            ix++;
-            if (hit || ix > ixhi) { out[idx] = hit ? 1 : 0; has = false; }
-        }
-    }
-}
-static inline size_t check_circle_lds_bytes(const DevMap& m) { return ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8; }
 
 // ---- corridor bounds (path_opti.compute_collision_H, optimization/path_optimazition.py:221-409) -------
 // One lane = one way-point. Near points = obstacle cells inside the footprint AABB grown by expand_dis

@@ -45,6 +45,17 @@ AVP_HD bool avp_circle_hit(double dx, double dy, double Rd)
     if (fabs(s - Rd) > Rd * 0x1p-49) return s <= Rd;
     return avp_pow2_norm(dx, dy) <= Rd;
 }
+// ... and without the square root: d2 = dx*dx + dy*dy against Rd^2 (1 -+ 2^-40) settles all but one test in ~1e11 (s = sqrt(d2) is
+// then further than Rd 2^-41 from Rd: avp_circle_hit would return the same through its own first branch); the rest take avp_circle_hit.
+struct AvpRd2 { double lo, hi; };
+AVP_HD AvpRd2 avp_circle_rd2(double Rd) { AvpRd2 r; r.lo = (Rd * Rd) * (1.0 - 0x1p-40); r.hi = (Rd * Rd) * (1.0 + 0x1p-40); return r; }
+AVP_HD bool avp_circle_hit2(double dx, double dy, double Rd, const AvpRd2 r)
+{
+    const double d2 = dx * dx + dy * dy;
+    if (d2 < r.lo) return true;
+    if (d2 > r.hi) return false;
+    return avp_circle_hit(dx, dy, Rd);          // (NaN lands here too: both comparisons false)
+}
 AVP_HD bool avp_within_radius(double dx, double dy, double radius)
 {
     const double s = sqrt(dx * dx + dy * dy);

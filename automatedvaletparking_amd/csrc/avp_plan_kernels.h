@@ -104,16 +104,6 @@ struct PlHeapEnt { double f; uint32_t node; uint32_t pad; };
 #define PL_HEAP_POS 1
 #endif
 
-// PL_FUSE (round 5): a record pop spent six workgroup barriers and a dependent global load of its node around ~20 k cycles of
-// work. With it a pop whose resolution takes the fast path on wave 0 runs on three: the loop-top barrier goes (nothing is read
-// between the end of a pop and its pop section by a wave other than wave 0), the barrier between the record's unpacking and
-// the resolution goes (thread 0 presets the resolution's flags before the barrier behind the unpacking), the pop's closing
-// bookkeeping is done by lane 0 of wave 0 behind its resolution, ahead of the barrier that ends it, and the popped node's record
-// comes from an LDS copy made by the wave that fetched its expansion record. Same results (tests/test_gpu_lookahead.py).
-#ifndef PL_FUSE
-#define PL_FUSE 1
-#endif
-static_assert(sizeof(PlNode) == 72, "PlNode is nine 64-bit words (PlShared::cn_w)");
 struct PlanWs {                       // per-slot workspace carve (device pointers)
     uint32_t* dist;                   // [idCap]
     uint8_t* flags;                   // [idCap]
@@ -315,6 +305,7 @@ __device__ __forceinline__ bool pl_check_pose(const PlChkEnv& e, TX X, TX Y, TB 
 {
     if (e.kind == 1) {
         const double Rd = e.circ_rd;
+        const AvpRd2 rd2 = avp_circle_rd2(Rd);
         const double fx = x + e.circ_cf * cs, fy = y + e.circ_cf * sn;
         const double rx = x + e.circ_cr * cs, ry = y + e.circ_cr * sn;
         double right, left, upper, down;
@@ -334,8 +325,8 @@ __device__ __forceinline__ bool pl_check_pose(const PlChkEnv& e, TX X, TX Y, TB 
                     bits &= bits - 1;
                     const double py = Y[(w << 6) + bpos];
                     const double d0x = px - fx, d0y = py - fy, d1x = px - rx, d1y = py - ry;
-                    if (avp_circle_hit(d0x, d0y, Rd)) return true;
-                    if (avp_circle_hit(d1x, d1y, Rd)) return true;
+                    if (avp_circle_hit2(d0x, d0y, Rd, rd2)) return true;
+                    if (avp_circle_hit2(d1x, d1y, Rd, rd2)) return true;
                 }
             }
         }
@@ -441,7 +432,6 @@ struct PlShared {
     DevMap km; avp_params kp; PlanDims kdims; PlanWs kw; PlLook klook;
     const double* k_starts; const double* k_goals; avp_plan_result_dev* k_results; double* k_paths; int32_t k_max_path, k_pad;
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
-    unsigned long long cn_w[9]; int32_t cn_node, bk_done;   // PL_FUSE: the next pop's node record, copied beside its expansion record (plk_look_fetch); the pop's closing bookkeeping is done
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
     int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
@@ -1817,12 +1807,6 @@ __device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& 
                                               int64_t hashCap = 0, int nchild = 0, bool lookups = false)
 {
     int ok = 0;
-#if PL_FUSE
-    // the node record of the pop that follows, for every wave of that pop (its fields are final once it is the popped root;
-    // state / heap_pos, which the pop-ahead may still be writing, are not read from this copy)
-    if (node >= 0 && lane < 9) s.cn_w[lane] = ((const unsigned long long*)&w.nodes[node])[lane];
-    if (lane == 0) s.cn_node = node;
-#endif
     if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
         if (node == s.pre_node && s.pre_ok) ok = 1;
         else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true);
@@ -2103,24 +2087,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         const int nwave = PL_THREADS / 64;
         int64_t n_pops = 0;
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
-#if PL_FUSE
-        bool first_pop = true;
-        if (tid == 0) { s.cn_node = -1; s.bk_done = 0; }
-        if (s.status == 0 && !s.done) for (;;) {
-            // (owners: between the barrier that ends a pop and the one behind the pop section no wave but wave 0 reads anything the
-            //  pop section writes, so the loop-top barrier is needed on the first trip only -- the entry test above -- and by the
-            //  helpers, whose `continue`s come here straight from reading s.job_skip)
-            if (first_pop || helper) __syncthreads();
-            first_pop = false;
-#else
         while (s.status == 0 && !s.done) {
             __syncthreads();
-#endif
             { const long long t_pop = PH_NOW();
             const int ahead = s.have_next;
             if (tid == 0 && !helper) {
-                if (PL_FUSE && s.status != 0) { }                              // (set by the slow path of the pop before: leave behind the barrier below)
-                else if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }     // popped ahead by wave 0 (n_pops < max_pops held there)
+                if (s.have_next) { s.have_next = 0; s.cur = s.next_cur; }     // popped ahead by wave 0 (n_pops < max_pops held there)
                 else if (s.nheap == 0) { s.status = 1; }
                 else if (n_pops >= max_pops) { s.status = 4; }
                 else {
@@ -2162,15 +2134,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (s.status != 0) break;
             if constexpr (LOOK) if (helper) { if (s.done) break; if (s.job_skip) continue; }
             PlNode cn;
-#if PL_FUSE
-            if (!helper && LOOK && s.cn_node == s.cur) {
-                const unsigned long long* cw = s.cn_w;
-                cn.x = pl_unbits(cw[0]); cn.y = pl_unbits(cw[1]); cn.th = pl_unbits(cw[2]); cn.g = pl_unbits(cw[3]); cn.h = pl_unbits(cw[4]); cn.f = pl_unbits(cw[5]);
-                cn.index = (int32_t)(uint32_t)cw[6]; cn.parent_index = (int32_t)(uint32_t)(cw[6] >> 32);
-                cn.parent_pos = (int32_t)(uint32_t)cw[7]; cn.heap_pos = (int32_t)(uint32_t)(cw[7] >> 32);
-                cn.forward = (int8_t)(cw[8] & 0xff); cn.steer_i = (int8_t)((cw[8] >> 8) & 0xff); cn.state = 3; cn.pad0 = 0; cn.pad1 = 0;
-            } else
-#endif
             if (!helper) cn = w.nodes[s.cur];
             else {
                 cn.x = pl_unbits(s.job[1]); cn.y = pl_unbits(s.job[2]); cn.th = pl_unbits(s.job[3]);
@@ -2219,11 +2182,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
                     s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
                     if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
-#if PL_FUSE
-                    // (what the block ahead of the resolution sets: with can_fast -- stable since the pop before ended -- the resolution
-                    //  starts right behind the barrier below)
-                    s.next_child = 0; s.have_d = 0; s.need_sweep = 0; s.fast = (s.closed_nonempty && (s.nnodes + nchild <= maxNodes)) ? 1 : 0; s.bk_done = 0;
-#endif
                 }
                 if (tid < nchild) {
                     PlChild& c = s.child[tid];
@@ -2490,12 +2448,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
             // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
             const bool tried = !use_rec && in_radius && can_fast;   // the speculative attempt above
-            const bool preset = PL_FUSE && use_rec && can_fast;     // (record pop: thread 0 did this ahead of the barrier behind the unpacking)
-            if (!preset) {
-            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; if (!tried) s.fast = can_fast ? 1 : 0; if (PL_FUSE) s.bk_done = 0; }
+            if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; if (!tried) s.fast = can_fast ? 1 : 0; }
             if (!can_fast && tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
-            }
             if (!tried && can_fast) {
                 if (wave == 0) {
                     pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops, LOOK && use_rec);
@@ -2507,18 +2462,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         }
                         else if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0);
                     }
-#if PL_FUSE
-                    // the pop's closing bookkeeping, here instead of between two more barriers: the resolution took the fast path,
-                    // nothing else of this pop reads these (the writer wave, which reads global_index, is done: wr_done)
-                    wave_sync();
-                    if (lane == 0 && s.fast && s.status == 0) {
-                        w.nodes[s.cur].state = 2;
-                        s.nclosed++; s.closed_nonempty = 1;
-                        s.global_index += nchild;
-                        s.bk_done = 1;
-                        if (PROFILE) s.phase[PH_RESOLVE] += clock64() - t_f;
-                    }
-#endif
                 } else if (LOOK && use_rec && wave == 1) {
                     // record pop: the other waves are idle, so this one fetches the next node's record as soon as wave 0
                     // knows that node (before it sifts the heap), and does the bounded wait for a pending record
@@ -2604,7 +2547,6 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 if (tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
                 __syncthreads();
             }
-            if (PL_FUSE && s.bk_done) { PH_MARK(4); continue; }      // (closed by wave 0 ahead of the barrier that ended its resolution)
             if (tid == 0) {
                 if (s.status == 0) {
                     w.nodes[s.cur].state = 2;

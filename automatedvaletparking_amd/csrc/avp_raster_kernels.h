@@ -54,4 +54,24 @@ __global__ void rasterize_kernel(RasterGrid g, const double* __restrict__ edges,
         else if (cell == -2) atomicAdd(multi, 1);
     }
 }
+
+// Many maps in ONE launch (batched TPCAP ingest, map/costmap.py:134-156 + 197-261 for a list of scenario files): the edge tables of
+// all maps concatenated, edge e belongs to map emap[e]; a map is a grid descriptor (its node tables inside one packed buffer) and
+// the offset of its occupancy bytes inside one packed, zeroed buffer; multi[k] counts map k's multi-match samples.
+struct RasterGridB { RasterGrid g; int64_t occ_off; };
+__global__ void rasterize_batch_kernel(const RasterGridB* __restrict__ grids, const double* __restrict__ edges, const int32_t* __restrict__ emap,
+                                       int64_t n_edges, uint8_t* __restrict__ occ, int32_t* __restrict__ multi)
+{
+    const int64_t ei = (int64_t)blockIdx.y + (int64_t)blockIdx.z * 65535;
+    if (ei >= n_edges) return;
+    const int32_t k = emap[ei];
+    const RasterGridB gb = grids[k];
+    const double* e = edges + ei * 6;
+    const int count = (int)e[5];
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
+        const int64_t cell = avp_raster_cell(gb.g, e, q);
+        if (cell >= 0) occ[gb.occ_off + cell] = 255;
+        else if (cell == -2) atomicAdd(multi + k, 1);
+    }
+}
 #endif

@@ -35,6 +35,15 @@ def case_map(k, cfg, device=None):
     return costmap.Map(file=os.path.join(CASES, f"Case{k}.csv"), discrete_size=cfg["map_discrete_size"], device=device)
 
 
+def case_maps(ks, cfg, device=None):
+    """Several BenchmarkCases at once: batched ingest on the device (Map.load_batch: one rasteriser launch for all of them) or, with
+    device=None, the host rasteriser file by file. Same maps either way."""
+    files = [os.path.join(CASES, f"Case{k}.csv") for k in ks]
+    if device is None:
+        return [costmap.Map(file=f, discrete_size=cfg["map_discrete_size"]) for f in files]
+    return costmap.Map.load_batch(files, discrete_size=cfg["map_discrete_size"], device=device)
+
+
 def case1_pairs(cfg, checker, n, device=None):
     """config[1] (n = 256) and north_star's target batch (n = 4096): Case1 map, n random pairs, seed 20260927."""
     m = case_map(1, cfg, device)
@@ -42,9 +51,9 @@ def case1_pairs(cfg, checker, n, device=None):
     return m, st, go
 
 
-def c3_map_pairs(k, cfg, checker, pairs=128, device=None):
-    """config[2], map k of 20: BenchmarkCase k, `pairs` random pairs, seed 20260927 + k."""
-    m = case_map(k, cfg, device)
+def c3_map_pairs(k, cfg, checker, pairs=128, device=None, m=None):
+    """config[2], map k of 20: BenchmarkCase k (or the already built map m), `pairs` random pairs, seed 20260927 + k."""
+    m = m if m is not None else case_map(k, cfg, device)
     st, go = sample_pairs(m, checker(m), pairs, np.random.default_rng(SEED + k), chunk=8 * pairs)
     return m, st, go
 

@@ -215,7 +215,8 @@ def main():
                      "Case1 map, 4096 random start/goal pairs (north_star target batch), pop cap 1000")
             return label, cfg, POP_CAP, [(m, st, go)]
         if name == "c3":
-            out = [workloads.c3_map_pairs(k, cfg, checker(300), 128, device="cuda") for k in range(1, 21)]
+            maps20 = workloads.case_maps(range(1, 21), cfg, device="cuda")          # batched ingest: one rasteriser launch for the 20 files
+            out = [workloads.c3_map_pairs(k, cfg, checker(300), 128, m=maps20[k - 1]) for k in range(1, 21)]
             return "all 20 BenchmarkCases x 128 random pairs (config[2]), pop cap 300", cfg, 300, out
         if name == "c5":
             m, c5, starts, goals, _ = workloads.c5_problems(cfg, 1024, device="cuda")

@@ -311,6 +311,18 @@ int32_t avp_rasterize_edges(int32_t device, void* stream, const double* xs, cons
                             double x0, double dx, double y0, double dy, const double* edges, int64_t n_edges,
                             int32_t max_count, uint8_t* occ, int32_t* multi);
 
+/* Batched ingest: the edge tables of n_maps maps rasterised in ONE launch (a many-map workload -- BASELINE config[2]: 20 scenario
+ * files -- otherwise pays one launch and one synchronisation per map). Replaces the per-sample part of map/costmap.py:236-261 for a
+ * LIST of maps built from TPCAP files (map/costmap.py:134-156); no reference counterpart for the batching itself. Host arrays:
+ * node_off[k] (offset, in doubles, of map k's X table inside `nodes`; its Y table follows at + nx[k]), nx, ny, geo[4 k ..] = {x0, dx,
+ * y0, dy}, occ_off[k] (offset of map k's nx * ny occupancy bytes inside `occ`). Device arrays: nodes, edges (n_edges x 6, as for
+ * avp_rasterize_edges), edge_map (the map of every edge), occ (zeroed), multi (n_maps zeroed counters), grid_scratch
+ * (>= 64 * n_maps bytes). Cells identical to n_maps calls of avp_rasterize_edges (tests/test_raster.py). */
+int32_t avp_rasterize_edges_batch(int32_t device, void* stream, int32_t n_maps, const double* nodes, const int64_t* node_off,
+                                  const int32_t* nx, const int32_t* ny, const double* geo, const int64_t* occ_off,
+                                  const double* edges, const int32_t* edge_map, int64_t n_edges, int32_t max_count,
+                                  uint8_t* occ, int32_t* multi, void* grid_scratch, int64_t grid_scratch_bytes);
+
 /* Device evaluation of the shared scalar maths (test hook): out_sin/out_cos = avp_sin/avp_cos(x). */
 int32_t avp_trig_batch(avp_map* map, const double* x, int64_t n, double* out_sin, double* out_cos);
 /* Device evaluation of the restated glibc libm (test hook; include/avp_glibc_libm.h): kind 0 out = atan2(a, b) as

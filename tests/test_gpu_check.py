@@ -58,8 +58,6 @@ def test_golden_collision_vectors(k, vehicle, cfg):
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), g3[f"c{k}_dist"])
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), g3[f"c{k}_dist"])
     assert np.array_equal(dm.check_batch(poses, kind=1), g3[f"c{k}_circ"])
-    for v in (1, 2, 3, 4, 5):                             # the plain walk and the persistent-tile forms (walk / refill, L1-L2 / LDS tables)
-        assert np.array_equal(dm.check_batch(poses, kind=1, variant=v), g3[f"c{k}_circ"]), v
 
 
 @pytest.mark.parametrize("k", [1, 19])
@@ -77,7 +75,7 @@ def test_random_poses_vs_oracle(k, vehicle, cfg):
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=0), want)
     assert np.array_equal(dm.check_batch(poses, kind=0, variant=1), want)
     wc = o.check_batch(poses, kind=1)
-    assert all(np.array_equal(dm.check_batch(poses, kind=1, variant=v), wc) for v in (0, 1, 2, 3, 4, 5))
+    assert np.array_equal(dm.check_batch(poses, kind=1), wc)
 
 
 def test_edge_inputs(vehicle, cfg):
