@@ -195,6 +195,9 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 #ifndef PL_LOOK_FAULT
 #define PL_LOOK_FAULT 0               // test builds (scripts/look_soak.py): > 0 = a helper publishes the records of the nodes divisible by it with ONE
 #endif                                // key word flipped behind the ready bit's back -- the owner must turn them down (same results, fewer records used)
+#ifndef PL_LOOK_LATE
+#define PL_LOOK_LATE 1                // a long pop adopts its node's record when that lands while the pop is under way (pl_look_late)
+#endif
 #ifndef PL_LOOK_WAIT
 #define PL_LOOK_WAIT 10000            // cycles an owner waits for a record that is posted but not finished (0 / 10 k / 20 k: 21.4 / 20.7 / 20.7 ms)
 #endif
@@ -478,6 +481,7 @@ struct PlShared {
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
     int32_t use_rec, job_skip, helper_reg, n_hits, n_sec[4];
+    unsigned long long poll_ri; int32_t poll_on, late_rec, n_late, late_pad;   // PL_LOOK_LATE: the pending record of the node being expanded the long way (pl_look_late)
 };
 
 static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
@@ -1779,6 +1783,8 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
                 while ((st & 6u) != 6u && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = PL_FLAG_LD32(look.state + ri); }
                 s.n_sec[3] += 1;
             }
+            // (the next pop's own look-up: a record that is posted but not finished is polled again while that pop goes the long way)
+            if (PL_LOOK_LATE && wait) { s.poll_ri = (unsigned long long)ri; s.poll_on = ((st & 1u) && (st & 6u) != 6u) ? 1 : 0; }
         }
         st = __shfl(st, 0, 64);
         ri = (size_t)__shfl((unsigned long long)ri, 0, 64);
@@ -1807,6 +1813,7 @@ __device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& 
                                               int64_t hashCap = 0, int nchild = 0, bool lookups = false)
 {
     int ok = 0;
+    if (PL_LOOK_LATE && lane == 0) { s.poll_on = 0; s.late_rec = 0; }
     if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
         if (node == s.pre_node && s.pre_ok) ok = 1;
         else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true);
@@ -2002,6 +2009,39 @@ __device__ __noinline__ void plk_look_prefetch(AVP_LDS PlShared* sp, int64_t pid
     pl_look_prefetch(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node);
 }
 
+// Late adoption (round 5). A pop goes the long way when its node's record is not there at the moment the node is popped -- for a
+// child of the node popped just before (a dive: a quarter of all pops) its job was posted one pop ago and takes ~42 k cycles,
+// the long way ~75 k. So the long way is started AND the record is looked for again while it runs: wave 0, in the slack it has
+// ahead of the barrier behind the sub-step checks and of the one behind the Reeds-Shepp words (it arrives 4 - 6 k cycles before
+// the other waves at both), polls the pending record's ready bits, and if both halves have landed copies and validates the
+// record exactly as pl_look_load does. The pop then leaves the long way at that barrier -- nothing it has done so far has
+// touched a counter, the arena, the heap or the hash -- and is resolved from the record like any record pop. Whether and when
+// a record lands changes the time of a pop, never a result (tests/test_gpu_lookahead.py).
+__device__ __noinline__ void plk_look_late(AVP_LDS PlShared* sp, int64_t pid)
+{
+    PlShared& s = *(PlShared*)sp;
+    if (!s.poll_on || s.late_rec) return;                              // (uniform)
+    const PlLook& look = s.klook;
+    const int lane = threadIdx.x & 63;
+    const size_t ri = (size_t)s.poll_ri;
+    uint32_t st = 0;
+    if (lane == 0) st = PL_FLAG_LD32(look.state + ri);
+    st = __shfl(st, 0, 64);
+    if ((st & 6u) != 6u) return;
+    const unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
+    unsigned long long* rec = s.recb[s.rec_cur];                       // (the buffer of the popped node's record: free on the long way; the other one is the prefetch target)
+    rec[lane] = pl_ld64(rp + lane);
+    if (lane + 64 < PL_REC_WORDS) rec[lane + 64] = pl_ld64(rp + lane + 64);
+    wave_sync();
+    const PlNode& nn = s.kw.nodes[s.cur];
+    const unsigned long long fl = rec[84];
+    const bool r_in = fl & 1ull, r_err = (fl >> 8) & 0xffull, r_hit = (fl >> 1) & 1ull;
+    const bool ok = rec[80] == pl_bits(nn.x) && rec[81] == pl_bits(nn.y) && rec[82] == pl_bits(nn.th) &&
+                    rec[83] == pl_look_key3(pid, s.goal[2]) && rec[86] == pl_bits(s.goal[0]) && rec[87] == pl_bits(s.goal[1]) &&
+                    !(r_in && (r_err || !r_hit)) && s.nheap >= 1;      // (as pl_look_load / pl_look_fetch: not the record of the only open node)
+    if (lane == 0) { s.poll_on = 0; if (ok) { s.late_rec = 1; s.n_hits += 1; s.n_late += 1; } }
+}
+
 template <bool STAGE, bool PROFILE, bool LOOK = false>
 __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p, const double* __restrict__ starts,
                                                           const double* __restrict__ goals, int64_t n, int32_t maxNodes,
@@ -2024,7 +2064,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         w.rsdir = (int8_t*)(look.hrs + (size_t)((int32_t)blockIdx.x - look.main_blocks) * PL_LOOK_HRS + pl_al((size_t)PL_RS_CAP * 3 * 8));
     }
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.look_calm = 0; s.look_live = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.look_calm = 0; s.look_live = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; s.poll_on = 0; s.late_rec = 0; s.n_late = 0; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll
@@ -2167,42 +2207,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             bool can_fast = false;
             long long t_f = 0;
             int32_t pre_cand = -1;
-            if (use_rec) {
-                // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
-                const unsigned long long* rec = s.recb[s.rec_cur];
-                if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s);      // (its record is fetched beside the resolution)
-                const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
-                if (wave == 2 && lane < nchild) {
-                    // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
-                    const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
-                    s.child[lane].pre_d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
-                }
-                if (tid == 0) {
-                    const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
-                    s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
-                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
-                    if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
-                }
-                if (tid < nchild) {
-                    PlChild& c = s.child[tid];
-                    c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
-                    c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
-                    if (nf) { c.found = s.nf_found[tid]; c.found_state = s.nf_state[tid]; }
-                    else {
-                        c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
-                        c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
-                    }
-                    c.id = avp_pos_to_index(m, c.x, c.y);
-                    c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
-                    c.rs_err = (int8_t)(rec[64 + tid] >> 32);
-                    c.L = pl_unbits(rec[48 + tid]);
-                }
-                PH_MARK(0);
-                __syncthreads();
-                can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
-                t_f = PH_NOW();
-                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);
-            } else {
+            bool late = false;                 // (PL_LOOK_LATE) the long way was left for the node's record, which landed meanwhile
+            if (!use_rec) {
             if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = hC ? 2 : 0; }
             // a helper runs its half only: queries = the children (hC), the shot (hS), both (an owner)
             const int qoff = hC ? 0 : 1, nq_all = hC ? nchild : (hS ? 1 : nchild + 1);
@@ -2228,7 +2234,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             } else if (one_pass && tid == PL_THREADS - 2 && !hC) s.frame[0] = rs_frame(cn.x, cn.y, cn.th, s.goal[0], s.goal[1], s.goal[2], p.maxc);
             else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nq_all) pl_rs_build_schedule(s, nq_all);
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
-            if constexpr (LOOK) if (!helper && look.on && wave == 0) plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, pl_look_prefetch_node(w, s));   // (wave 0 idles until the sub-step checks are done)
+            if constexpr (LOOK) if (!helper && look.on && wave == 0) {
+                plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, pl_look_prefetch_node(w, s));   // (wave 0 idles until the sub-step checks are done)
+                if (PL_LOOK_LATE) plk_look_late((AVP_LDS PlShared*)&s, pid);                             // ... and looks for this node's pending record again
+            }
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
             const int nsubs = nchild * p.n_sub;
@@ -2252,6 +2261,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             PH_MARK(0);
             __syncthreads();
+#if PL_LOOK_LATE
+            if constexpr (LOOK) if (!helper && s.late_rec) { late = true; goto pl_late_record; }      // the record has landed: leave the long way here
+#endif
             if (!hS) for (int t = tid; t < nsubs; t += PL_THREADS)
                 if (s.chk_hit[t]) { const int ci = t / p.n_sub; atomicMin(&s.child[ci].first_coll, t - ci * p.n_sub); }
             const long long t_e = PH_NOW();
@@ -2270,8 +2282,14 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (g < qoff) { x = cn.x; y = cn.y; th = cn.th; }
                         else { x = s.child[g - qoff].x; y = s.child[g - qoff].y; th = s.child[g - qoff].th; }
                     }, one_pass);
+#if PL_LOOK_LATE
+                    if constexpr (LOOK) if (!helper && look.on && wave == 0 && base == 0) plk_look_late((AVP_LDS PlShared*)&s, pid);      // (wave 0 is done with its words ~5 k cycles before the others)
+#endif
                     if (base == 0) PH_MARK(1);
                     __syncthreads();
+#if PL_LOOK_LATE
+                    if constexpr (LOOK) if (!helper && base == 0 && s.late_rec) { late = true; goto pl_late_record; }
+#endif
                     if (PROFILE && tid == 0) s.phase[PH_RS_WORDS] += clock64() - t_e;
                     // set_path and arg-min, a whole query per wave (20 lanes run its type groups, then the wave folds):
                     // no cross-wave hand-over. Wave 0 owns the shot (query 0 of the first pass) and goes straight on to
@@ -2444,25 +2462,65 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             }
             if (s.status != 0 || s.done) break;
             }
+#if PL_LOOK_LATE
+            pl_late_record:
+#endif
+            if (use_rec || late) {
+                // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
+                const unsigned long long* rec = s.recb[s.rec_cur];
+                if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s);      // (its record is fetched beside the resolution)
+                const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
+                if (wave == 2 && lane < nchild) {
+                    // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
+                    const int64_t id = avp_pos_to_index(m, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]));
+                    s.child[lane].pre_d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
+                }
+                if (tid == 0) {
+                    const int32_t fc = (int32_t)(uint32_t)(rec[85] & 0xffffffffull);
+                    s.in_radius = in_radius ? 1 : 0; s.collision = in_radius ? 1 : 0; s.rs_first_coll = in_radius ? fc : 0x7fffffff;
+                    s.rs_npts = (int32_t)(uint32_t)(rec[85] >> 32); s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = 2; s.fetch_go = 0; s.wr_go = 0; s.wr_done = 0;
+                    if (in_radius) { s.n_rs += 1; s.n_checks += fc + 1; }
+                }
+                if (tid < nchild) {
+                    PlChild& c = s.child[tid];
+                    c.x = pl_unbits(rec[tid]); c.y = pl_unbits(rec[16 + tid]); c.th = pl_unbits(rec[32 + tid]);
+                    c.oob = (c.x > m.b1 || c.x < m.b0 || c.y > m.b3 || c.y < m.b2) ? 1 : 0;
+                    if (nf) { c.found = s.nf_found[tid]; c.found_state = s.nf_state[tid]; }
+                    else {
+                        c.found = pl_hash_find(w, dims.hashCap, c.x, c.y, c.th);
+                        c.found_state = c.found >= 0 ? w.nodes[c.found].state : 0;
+                    }
+                    c.id = avp_pos_to_index(m, c.x, c.y);
+                    c.first_coll = (int32_t)(uint32_t)(rec[64 + tid] & 0xffffffffull);
+                    c.rs_err = (int8_t)(rec[64 + tid] >> 32);
+                    c.L = pl_unbits(rec[48 + tid]);
+                }
+                PH_MARK(0);
+                __syncthreads();
+                can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
+                t_f = PH_NOW();
+                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);
+            }
 
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
             // query misses the closed frontier the whole workgroup extends the sweep, then thread 0 resumes.
-            const bool tried = !use_rec && in_radius && can_fast;   // the speculative attempt above
+            const bool rec = use_rec || late;                       // resolved from a record (popped with it, or adopted on the way)
+            const bool tried = !rec && in_radius && can_fast;       // the speculative attempt above
             if (tid == 0) { s.next_child = 0; s.have_d = 0; s.need_sweep = 0; if (!tried) s.fast = can_fast ? 1 : 0; }
             if (!can_fast && tid < nchild) s.child[tid].pre_d = pl_id_in_range(m, s.child[tid].id) ? w.dist[s.child[tid].id] : PL_UNSEEN;
             __syncthreads();
             if (!tried && can_fast) {
                 if (wave == 0) {
-                    pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops, LOOK && use_rec);
+                    pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops, LOOK && rec);
                     if constexpr (LOOK) if (look.on) {
                         wave_sync();
-                        if (use_rec) {       // (resolution left early / nothing popped ahead: release the writer and the fetcher)
+                        if (rec) {       // (resolution left early / nothing popped ahead: release the writer and the fetcher)
                             if (lane == 0 && *(volatile int32_t*)&s.wr_go == 0) *(volatile int32_t*)&s.wr_go = 2;
                             if (lane == 0 && *(volatile int32_t*)&s.fetch_go == 0) *(volatile int32_t*)&s.fetch_go = 2;
                         }
                         else if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0);
                     }
-                } else if (LOOK && use_rec && wave == 1) {
+                } else if (LOOK && rec && wave == 1) {
                     // record pop: the other waves are idle, so this one fetches the next node's record as soon as wave 0
                     // knows that node (before it sifts the heap), and does the bounded wait for a pending record
                     if constexpr (LOOK) {
@@ -2472,12 +2530,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         if (*(volatile int32_t*)&s.fetch_go == 1) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.fetch_nheap, nchild, 1);
                     }
-                } else if (LOOK && use_rec && wave == 2) {
+                } else if (LOOK && rec && wave == 2) {
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
-                } else if (LOOK && use_rec && wave == nwave - 1) {
+                } else if (LOOK && rec && wave == nwave - 1) {
                     if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
                 }
-                if (LOOK && use_rec) PH_MARK(3);
+                if (LOOK && rec) PH_MARK(3);
                 __syncthreads();
             }
             if (s.fast) {
@@ -2575,7 +2633,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
         if (tid == 0) {
             plk_write_result<PROFILE>((AVP_LDS PlShared*)&s, pid, n_pops, (int32_t)blockIdx.x, t_fin);
-            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } }   // ([8]: records used, a diagnostic)
+            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } if (s.n_late) { atomicAdd(look.ctrl + 76, (unsigned long long)s.n_late); s.n_late = 0; } }   // ([8]: records used, [76]: of which adopted late -- diagnostics)
         }
         __syncthreads();
     }

@@ -46,7 +46,7 @@ def main():
             c = bp._look[:1024].cpu().numpy().view(np.uint64)
             e.update(jobs_posted=int(c[0]), children_halves_made=int(c[24]), shot_halves_made=int(c[88]), records_used=int(c[8]),
                      helper_workgroups=int(c[48]), record_pop_frac=float(c[8]) / max(int(rec["n_pops"].sum()), 1),
-                     child_lookups={"not_posted": int(c[72]), "pending": int(c[73]), "ready": int(c[74]), "waited": int(c[75])},
+                     child_lookups={"not_posted": int(c[72]), "pending": int(c[73]), "ready": int(c[74]), "waited": int(c[75])}, records_adopted_late=int(c[76]),
                      lookahead_workspace_bytes=int(bp._look.numel()))
         out[name] = e
     a, b = keep["without_lookahead"], keep["with_lookahead"]
