@@ -489,6 +489,8 @@ static inline __host__ __device__ size_t pl_lds_tables_offset() { return (sizeof
 static inline size_t pl_lds_tables_bytes(const DevMap& m) { return ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8; }
 
 AVP_D int32_t pl_bucket(uint32_t d) { return (int32_t)(d / 10u); }
+// AVP_PLAN_BAD_POSE: coordinates / headings the loops of the set-up (pi_2_pi's subtract-2-pi loop, the lattice walk) would not come back from
+AVP_D bool pl_pose_ok(double x, double y, double th) { return fabs(x) <= 1e9 && fabs(y) <= 1e9 && fabs(th) <= 1e6; }      // (NaN: false)
 
 AVP_D uint64_t pl_mix(uint64_t z) { z ^= z >> 33; z *= 0xff51afd7ed558ccdULL; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL; z ^= z >> 33; return z; }
 AVP_D uint64_t pl_pose_hash(double x, double y, double th)
@@ -924,6 +926,9 @@ AVP_D void pl_sweep_init(const DevMap& m, const PlanWs& w, S& s, const PlanDims&
         const int orow0 = (int)floor((gy - m.b2) / m.dy) - 1;
         int regular = 1;
         int colMin = col0, colMax = col0, rowMin = row0, rowMax = row0;
+        // (a goal outside the map is refused BEFORE the walks below: from a goal far outside they take |g - b| / dx trips)
+        if (!(gx >= m.b0 && gx <= m.b1 && gy >= m.b2 && gy <= m.b3)) regular = 0;
+        else {
         double v = gx;
         for (int a = 1;; a++) { v = v + m.dx; if (!(v <= m.b1)) break; const int c = (int)floor((v - m.b0) / m.dx); if (c != col0 + a) regular = 0; colMax = col0 + a; }
         v = gx;
@@ -942,7 +947,7 @@ AVP_D void pl_sweep_init(const DevMap& m, const PlanWs& w, S& s, const PlanDims&
             if (r != row0 + b || o != orow0 - b) regular = 0;
             rowMax = row0 + b;
         }
-        if (!(gx >= m.b0 && gx <= m.b1 && gy >= m.b2 && gy <= m.b3)) regular = 0;
+        }
         if (colMin < 0 || colMax > m.S || rowMin < 0 || rowMax > m.Sy + 1) regular = 0;
         s.col0 = col0; s.row0 = row0; s.orow0 = orow0; s.colMin = colMin; s.colMax = colMax; s.rowMin = rowMin; s.rowMax = rowMax;
         s.alias = (colMax == m.S) ? 1 : 0;
@@ -1423,12 +1428,14 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
         wave_sync();
         if (!wide) {
             int tot = 0;
+            bool odd = false;                           // a range this walk does not cover (only a non-finite pose can have one on a map whose footprints fit): the pose goes to the lane-per-pose walk
 #pragma unroll
             for (int i = 0; i < PL_WPOSE; i++) {
                 if (i >= lo && i < hi) {
                     const int ixlo = wc.rng[i][0], ixhi = wc.rng[i][1], iylo = wc.rng[i][2], iyhi = wc.rng[i][3];
                     if (iylo <= iyhi && lane <= ixhi - ixlo) {
                         const int ix = ixlo + lane, w0 = iylo >> 6, w1 = iyhi >> 6;
+                        if (w1 - w0 > 1 || ixhi - ixlo >= 64) odd = true;
                         uint64_t x0 = mt.bits[(size_t)ix * wpc + w0] & (~0ull << (iylo & 63));
                         if (w1 == w0) x0 &= ~0ull >> (63 - (iyhi & 63));
                         const uint64_t x1 = w1 > w0 ? (mt.bits[(size_t)ix * wpc + w1] & (~0ull >> (63 - (iyhi & 63)))) : 0ull;
@@ -1437,7 +1444,7 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
                 }
             }
             int pos = tot ? atomicAdd(&wc.qn, tot) : 0;
-            if (pos + tot > QCAP) { if (tot) wc.over = 1; }
+            if (odd || pos + tot > QCAP) { if (tot || odd) wc.over = 1; }
             else if (tot) {
 #pragma nounroll
                 for (int i = lo; i < hi; i++) {
@@ -1945,16 +1952,19 @@ __device__ __noinline__ void plk_init(AVP_LDS PlShared* sp, int64_t pid)
     const double sx = s.k_starts[3 * pid], sy = s.k_starts[3 * pid + 1], sth = s.k_starts[3 * pid + 2];
     const double gx = s.k_goals[3 * pid], gy = s.k_goals[3 * pid + 1], gth = s.k_goals[3 * pid + 2];
     const long long t_init0 = PH_NOW();
+    const bool pose_ok = pl_pose_ok(sx, sy, sth) && pl_pose_ok(gx, gy, gth);      // (the same in every thread)
     for (int64_t i = tid; i < s.kdims.hashCap; i += PL_THREADS) w.hash[i] = 0;
     if (tid == 0) {
         s.status = 0; s.done = 0;
         s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1; s.nf_node = -1;
         s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0;
         for (int k = 0; k < PH_COUNT; k++) s.phase[k] = 0;
-        s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
+        s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = pose_ok ? avp_pi_2_pi(gth) : 0.0;
         s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
+        if (!pose_ok) { s.status = 7; s.E = 0; s.h_cells = 0; s.h_misses = 0; s.qover = 0; }      // AVP_PLAN_BAD_POSE
     }
-    pl_sweep_init(m, w, s, s.kdims, gx, gy);
+    if (pose_ok) pl_sweep_init(m, w, s, s.kdims, gx, gy);
+    else __syncthreads();
     if (s.status == 0) {
         // hybrid_a_star.__init__: compute_path(x0, y0) (:89-91)
         const int64_t sid = avp_pos_to_index(m, sx, sy);

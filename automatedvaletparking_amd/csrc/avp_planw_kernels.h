@@ -404,10 +404,11 @@ __device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
     const double gx = c.goals[3 * pid], gy = c.goals[3 * pid + 1], gth = c.goals[3 * pid + 2];
     for (int64_t i = gtid; i < c.dims.hashCap; i += G::N) w.hash[i] = 0;
     if (gtid == 0) {
-        s.status = (c.nchild > PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;
+        const bool pose_ok = pl_pose_ok(sx, sy, sth) && pl_pose_ok(gx, gy, gth);
+        s.status = !pose_ok ? 7 /* AVP_PLAN_BAD_POSE */ : (c.nchild > PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;
         s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
         s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0; s.n_pops = 0;
-        s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = avp_pi_2_pi(gth);
+        s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = pose_ok ? avp_pi_2_pi(gth) : 0.0;
         s.rs_status = 0; s.rs_npts = 0; s.in_radius = 0; s.collision = 0; s.rs.n = 0; s.rs.L = 0;
         s.E = 0; s.h_cells = 0; s.h_misses = 0;
     }

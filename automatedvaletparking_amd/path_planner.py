@@ -22,7 +22,7 @@ from . import collision_check
 from .costmap import Map, Vehicle
 from .rs_curve import PATH, path_from_arrays
 
-STATUS_NAMES = {0: "OK", 1: "NO_PATH", 2: "H_UNREACHABLE", 3: "RS_ERROR", 4: "ITER_LIMIT", 5: "CAPACITY", 6: "LATTICE",
+STATUS_NAMES = {0: "OK", 1: "NO_PATH", 2: "H_UNREACHABLE", 3: "RS_ERROR", 4: "ITER_LIMIT", 5: "CAPACITY", 6: "LATTICE", 7: "BAD_POSE",
                 100: "DEFERRED", -1: "UNFINISHED"}       # (DEFERRED: only from the first stage of a staged call run on its own, BatchPlanner.plan_dev(first_stage_only=True))
 STAGED = 16                           # BatchPlanner mode: avp_plan_batch_staged
 
