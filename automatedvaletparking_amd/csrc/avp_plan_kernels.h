@@ -490,7 +490,7 @@ static inline size_t pl_lds_tables_bytes(const DevMap& m) { return ((size_t)m.nx
 
 AVP_D int32_t pl_bucket(uint32_t d) { return (int32_t)(d / 10u); }
 // AVP_PLAN_BAD_POSE: coordinates / headings the loops of the set-up (pi_2_pi's subtract-2-pi loop, the lattice walk) would not come back from
-AVP_D bool pl_pose_ok(double x, double y, double th) { return fabs(x) <= 1e9 && fabs(y) <= 1e9 && fabs(th) <= 1e6; }      // (NaN: false)
+AVP_D bool pl_pose_ok(double x, double y, double th) { return fabs(x) <= 1.7e308 && fabs(y) <= 1.7e308 && fabs(th) <= 1e6; }      // (finite coordinates -- the BenchmarkCases' run to 9e9 m --, a heading the wrap loop finishes; NaN: false)
 
 AVP_D uint64_t pl_mix(uint64_t z) { z ^= z >> 33; z *= 0xff51afd7ed558ccdULL; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL; z ^= z >> 33; return z; }
 AVP_D uint64_t pl_pose_hash(double x, double y, double th)

@@ -489,8 +489,8 @@ __global__ __launch_bounds__(64) void rs_optimal_kernel(const double* __restrict
     const double ax = q0[3 * i], ay = q0[3 * i + 1], at = q0[3 * i + 2];
     const double bx = q1[3 * i], by = q1[3 * i + 1], bt = q1[3 * i + 2];
     // status 7: a pose the reference itself never returns on -- pi_2_pi's subtract-2-pi loop (rs_curve.py:649-656) on an infinite heading,
-    // its float % on infinite coordinates; headings up to 1e6 rad are wrapped by that very loop, bit for bit (NaN: refused too)
-    if (!(fabs(ax) <= 1e9 && fabs(ay) <= 1e9 && fabs(at) <= 1e6 && fabs(bx) <= 1e9 && fabs(by) <= 1e9 && fabs(bt) <= 1e6)) {
+    // headings up to 1e6 rad are wrapped by that very loop, bit for bit; coordinates must be finite (NaN: refused too)
+    if (!(fabs(ax) <= 1.7e308 && fabs(ay) <= 1.7e308 && fabs(at) <= 1e6 && fabs(bx) <= 1.7e308 && fabs(by) <= 1.7e308 && fabs(bt) <= 1e6)) {
         for (int k = 0; k < 5; k++) { types[i * 5 + k] = (int8_t)-1; lens[i * 5 + k] = 0.0; }
         L[i] = 0.0; npts[i] = 0; status[i] = 7;
         return;

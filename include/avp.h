@@ -44,7 +44,7 @@ enum {
     AVP_PLAN_ITER_LIMIT = 4,    /* params.max_pops reached (the reference has no cap)           */
     AVP_PLAN_CAPACITY = 5,      /* node arena / path buffer / sweep queue exhausted             */
     AVP_PLAN_LATTICE = 6,       /* goal outside the map or goal-anchored lattice not regular     */
-    AVP_PLAN_BAD_POSE = 7       /* a start / goal coordinate that is not finite or beyond 1e9 m, a heading that is not finite or
+    AVP_PLAN_BAD_POSE = 7       /* a start / goal coordinate that is not finite, a heading that is not finite or
                                    beyond 1e6 rad: the reference never returns on an infinite heading (rs_curve.pi_2_pi's
                                    subtract-2-pi loop, hybrid_a_star.py:72-124) and neither would the device -- refused before
                                    the first loop; headings up to 1e6 rad are wrapped by that very loop, bit for bit */
@@ -125,7 +125,7 @@ int32_t avp_corridor_batch_v(avp_map* map, double expand_dis, const double* x, c
  * Replaces: rs_curve.calc_optimal_path (path_plan/rs_curve.py:99-134), one call per (start, goal)
  * pair in the reference. All pointers device. q0, q1: n x 3 (x, y, yaw) row-major; maxc = 1 /
  * min turning radius. Outputs per query i: status[i] (0 ok, 1 no candidate word, 2 the reference's
- * "L >= 0.01" assertion fails, 3 more than maxpts samples (npts[i] = needed), 7 a coordinate that is not finite or beyond 1e9 m / a
+ * "L >= 0.01" assertion fails, 3 more than maxpts samples (npts[i] = needed), 7 a coordinate that is not finite / a
  * heading that is not finite or beyond 1e6 rad: the reference's pi_2_pi loop never ends on an infinite heading), L[i] total length [m], types[i*5+k] in {0 S, 1 L, 2 R, -1 unused}, lens[i*5+k] signed
  * segment lengths [m], npts[i], xyyaw[(i*maxpts+j)*3 + {0,1,2}] world-frame samples every 0.5 m
  * (yaw wrapped by pi_2_pi), dir[i*maxpts+j] in {+1,-1}. maxpts = 0 (xyyaw/dir NULL) skips sampling.
