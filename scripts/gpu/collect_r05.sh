@@ -7,8 +7,8 @@ cp $O/bench_force_dist.json $P/r05_bench_force_dist_n1.json
 cp $O/pmc_summary.json $P/r05_pmc_summary.json
 cp $O/pmc_saturating_batch.json $P/r05_pmc_saturating_batch.json
 cp $O/bench_headline_under_rocprof.json $P/r05_bench_headline_under_rocprof.json
-cp "$(find $O/stats_headline -name '*kernel_stats.csv' | head -1)" $P/r05_bench_headline_kernel_stats.csv
-cp "$(find $O/stats_check -name '*kernel_stats.csv' | head -1)" $P/r05_secondary_kernel_stats.csv
+cp "$(ls -t $(find $O/stats_headline -name '*kernel_stats.csv') | head -1)" $P/r05_bench_headline_kernel_stats.csv
+cp "$(ls -t $(find $O/stats_check -name '*kernel_stats.csv') | head -1)" $P/r05_secondary_kernel_stats.csv
 cp $O/bench_check.jsonl $P/r05_secondary_kernels.jsonl
 cp $O/phase_profile.json $P/r05_plan_kernel_phase_cycles.json
 python3 - <<'PY'
