@@ -16,7 +16,8 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVP_HIP_LIB") or os.path.join(_PKG, "libavp_hip.so")    # AVP_HIP_LIB: kernel-variant experiments (scripts/variant_bench.py)
 HOSTMATH_PATH = os.path.join(_PKG, "libavp_hostmath.so")
-AVP_MAX_STEER = 16
+AVP_MAX_STEER = 32
+AVP_MAX_SUBS = 512
 
 EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
@@ -34,8 +35,8 @@ class AvpParams(C.Structure):
         ("circ_rd", C.c_double), ("circ_cf", C.c_double), ("circ_cr", C.c_double),
         ("n_steer", C.c_int32), ("n_sub", C.c_int32),
         ("steer", C.c_double * AVP_MAX_STEER), ("dth_dt", C.c_double * AVP_MAX_STEER),
-        ("dth_ddt", (C.c_double * 4) * AVP_MAX_STEER),
-        ("travel_dt", C.c_double), ("travel_ddt", C.c_double * 4),
+        ("dth_ddt1", C.c_double * AVP_MAX_STEER),
+        ("travel_dt", C.c_double), ("travel_ddt1", C.c_double),
         ("flag_radius", C.c_double),
         ("cost_gear", C.c_double), ("cost_heading", C.c_double), ("cost_scale", C.c_double),
         ("maxc", C.c_double),
@@ -61,21 +62,21 @@ def make_params(config: dict, vehicle, max_pops: int = 0) -> AvpParams:
     p.circ_cr = 1 / 4 * (v.lw + v.lf - 3 * v.lr)                                         # :96
     n = int(config['steering_angle_num'])
     if not (1 <= n <= AVP_MAX_STEER):
-        raise ValueError("steering_angle_num must be in 1..16")
+        raise ValueError("steering_angle_num must be in 1..%d (2 x 32 children: one lane of a wave each)" % AVP_MAX_STEER)
     steer = np.linspace(-v.max_steering_angle, v.max_steering_angle, n)                  # hybrid_a_star.py:81-83
     dt, ddt = config['dt'], config['trajectory_dt']
     n_sub = math.ceil(dt / ddt)                                                         # :185
-    if not (1 <= n_sub <= 4):
-        raise ValueError("ceil(dt/trajectory_dt) must be in 1..4")
+    if not (1 <= n_sub and 2 * n * n_sub <= AVP_MAX_SUBS):
+        raise ValueError("2 * steering_angle_num * ceil(dt / trajectory_dt) must be in 1..%d (trajectory_dt too small for this steering_angle_num)" % AVP_MAX_SUBS)
     p.n_steer, p.n_sub = n, n_sub
     for i in range(n):
         p.steer[i] = float(steer[i])
         p.dth_dt[i] = float((v.max_v * np.tan(steer[i])) / v.lw * dt)                    # :146-148
-        for j in range(n_sub):
-            p.dth_ddt[i][j] = float((v.max_v * np.tan(steer[i])) / v.lw * ddt * (j + 1))  # :189-191
+        # :189-191 `(max_v * tan) / lw * ddt * (i + 1)` is evaluated left to right: everything up to the last factor here, the
+        # multiplication by the exact small integer (i + 1) on the device (IEEE, -ffp-contract=off): the same double
+        p.dth_ddt1[i] = float((v.max_v * np.tan(steer[i])) / v.lw * ddt)
     p.travel_dt = v.max_v * dt                                                          # :145
-    for j in range(n_sub):
-        p.travel_ddt[j] = v.max_v * ddt * (j + 1)                                       # :188
+    p.travel_ddt1 = v.max_v * ddt                                                       # :188 `speed * ddt * (i + 1)`, likewise
     p.flag_radius = float(config['flag_radius'])
     p.cost_gear, p.cost_heading, p.cost_scale = config['cost_gear'], config['cost_heading_change'], config['cost_scale']
     p.maxc = 1 / float(v.min_radius_turn)                                               # :285
@@ -173,17 +174,20 @@ def rasterize_edges_batch(grids, edge_tables, device=None, stream=None):
     edges = np.concatenate(tabs) if tabs else np.zeros((0, 6))
     emap = np.concatenate([np.full(len(t), k, np.int32) for k, t in enumerate(tabs)]) if tabs else np.zeros(0, np.int32)
     st = stream if stream is not None else torch.cuda.current_stream(dev)
-    d_nodes, d_edges, d_emap = torch.as_tensor(nodes, device=dev), torch.as_tensor(edges, device=dev), torch.as_tensor(emap, device=dev)
-    occ = torch.zeros(int(cells.sum()), dtype=torch.uint8, device=dev)
-    multi = torch.zeros(n, dtype=torch.int32, device=dev)
-    scratch = torch.empty(64 * n, dtype=torch.uint8, device=dev)
-    chk(lib().avp_rasterize_edges_batch(C.c_int32(dev.index if dev.index is not None else torch.cuda.current_device()), C.c_void_p(st.cuda_stream),
-                                        C.c_int32(n), C.c_void_p(d_nodes.data_ptr()), _vp(node_off), _vp(nxs), _vp(nys), _vp(np.ascontiguousarray(geo)), _vp(occ_off),
-                                        C.c_void_p(d_edges.data_ptr()), C.c_void_p(d_emap.data_ptr()), C.c_int64(len(edges)),
-                                        C.c_int32(int(edges[:, 5].max()) if len(edges) else 0), C.c_void_p(occ.data_ptr()), C.c_void_p(multi.data_ptr()),
-                                        C.c_void_p(scratch.data_ptr()), C.c_int64(scratch.numel())), "avp_rasterize_edges_batch")
-    occ_h = occ.cpu().numpy()                              # (the one synchronisation of the batch)
-    mult = multi.cpu().numpy()
+    # every allocation, upload, zero-fill and read-back runs on the stream the kernel is launched on (torch's current stream is
+    # not necessarily `stream`: a zero-fill or a read-back queued elsewhere would race the launch)
+    with torch.cuda.stream(st):
+        d_nodes, d_edges, d_emap = torch.as_tensor(nodes, device=dev), torch.as_tensor(edges, device=dev), torch.as_tensor(emap, device=dev)
+        occ = torch.zeros(int(cells.sum()), dtype=torch.uint8, device=dev)
+        multi = torch.zeros(n, dtype=torch.int32, device=dev)
+        scratch = torch.empty(64 * n, dtype=torch.uint8, device=dev)
+        chk(lib().avp_rasterize_edges_batch(C.c_int32(dev.index if dev.index is not None else torch.cuda.current_device()), C.c_void_p(st.cuda_stream),
+                                            C.c_int32(n), C.c_void_p(d_nodes.data_ptr()), _vp(node_off), _vp(nxs), _vp(nys), _vp(np.ascontiguousarray(geo)), _vp(occ_off),
+                                            C.c_void_p(d_edges.data_ptr()), C.c_void_p(d_emap.data_ptr()), C.c_int64(len(edges)),
+                                            C.c_int32(int(edges[:, 5].max()) if len(edges) else 0), C.c_void_p(occ.data_ptr()), C.c_void_p(multi.data_ptr()),
+                                            C.c_void_p(scratch.data_ptr()), C.c_int64(scratch.numel())), "avp_rasterize_edges_batch")
+        occ_h = occ.cpu().numpy()                          # (the one synchronisation of the batch)
+        mult = multi.cpu().numpy()
     return [occ_h[occ_off[k]:occ_off[k] + cells[k]].reshape(int(nxs[k]), int(nys[k])) for k in range(n)], [int(v) for v in mult]
 
 

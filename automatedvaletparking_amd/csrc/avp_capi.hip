@@ -337,6 +337,7 @@ AVP_EXPORT int32_t avp_rasterize_edges_batch(int32_t device, void* stream, int32
     std::vector<RasterGridB> h((size_t)n_maps);
     for (int32_t k = 0; k < n_maps; k++) {
         if (nx[k] < 2 || ny[k] < 2 || !(geo[4 * k + 1] > 0) || !(geo[4 * k + 3] > 0)) return set_err(AVP_ERR_ARG, "avp_rasterize_edges_batch: bad map geometry");
+        if (node_off[k] < 0 || occ_off[k] < 0) return set_err(AVP_ERR_ARG, "avp_rasterize_edges_batch: negative buffer offset");
         RasterGrid& g = h[k].g;
         g.X = nodes + node_off[k]; g.Y = g.X + nx[k]; g.nx = nx[k]; g.ny = ny[k];
         g.b0 = geo[4 * k]; g.dx = geo[4 * k + 1]; g.b2 = geo[4 * k + 2]; g.dy = geo[4 * k + 3];
@@ -346,7 +347,7 @@ AVP_EXPORT int32_t avp_rasterize_edges_batch(int32_t device, void* stream, int32
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));        // (the pageable host vector goes out of scope)
     const unsigned gy = (unsigned)(n_edges < 65535 ? n_edges : 65535), gz = (unsigned)((n_edges + 65534) / 65535);
     hipLaunchKernelGGL(rasterize_batch_kernel, dim3((unsigned)((max_count + 63) / 64), gy, gz), dim3(64), 0, (hipStream_t)stream,
-                       (const RasterGridB*)grid_scratch, edges, edge_map, n_edges, occ, multi);
+                       (const RasterGridB*)grid_scratch, n_maps, edges, edge_map, n_edges, occ, multi);
     HIPCHK(hipGetLastError());
     return AVP_OK;
 }

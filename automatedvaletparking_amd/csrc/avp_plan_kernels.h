@@ -31,7 +31,8 @@
 #endif
 #define PL_QCAP 32768                 // entries per rotating bucket queue
 #define PL_NQ 4                       // rotating bucket queues
-#define PL_MAXCHILD 32
+#define PL_MAXCHILD (2 * AVP_MAX_STEER)   // children of one expansion: a lane of the resolving wave each
+#define PL_MAXSUBS AVP_MAX_SUBS          // sub-step poses of one expansion (children x sub-steps)
 #define PL_RSQ 11                     // RS queries evaluated per pass (46 words each): the shot + 10 children (<= 16)
 #define PL_CHK_MAX 1280               // poses per collision pass (shot samples + sub-steps)
 #define PL_RS_CAP 1024                // samples of one RS shot
@@ -204,31 +205,59 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 struct PlLook {
     unsigned long long* ctrl;         // ring r (0: children halves, 1: shot halves): [64 r] tail, [64 r + 16] head; [32] problems finished,
                                       // [48] helpers alive (one 128-B line each); [8], [24], [88], [72 ..] diagnostics
-    unsigned long long* jobs;         // [2][PL_JCAP][PL_JOB_WORDS]: node | pid << 32 | slot << 52, pose, goal, sequence number
-    uint32_t* state;                  // [n][maxNodes][1 + PL_LOOK_KIDS]: bit 0 posted, bit 1 children half ready, bit 2 shot half ready
-    unsigned long long* recs;         // [n][maxNodes][1 + PL_LOOK_KIDS][PL_REC_WORDS]
+    unsigned long long* jobs;         // [2][PL_JCAP][PL_JOB_WORDS]: tag (node | pid << 24 | slot << 40), pose, goal, sequence number
+    unsigned long long* state;        // [entries]: tag << 8 | generation << 3 | bit 0 posted, bit 1 children half ready, bit 2 shot half ready
+    unsigned long long* recs;         // [entries][PL_REC_WORDS]
     char* hrs;                        // [helper-only workgroups][PL_LOOK_HRS]
     int32_t on, main_blocks;          // workgroups [0, main_blocks) own a workspace slot and take problems
+    uint32_t emask, pad;              // entries - 1 (a power of two)
 };
 // Every expansion is posted as TWO jobs that two helpers serve at the same time -- the children half (children poses,
 // sub-step checks, the children's Reeds-Shepp lengths) and the shot half (the node's own Reeds-Shepp path, sampled and
 // checked) -- so a record is there after ~35 k cycles instead of ~55 k; a helper serves one kind only (even / odd
-// workgroups), which keeps its RS word schedule fixed. Record slot 0 of a node is the node's own expansion (posted by the
-// owner when the node reaches the top of its open list). Slots 1 .. PL_LOOK_KIDS belong to CHILDREN the node does not
-// have yet: a quarter of all pops expand a child of the node popped just before (searches dive), 99.9 % of those
-// children keep the parent's gear and 77 % steer within one step of it (CPU oracle, bench workload). When a pop takes
-// the long way the owner posts those three children right at its start, keyed (node, steering step); the fresh child is
-// looked up through its parent when it is popped ahead ~65 k cycles later.
-static inline __host__ __device__ size_t pl_look_state_bytes(int64_t n, int32_t maxNodes) { return pl_al((size_t)n * maxNodes * (1 + PL_LOOK_KIDS) * 4); }
-static inline __host__ __device__ size_t pl_look_bytes(int64_t n, int32_t maxNodes, int32_t helper_blocks)
+// workgroups), which keeps its RS word schedule fixed.
+//
+// THE RECORD STORE (round 6) is a direct-mapped table of fixed size -- PL_LOOK_ENTRIES records whatever the batch size and
+// the node arena (until round 5: one slot per (problem, arena node, 4): n x max_nodes x 2 832 B, 26 GB at pop cap 3 000, which
+// silently switched the lookahead off). A record is named by its TAG = (problem, node, slot): slot 0 is the node's own
+// expansion (posted when the node reaches the top of its open list), slot 1 + i belongs to CHILD i the node does not have yet
+// (searches dive: a quarter of all pops expand a child of the node popped just before, too soon after its creation for a job
+// posted then -- so likely children are posted through their parent: the three that keep the gear and steer within one step
+// at the start of a pop that takes the long way, and the ONE child that will be the open list's next root as soon as the
+// parent's own record is in the owner's hands, pl_look_predict). The entry of a tag is hash(tag); its state word carries the
+// tag, so two tags that share an entry never share a record:
+//   * an owner CLAIMS the entry for a tag with a compare-and-swap before it posts the job (pl_look_claim): an empty entry or
+//     one whose record is COMPLETE (both halves there: nobody will write it any more) may be taken over, an entry whose jobs
+//     are still in flight may not (that post is skipped: the pop goes the long way, as it would without the lookahead);
+//   * helpers write the payload, drain, then OR their ready bit into the state word -- the entry is theirs until both bits are set;
+//   * a reader takes the state word, copies the record, and takes the state word AGAIN (seqlock): any take-over starts
+//     with the claim's change of that word (tag, generation count), which precedes the new helper's first payload store by a
+//     trip through the job ring, so a copy framed by two equal state words is a copy of ONE record. The key words inside the
+//     record (exact pose bits, problem, goal) are still checked: they are what ties the record to the node's pose.
+// Whether a record exists, is evicted or is refused changes the time of a pop, never a result (tests/test_gpu_lookahead.py).
+#ifndef PL_LOOK_ENT_LOG2
+#define PL_LOOK_ENT_LOG2 18            // 262 144 records x 704 B = 184 MB (config[1] keeps ~3 000 alive; a launch zeroes the 2 MB of state words)
+#endif
+#define PL_LOOK_ENTRIES (1u << PL_LOOK_ENT_LOG2)
+static inline __host__ __device__ size_t pl_look_state_bytes() { return pl_al((size_t)PL_LOOK_ENTRIES * 8); }
+static inline __host__ __device__ size_t pl_look_bytes(int32_t helper_blocks)
 {
-    return 1024 + 2 * (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_look_state_bytes(n, maxNodes) +
-           (size_t)n * maxNodes * (1 + PL_LOOK_KIDS) * PL_REC_WORDS * 8 + (size_t)helper_blocks * PL_LOOK_HRS;
+    return 1024 + 2 * (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_look_state_bytes() +
+           (size_t)PL_LOOK_ENTRIES * PL_REC_WORDS * 8 + (size_t)helper_blocks * PL_LOOK_HRS;
 }
-__device__ __forceinline__ size_t pl_look_idx(int64_t pid, int32_t maxNodes, int64_t node, int slot) { return ((size_t)pid * maxNodes + (size_t)node) * (1 + PL_LOOK_KIDS) + slot; }
-#define PL_JOB_NODE(w0) ((uint32_t)((w0) & 0xffffffffull))
-#define PL_JOB_PID(w0) ((int64_t)(((w0) >> 32) & 0xfffffull))
-#define PL_JOB_SLOT(w0) ((int)(((w0) >> 52) & 15ull))
+#define PL_LOOK_NODE_MAX (1 << 24)     // tag fields: node 24 bits, problem 16 bits, slot 8 bits
+#define PL_LOOK_PID_MAX (1 << 16)
+__device__ __forceinline__ unsigned long long pl_look_tag(int64_t pid, int64_t node, int slot) { return (unsigned long long)node | ((unsigned long long)pid << 24) | ((unsigned long long)slot << 40); }
+__device__ __forceinline__ size_t pl_look_ent(const PlLook& look, unsigned long long tag)
+{
+    unsigned long long z = tag * 0x9E3779B97F4A7C15ULL;
+    z ^= z >> 32; z *= 0xd6e8feb86659fd93ULL; z ^= z >> 29;
+    return (size_t)(z & (unsigned long long)look.emask);
+}
+#define PL_JOB_TAG(w0) ((w0) & 0xffffffffffffull)
+#define PL_JOB_NODE(w0) ((uint32_t)((w0) & 0xffffffull))
+#define PL_JOB_PID(w0) ((int64_t)(((w0) >> 24) & 0xffffull))
+#define PL_JOB_SLOT(w0) ((int)(((w0) >> 40) & 255ull))
 // agent-scope relaxed accesses (sc1): payload stores, s_waitcnt vmcnt(0), flag store on the producer side; flag load,
 // then payload loads on the consumer side -- the "sc1 payload -> drained -> sc1 flag" hand-off of MI355X_MICROARCH.md
 // (every access of both sides bypasses the non-coherent L1). PL_LOOK_ATOMICS = 1 builds the same protocol from
@@ -242,13 +271,13 @@ __device__ __forceinline__ size_t pl_look_idx(int64_t pid, int32_t maxNodes, int
 #define PL_FLAG_ST64(q, v) __hip_atomic_store((q), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 #define PL_FLAG_LD64(q) __hip_atomic_load((q), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
 #define PL_FLAG_LD32(q) __hip_atomic_load((q), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
-#define PL_FLAG_OR32(q, v) __hip_atomic_fetch_or((q), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#define PL_FLAG_OR64(q, v) __hip_atomic_fetch_or((q), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define PL_LOOK_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define PL_FLAG_ST64(q, v) pl_st64((q), (v))
 #define PL_FLAG_LD64(q) pl_ld64(q)
 #define PL_FLAG_LD32(q) pl_ld32(q)
-#define PL_FLAG_OR32(q, v) atomicOr((q), (v))
+#define PL_FLAG_OR64(q, v) atomicOr((q), (v))
 #endif
 __device__ __forceinline__ unsigned long long pl_ld64(const unsigned long long* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pl_st64(unsigned long long* q, unsigned long long v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -435,8 +464,8 @@ struct PlShared {
     DevMap km; avp_params kp; PlanDims kdims; PlanWs kw; PlLook klook;
     const double* k_starts; const double* k_goals; avp_plan_result_dev* k_results; double* k_paths; int32_t k_max_path, k_pad;
     uint32_t chk_arrived;             // software barrier of the waves that check the shot's samples
-    double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];   // lane-indexed motion-primitive constants (copy of avp_params)
-    int8_t sub_child[PL_MAXCHILD * 4], sub_j[PL_MAXCHILD * 4], sub_steer[PL_MAXCHILD * 4];   // sub-step t -> child, step, steer index (no integer divisions per pose)
+    double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt1[AVP_MAX_STEER], k_travel_ddt1;   // lane-indexed motion-primitive constants (copy of avp_params); sub-step j: x (j + 1)
+    int8_t sub_child[PL_MAXSUBS], sub_j[PL_MAXSUBS], sub_steer[PL_MAXSUBS];   // sub-step t -> child, step, steer index (no integer divisions per pose)
     int32_t shot_ready;               // 0 = the shot's arg-min is pending, 1 = s.rs holds its path, 2 = no shot
     long long phase[PH_COUNT];
     uint32_t hq_d;                    // result of the collective query
@@ -470,7 +499,7 @@ struct PlShared {
     uint32_t hl_n[PL_HEAP_LDS > 0 ? PL_HEAP_LDS : 1];    // ... nodes
     static constexpr bool POINT_FAST = false;         // (pl_check_narrow)
     __device__ __forceinline__ PlWaveChk& wave_chk() { return wchk[threadIdx.x >> 6]; }
-    uint32_t chk_hit[PL_MAXCHILD * 4];   // hit flag per sub-step pose of the current pop
+    uint32_t chk_hit[PL_MAXSUBS];   // hit flag per sub-step pose of the current pop
     int32_t next_cur, have_next;      // node popped ahead by wave 0 at the end of its resolution (see pl_resolve_fast_wave)
     // expansion lookahead
     unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
@@ -481,7 +510,11 @@ struct PlShared {
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
     int32_t use_rec, job_skip, helper_reg, n_hits, n_sec[4];
-    unsigned long long poll_ri; int32_t poll_on, late_rec, n_late, late_pad;   // PL_LOOK_LATE: the pending record of the node being expanded the long way (pl_look_late)
+    unsigned long long poll_tag; int32_t n_pred, n_busy, n_torn, look_pad;      // the pending record's tag; diagnostics: children posted by pl_look_predict, claims refused (entry busy), copies refused by the seqlock
+    static constexpr bool LOOK_SECOND = true;   // (pl_resolve_fast_wave publishes fetch_second)
+    double fetch_second;                        // the open list's second-best key as of the pop-ahead that named next_cur (pl_resolve_fast_wave -> pl_look_fetch)
+    unsigned long long poll_ri; int32_t poll_on, late_rec, n_late, late_rec2;  // PL_LOOK_LATE: the pending record of the node being expanded the long way (plk_look_late);
+                                                                               // late_rec: adopted at the first poll (read at exit #1 only), late_rec2: at the second (read at exit #2 only)
 };
 
 static_assert(sizeof(PlShared) <= 160 * 1024, "PlShared must fit the 160 KiB LDS of a CU");
@@ -489,7 +522,8 @@ static inline __host__ __device__ size_t pl_lds_tables_offset() { return (sizeof
 static inline size_t pl_lds_tables_bytes(const DevMap& m) { return ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8; }
 
 AVP_D int32_t pl_bucket(uint32_t d) { return (int32_t)(d / 10u); }
-// AVP_PLAN_BAD_POSE: coordinates / headings the loops of the set-up (pi_2_pi's subtract-2-pi loop, the lattice walk) would not come back from
+// AVP_PLAN_BAD_POSE: coordinates that are not finite; headings that are not finite or beyond 1e6 rad -- the reference's pi_2_pi loop (rs_curve.py:648-655)
+// takes |theta| / 2 pi trips (> 1.6e5 beyond 1e6 rad; it never returns beyond ~1e16 or on inf / NaN): a narrower domain than the reference's, by choice
 AVP_D bool pl_pose_ok(double x, double y, double th) { return fabs(x) <= 1.7e308 && fabs(y) <= 1.7e308 && fabs(th) <= 1e6; }      // (finite coordinates -- the BenchmarkCases' run to 9e9 m --, a heading the wrap loop finishes; NaN: false)
 
 AVP_D uint64_t pl_mix(uint64_t z) { z ^= z >> 33; z *= 0xff51afd7ed558ccdULL; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL; z ^= z >> 33; return z; }
@@ -1178,7 +1212,7 @@ AVP_D int pl_rs_sample_book(S& s, const avp_params& p)
     const int point_num = (int)(rp.L / step) + rp.n + 3;
     s.smp_point_num = point_num;
     s.smp_hi = 0;
-    if (point_num > S::RS_CAP || point_num > PL_CHK_MAX - 4 * PL_MAXCHILD) return 5;
+    if (point_num > S::RS_CAP || point_num > PL_CHK_MAX - 256) return 5;
     int ind = 1, hi = 0;
     double d = rp.l[0] > 0.0 ? step : -step;
     double pd = d, ll = 0.0;
@@ -1638,7 +1672,14 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // heappop returns the root; the sift that follows only restores the heap. Publish the node first: on a record pop
         // another wave fetches its expansion record (and waits for a pending one) while this wave walks the heap.
-        const uint32_t root = pl_heap_get(w, s, 0).node;
+        // (lanes 1 and 2 read the root's children in the same instruction: the smaller key is the list's second best, which the
+        //  lookahead's dive prediction compares a child's cost with, pl_look_predict)
+        const PlHeapEnt top3 = pl_heap_get(w, s, (S::LOOK_SECOND && lane < 3 && lane < nheap) ? lane : 0);
+        const uint32_t root = (uint32_t)__builtin_amdgcn_readfirstlane((int)top3.node);
+        if constexpr (S::LOOK_SECOND) {
+            const double k1 = pl_readlane_f64(top3.f, 1), k2 = pl_readlane_f64(top3.f, 2);
+            if (lane == 0) s.fetch_second = nheap < 2 ? INFINITY : (nheap < 3 || k1 < k2) ? k1 : k2;
+        }
         if (lane == 0) {
             s.next_cur = (int32_t)root; s.have_next = 1; s.fetch_nheap = nheap - 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1664,7 +1705,7 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
 // finish_path (hybrid_a_star.py:351-389) + assembly (path_planner.py:100-108): ONE thread writes the record of problem
 // pid straight to global memory (no local copy of the struct: its dynamically indexed arrays would be a stack object).
 // The counts and the RS fields are filled whether or not the caller asked for way-points (paths == NULL).
-// k_travel_ddt / k_dth_ddt: the LDS copies of the motion-primitive constants.
+// travel_ddt1 / k_dth_ddt1: the motion-primitive constants of one sub-step (LDS copies); sub-step j: x (j + 1), as the reference (:367-374).
 // The writer wave of a split resolution (see pl_resolve_fast_wave): once wave 0 has classified the children it creates
 // the new nodes (arena records, pose hash) while wave 0 pushes them onto the heap. The two touch different bytes of a node
 // record (the pushes its heap_pos), and wave 0 waits for wr_done before it may pop one of these nodes ahead.
@@ -1697,7 +1738,7 @@ AVP_D void pl_resolve_writer_wave(const avp_params& p, const PlanWs& w, S& s, co
 }
 
 template <bool PROFILE, class S>
-AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const double* k_travel_ddt, const double (*k_dth_ddt)[4],
+AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const double travel_ddt1, const double* k_dth_ddt1,
                            avp_plan_result_dev* __restrict__ results, double* __restrict__ paths, int32_t max_path, int64_t pid,
                            int64_t n_pops, int32_t slot, long long t_fin)
 {
@@ -1735,8 +1776,9 @@ AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const dou
                     else {
                         const PlNode& par = w.nodes[prev];
                         for (int j = 0; j < p.n_sub; j++) {
-                            const double td = nd.forward ? k_travel_ddt[j] : -k_travel_ddt[j];
-                            const double th_j = avp_pi_2_pi(par.th + k_dth_ddt[nd.steer_i][j]);
+                            const double tj = travel_ddt1 * (double)(j + 1);
+                            const double td = nd.forward ? tj : -tj;
+                            const double th_j = avp_pi_2_pi(par.th + k_dth_ddt1[nd.steer_i] * (double)(j + 1));
                             double s_j, c_j;
                             avp_sincos(th_j, s_j, c_j);
                             push(par.x + td * c_j, par.y + td * s_j, th_j, 0.0);
@@ -1761,104 +1803,90 @@ AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const dou
             else { for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = 0; }
 }
 
+// ---- the record store: state words ---------------------------------------------------------------------------------------
+#define PL_ST_TAG(st) ((st) >> 8)
+#define PL_ST_POSTED(st) (((st) & 1ull) != 0ull)
+#define PL_ST_READY(st) (((st) & 6ull) == 6ull)
+#ifndef PL_LOOK_PREDICT
+#define PL_LOOK_PREDICT 1             // post the child that will be the open list's next root as soon as its parent's record is in the owner's hands (pl_look_predict)
+#endif
+#ifndef PL_LOOK_PREDICT_FETCH
+#define PL_LOOK_PREDICT_FETCH 0       // ... also from a record that only arrives with the fetch at the end of the pop before (one pop of lead instead of two): measured 18.3 vs 18.0 ms -- those jobs come too late and load the helpers
+#endif
+// Owner (one lane per tag): take the tag's entry for a new pair of jobs. True = this lane posts them. False: the tag has its
+// jobs already (in flight or done), or the entry is busy with another tag's jobs in flight (*busy counts those).
+__device__ __forceinline__ bool pl_look_claim(const PlLook& look, unsigned long long tag, int32_t* busy)
+{
+    unsigned long long* q = look.state + pl_look_ent(look, tag);
+    const unsigned long long st = pl_ld64(q);
+    if (PL_ST_TAG(st) == tag && PL_ST_POSTED(st)) return false;
+    if (st != 0ull && !PL_ST_READY(st)) { *busy += 1; return false; }
+    const unsigned long long nw = (tag << 8) | (((((st >> 3) & 31ull) + 1ull) & 31ull) << 3) | 1ull;
+    return atomicCAS(q, st, nw) == st;
+}
+// One wave copies the record of entry ri (state word st: the caller saw it READY) to rec[] and validates it: the state word
+// must be the same after the copy (seqlock: no take-over began meanwhile), and the key words must name this node's exact pose
+// bits, this problem and this goal. Not used: a record whose shot failed to solve or came out collision free (that pop ends
+// the search or raises: the long way).
+template <class S>
+__device__ __forceinline__ int pl_look_copy(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t node, int lane, size_t ri, unsigned long long st, unsigned long long* rec)
+{
+    const unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
+    rec[lane] = pl_ld64(rp + lane);
+    if (lane + 64 < PL_REC_WORDS) rec[lane + 64] = pl_ld64(rp + lane + 64);
+    PL_LOOK_DRAIN();
+    wave_sync();
+    unsigned long long st2 = 0;
+    if (lane == 0) st2 = PL_FLAG_LD64(look.state + ri);
+    st2 = __shfl(st2, 0, 64);
+    const PlNode& nn = w.nodes[node];
+    const unsigned long long fl = rec[84];
+    const bool r_in = fl & 1ull, r_err = (fl >> 8) & 0xffull, r_hit = (fl >> 1) & 1ull;
+    if (st2 != st) { if (lane == 0) atomicAdd(&s.n_torn, 1); return 0; }
+    return rec[80] == pl_bits(nn.x) && rec[81] == pl_bits(nn.y) && rec[82] == pl_bits(nn.th) &&
+           rec[83] == pl_look_key3(pid, s.goal[2]) && rec[86] == pl_bits(s.goal[0]) && rec[87] == pl_bits(s.goal[1]) &&
+           !(r_in && (r_err || !r_hit));
+}
 // Owner side of the lookahead (one wave): the expansion record of `node`, if both halves are finished, is copied to
-// s.recb[buf]; returns whether it is there and is keyed with the node's exact pose bits, this problem and this goal.
-// A node without a record of its own is looked up among its parent's child records. Consumer order: flags, then payload.
+// s.recb[buf]; returns whether it is there and valid (pl_look_copy). A node without jobs of its own is looked up under its
+// parent (slot 1 + child index). Consumer order: state word, payload, state word.
 template <class S>
 __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int buf, bool wait)
 {
     int ok = 0;
     if (node >= 0) {
-        size_t ri = pl_look_idx(pid, maxNodes, node, 0);
-        uint32_t st = 0;
+        unsigned long long tag = 0, st = 0;
+        size_t ri = 0;
         if (lane == 0) {
-            st = PL_FLAG_LD32(look.state + ri);
-            if ((st & 6u) != 6u && !(st & 1u)) {
+            tag = pl_look_tag(pid, node, 0);
+            ri = pl_look_ent(look, tag);
+            st = PL_FLAG_LD64(look.state + ri);
+            bool mine = PL_ST_TAG(st) == tag && PL_ST_POSTED(st);
+            if (!mine) {
                 const PlNode& nn = w.nodes[node];
-                if (nn.parent_pos >= 0) {
-                    const PlNode& pp = w.nodes[nn.parent_pos];
-                    const int d = (int)nn.steer_i - (int)pp.steer_i;
-                    if (pp.steer_i >= 0 && nn.forward == pp.forward && d >= -PL_LOOK_KSPAN && d <= PL_LOOK_KSPAN) {
-                        ri = pl_look_idx(pid, maxNodes, nn.parent_pos, 1 + PL_LOOK_KSPAN + d);
-                        st = PL_FLAG_LD32(look.state + ri);
-                        s.n_sec[(st & 6u) == 6u ? 2 : (st & 1u)] += 1;
-                    }
+                if (nn.parent_pos >= 0 && nn.steer_i >= 0) {
+                    tag = pl_look_tag(pid, nn.parent_pos, 1 + (nn.forward ? 0 : s.kp.n_steer) + nn.steer_i);
+                    ri = pl_look_ent(look, tag);
+                    st = PL_FLAG_LD64(look.state + ri);
+                    mine = PL_ST_TAG(st) == tag && PL_ST_POSTED(st);
+                    s.n_sec[!mine ? 0 : PL_ST_READY(st) ? 2 : 1] += 1;
                 }
             }
-            if (PL_LOOK_WAIT > 0 && wait && s.look_calm && (st & 1u) && (st & 6u) != 6u) {
+            if (!mine) st = 0ull;
+            if (PL_LOOK_WAIT > 0 && wait && s.look_calm && st != 0ull && !PL_ST_READY(st)) {
+                // (an entry whose jobs are in flight is nobody else's to claim: the tag stays while we wait)
                 const long long t0 = clock64();
-                while ((st & 6u) != 6u && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = PL_FLAG_LD32(look.state + ri); }
+                while (!PL_ST_READY(st) && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = PL_FLAG_LD64(look.state + ri); }
                 s.n_sec[3] += 1;
             }
             // (the next pop's own look-up: a record that is posted but not finished is polled again while that pop goes the long way)
-            if (PL_LOOK_LATE && wait) { s.poll_ri = (unsigned long long)ri; s.poll_on = ((st & 1u) && (st & 6u) != 6u) ? 1 : 0; }
+            if (PL_LOOK_LATE && wait) { s.poll_ri = (unsigned long long)ri; s.poll_tag = tag; s.poll_on = (st != 0ull && !PL_ST_READY(st)) ? 1 : 0; }
         }
         st = __shfl(st, 0, 64);
         ri = (size_t)__shfl((unsigned long long)ri, 0, 64);
-        if ((st & 6u) == 6u) {
-            const unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
-            unsigned long long* rec = s.recb[buf];
-            rec[lane] = pl_ld64(rp + lane);
-            if (lane + 64 < PL_REC_WORDS) rec[lane + 64] = pl_ld64(rp + lane + 64);
-            wave_sync();
-            const PlNode& nn = w.nodes[node];
-            const unsigned long long fl = rec[84];
-            const bool r_in = fl & 1ull, r_err = (fl >> 8) & 0xffull, r_hit = (fl >> 1) & 1ull;
-            // (a record whose shot failed to solve or came out collision free is not used: that pop takes the long way)
-            ok = rec[80] == pl_bits(nn.x) && rec[81] == pl_bits(nn.y) && rec[82] == pl_bits(nn.th) &&
-                 rec[83] == pl_look_key3(pid, s.goal[2]) && rec[86] == pl_bits(s.goal[0]) && rec[87] == pl_bits(s.goal[1]) &&
-                 !(r_in && (r_err || !r_hit));
-        }
+        if (st != 0ull && PL_ST_READY(st)) ok = pl_look_copy(look, w, s, pid, node, lane, ri, st, s.recb[buf]);
     }
     return ok;
-}
-// The record of the node the next pop expands (wave 0, once that node is known): the prefetched one if it is that node's,
-// else loaded now. Not for the only open node: the search may end with that pop and hand back its (colliding) shot,
-// which a record does not hold.
-template <class S>
-__device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int32_t nheap_after,
-                                              int64_t hashCap = 0, int nchild = 0, bool lookups = false)
-{
-    int ok = 0;
-    if (PL_LOOK_LATE && lane == 0) { s.poll_on = 0; s.late_rec = 0; }
-    if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
-        if (node == s.pre_node && s.pre_ok) ok = 1;
-        else ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true);
-    }
-    wave_sync();
-    if (lane == 0) { s.use_rec = ok; s.n_hits += ok; if (ok) s.rec_cur ^= 1; s.pre_node = -1; s.pre_ok = 0; }
-    wave_sync();
-    if (lookups && ok) {
-        // (record pop, fetching wave) This pop creates no more nodes -- the writer wave is done before the pop-ahead that
-        // named `node` --, so the pose-hash look-ups of the NEXT pop's children are final now: do them here, beside the
-        // heap sift on wave 0, instead of at the start of that pop. Two states move until then and are set as they will
-        // be: the node being expanded now will be closed, the popped node is marked as such.
-        const unsigned long long* rec = s.recb[s.rec_cur];
-        if (lane < nchild) {
-            const int32_t f = pl_hash_find(w, hashCap, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]), pl_unbits(rec[32 + lane]));
-            int st = f >= 0 ? w.nodes[f].state : 0;
-            if (f == s.cur) st = 2;
-            if (f == node) st = 3;
-            s.nf_found[lane] = f; s.nf_state[lane] = (int8_t)st;
-        }
-        if (lane == 0) s.nf_node = node;
-        wave_sync();
-    }
-}
-// Ahead of that: while the pop is busy elsewhere, an otherwise idle wave copies the record of the node on top of the open
-// list -- the next pop's node unless a child of this one beats it.
-template <class S>
-__device__ __forceinline__ int32_t pl_look_prefetch_node(const PlanWs& w, S& s)       // (reads the heap: while nobody changes it)
-{
-    int32_t node = -1;
-    if (s.look_live && s.nheap >= 2) node = (int32_t)pl_heap_get(w, s, 0).node;      // (with one open node left the record would not be used)
-    return node;
-}
-template <class S>
-__device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane, int32_t node)
-{
-    const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, false);
-    if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
 }
 
 // One wave posts the jobs of its lanes that `want` one to BOTH rings (children half, shot half): one ticket range per ring.
@@ -1881,6 +1909,124 @@ __device__ __forceinline__ void pl_ring_post2(const PlLook& look, int lane, bool
         PL_FLAG_ST64(e1 + 7, t1 + k + 1ull);
     }
 }
+
+// Dive prediction (round 6; one wave, with the validated record of `node` in s.recb[buf]). A quarter of all pops expand a child
+// of the node popped just before; until round 5 such a child had a record only if its parent's pop took the long way (which
+// posts three likely children) -- three quarters of the long pops that were left were dives below RECORD pops. But a parent's
+// record already names its children: poses, first colliding sub-step, Reeds-Shepp length. So as soon as the owner holds the
+// record of the node on top of its open list (prefetched during the pop before: two pops of lead; or fetched at the end of the pop
+// before: one) it costs the children as expand_node will (g from calc_node_cost, h = max(field distance / 100, RS length):
+// hybrid_a_star.py:243-283) and, when the cheapest new child would be the list's next root -- its f below the list's
+// second-best key --, posts THAT child through its parent (slot 1 + child index). A guess: children equal to existing nodes,
+// queries that would miss the closed frontier and the children of the pop in progress are ignored; a wrong guess is a wasted
+// job, a right one turns the dive's long pop (~70 k cycles) into a record pop (~26 k).
+template <class S>
+__device__ __forceinline__ void pl_look_predict(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int lane, int32_t node, int buf, double second_f)
+{
+    const DevMap& m = s.km;
+    const avp_params& p = s.kp;
+    const int nchild = 2 * p.n_steer;
+    const unsigned long long* rec = s.recb[buf];
+    const PlNode& tn = w.nodes[node];
+    const double tth = tn.th;
+    const int tfw = tn.forward;
+    bool valid = lane < nchild;
+    double cx = 0.0, cy = 0.0, cth = 0.0, f = 0.0;
+    if (valid) {
+        cx = pl_unbits(rec[lane]); cy = pl_unbits(rec[16 + lane]); cth = pl_unbits(rec[32 + lane]);
+        const double L = pl_unbits(rec[48 + lane]);
+        const uint32_t fc = (uint32_t)(rec[64 + lane] & 0xffffffffull);
+        const int err = (int)((rec[64 + lane] >> 32) & 0xffull);
+        valid = !(cx > m.b1 || cx < m.b0 || cy > m.b3 || cy < m.b2) && fc == 0x7fffffffu && !err;
+        if (valid) {
+            const int64_t id = avp_pos_to_index(m, cx, cy);
+            const uint32_t d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
+            uint32_t hd = PL_UNSEEN;
+            valid = pl_hquery_hit(m, s, id, d, hd) && hd != PL_UNSEEN;
+            const double hv1 = (double)hd / 100;
+            f = pl_node_cost(p, lane < p.n_steer ? 1 : 0, cth, tth, tfw) + (L > hv1 ? L : hv1);
+        }
+    }
+    // the smallest f (costs are >= +0: the bit patterns order like the values), the first in child order among equals
+    const unsigned long long key = valid ? pl_bits(f) : ~0ull;
+    unsigned long long mn = key;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_xor(mn, d, 64); if (o < mn) mn = o; }
+    if (mn == ~0ull) return;
+    if (!(pl_unbits(mn) < second_f)) return;                 // (uniform) another open node would be popped before it
+    const int best = __ffsll((unsigned long long)__ballot(key == mn)) - 1;
+    bool want = false;
+    unsigned long long w0 = 0;
+    if (lane == best) {
+        w0 = pl_look_tag(pid, node, 1 + best);
+        int32_t busy = 0;
+        want = pl_look_claim(look, w0, &busy);
+        if (busy) atomicAdd(&s.n_busy, busy);
+        if (want) atomicAdd(&s.n_pred, 1);
+    }
+    pl_ring_post2(look, lane, want, w0, cx, cy, cth, s.goal);
+}
+
+// The record of the node the next pop expands (wave 0, once that node is known): the prefetched one if it is that node's,
+// else loaded now. Not for the only open node: the search may end with that pop and hand back its (colliding) shot,
+// which a record does not hold.
+template <class S>
+__device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int32_t nheap_after,
+                                              int64_t hashCap = 0, int nchild = 0, bool lookups = false, bool predict = false)
+{
+    int ok = 0;
+    bool fresh = false;
+    if (PL_LOOK_LATE && lane == 0) { s.poll_on = 0; s.late_rec = 0; s.late_rec2 = 0; }
+    if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
+        if (node == s.pre_node && s.pre_ok) ok = 1;
+        else { ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true); fresh = true; }
+    }
+    wave_sync();
+    if (lane == 0) { s.use_rec = ok; s.n_hits += ok; if (ok) s.rec_cur ^= 1; s.pre_node = -1; s.pre_ok = 0; }
+    wave_sync();
+    // (a record that was not prefetched has not been looked at for a dive yet; the open list's second-best key as of the pop-ahead
+    //  that named `node` was published with it: s.fetch_second)
+    if (PL_LOOK_PREDICT && PL_LOOK_PREDICT_FETCH && predict && ok && fresh && s.look_calm) pl_look_predict(look, w, s, pid, lane, node, s.rec_cur, s.fetch_second);
+    if (lookups && ok) {
+        // (record pop, fetching wave) This pop creates no more nodes -- the writer wave is done before the pop-ahead that
+        // named `node` --, so the pose-hash look-ups of the NEXT pop's children are final now: do them here, beside the
+        // heap sift on wave 0, instead of at the start of that pop. Two states move until then and are set as they will
+        // be: the node being expanded now will be closed, the popped node is marked as such.
+        const unsigned long long* rec = s.recb[s.rec_cur];
+        if (lane < nchild) {
+            const int32_t f = pl_hash_find(w, hashCap, pl_unbits(rec[lane]), pl_unbits(rec[16 + lane]), pl_unbits(rec[32 + lane]));
+            int st = f >= 0 ? w.nodes[f].state : 0;
+            if (f == s.cur) st = 2;
+            if (f == node) st = 3;
+            s.nf_found[lane] = f; s.nf_state[lane] = (int8_t)st;
+        }
+        if (lane == 0) s.nf_node = node;
+        wave_sync();
+    }
+}
+// Ahead of that: while the pop is busy elsewhere, an otherwise idle wave copies the record of the node on top of the open
+// list -- the next pop's node unless a child of this one beats it -- and looks at it for a dive (pl_look_predict: second_f =
+// the list's second-best key, the smaller of the root's two children, read together with the root).
+template <class S>
+__device__ __forceinline__ int32_t pl_look_prefetch_node(const PlanWs& w, S& s, double& second_f)       // (reads the heap: while nobody changes it)
+{
+    int32_t node = -1;
+    second_f = INFINITY;
+    if (s.look_live && s.nheap >= 2) {      // (with one open node left the record would not be used)
+        node = (int32_t)pl_heap_get(w, s, 0).node;
+        second_f = pl_heap_get(w, s, 1).f;
+        if (s.nheap >= 3) { const double f2 = pl_heap_get(w, s, 2).f; if (f2 < second_f) second_f = f2; }
+    }
+    return node;
+}
+template <class S>
+__device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane, int32_t node, double second_f)
+{
+    const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, false);
+    if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
+    if (PL_LOOK_PREDICT && ok && s.look_calm) pl_look_predict(look, w, s, pid, lane, node, s.rec_cur ^ 1, second_f);
+}
+
 // Owner side of the lookahead: one wave posts, in ONE round (one look at the ring counters, one ticket range per ring,
 // one drain of the payload stores),
 //  * lanes 0 .. PL_LOOK_TOP-1: the nodes in the first heap slots that have no job yet (pl_look_candidate reads the heap
@@ -1904,22 +2050,25 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     // ring counters (head counts the tickets drawn: it runs ahead of the tail while helpers wait for work)
     unsigned long long c = 0;
     if (lane < 5) c = pl_ld64(look.ctrl + (lane == 0 ? 48 : lane == 1 ? 0 : lane == 2 ? 16 : lane == 3 ? 64 : 80));
-    // candidates: does the slot have a job already?
     const int d = lane - 32 - PL_LOOK_KSPAN, sc = (int)cn.steer_i + d;
     const bool kid = kids && lane >= 32 && lane < 32 + PL_LOOK_KIDS && cn.steer_i >= 0 && sc >= 0 && sc < p.n_steer;
     const bool cand = lane < 32 && node != 0xffffffffu;
-    const size_t si = kid ? pl_look_idx(pid, maxNodes, s.cur, 1 + PL_LOOK_KSPAN + d) : pl_look_idx(pid, maxNodes, cand ? node : 0, 0);
-    bool want = false;
-    if (kid || cand) want = pl_ld32(look.state + si) == 0u;
     const unsigned long long helpers = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
     const long long backlog = max((long long)(ta - ha), (long long)(tb - hb));
     if (lane == 0) { s.look_calm = (helpers != 0 && backlog <= PL_LOOK_BACKLOG) ? 1 : 0; s.look_live = helpers != 0 ? 1 : 0; }   // (calm: the helpers keep up, a pending record is worth a short wait)
-    // nobody to serve / a ring is nearly full: every owner may post up to PL_LOOK_TOP + PL_LOOK_KIDS jobs from the same (stale)
-    // reading of the counters, so the margin is several times owners x jobs (256 x 19 = 4 864) -- an unread entry is never overwritten
+    // nobody to serve / a ring is nearly full: every owner may post up to PL_LOOK_TOP + PL_LOOK_KIDS + 1 jobs from the same (stale)
+    // reading of the counters, so the margin is several times owners x jobs (512 x 20 = 10 240) -- an unread entry is never overwritten
     if (helpers == 0 || backlog > PL_JCAP - 16384) return;
-    if (backlog > PL_LOOK_BACKLOG && lane >= 32) want = false;
-    double x = 0.0, y = 0.0, th = 0.0;
+    // does the tag have its jobs already? else claim its entry (the children of the node being expanded: slot 1 + child index)
+    bool want = false;
     unsigned long long w0 = 0;
+    if ((kid && backlog <= PL_LOOK_BACKLOG) || cand) {
+        w0 = kid ? pl_look_tag(pid, s.cur, 1 + (cn.forward ? 0 : p.n_steer) + sc) : pl_look_tag(pid, node, 0);
+        int32_t busy = 0;
+        want = pl_look_claim(look, w0, &busy);
+        if (busy) atomicAdd(&s.n_busy, busy);
+    }
+    double x = 0.0, y = 0.0, th = 0.0;
     if (want) {
         if (kid) {
             // (the children stage's expressions, hybrid_a_star.py:134-151)
@@ -1929,13 +2078,10 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
             avp_sincos(th, sth, cth);
             x = cn.x + travel * cth;
             y = cn.y + travel * sth;
-            w0 = (unsigned long long)(uint32_t)s.cur | ((unsigned long long)pid << 32) | ((unsigned long long)(1 + PL_LOOK_KSPAN + d) << 52);
         } else {
             const PlNode& nd = w.nodes[node];
             x = nd.x; y = nd.y; th = nd.th;
-            w0 = (unsigned long long)node | ((unsigned long long)pid << 32);
         }
-        pl_st32(look.state + si, 1u);
     }
     pl_ring_post2(look, lane, want, w0, x, y, th, s.goal);
 }
@@ -1996,7 +2142,7 @@ template <bool PROFILE>
 __device__ __noinline__ void plk_write_result(AVP_LDS PlShared* sp, int64_t pid, int64_t n_pops, int32_t slot, long long t_fin)
 {
     PlShared& s = *(PlShared*)sp;
-    pl_write_result<PROFILE>(s.kp, s.kw, s, s.k_travel_ddt, s.k_dth_ddt, s.k_results, s.k_paths, s.k_max_path, pid, n_pops, slot, t_fin);
+    pl_write_result<PROFILE>(s.kp, s.kw, s, s.k_travel_ddt1, s.k_dth_ddt1, s.k_results, s.k_paths, s.k_max_path, pid, n_pops, slot, t_fin);
 }
 
 // the owner side of the lookahead (one wave each), as called functions: five call sites in the pop loop
@@ -2008,15 +2154,17 @@ __device__ __noinline__ void plk_look_post(AVP_LDS PlShared* sp, int64_t pid, in
     cn.x = cnx; cn.y = cny; cn.th = cnth; cn.forward = (int8_t)cn_forward; cn.steer_i = (int8_t)cn_steer;     // (what pl_look_post reads of the node)
     pl_look_post(s.klook, s.kw, s, s.kp, cn, pid, maxNodes, threadIdx.x & 63, node, kids != 0);
 }
-__device__ __noinline__ void plk_look_fetch(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node, int32_t nheap_after, int nchild, int lookups)
+__device__ __noinline__ void plk_look_fetch(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node, int32_t nheap_after, int nchild, int flags)
 {
+    // flags: bit 0 = do the pose-hash look-ups of the node's children (record pop, fetching wave), bit 1 = the node was named by a pop-ahead
+    // (s.fetch_second is that pop-ahead's): look at a freshly loaded record for a dive
     PlShared& s = *(PlShared*)sp;
-    pl_look_fetch(s.klook, s.kw, s, pid, maxNodes, node, threadIdx.x & 63, nheap_after, s.kdims.hashCap, nchild, lookups != 0);
+    pl_look_fetch(s.klook, s.kw, s, pid, maxNodes, node, threadIdx.x & 63, nheap_after, s.kdims.hashCap, nchild, (flags & 1) != 0, (flags & 2) != 0);
 }
-__device__ __noinline__ void plk_look_prefetch(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node)
+__device__ __noinline__ void plk_look_prefetch(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node, double second_f)
 {
     PlShared& s = *(PlShared*)sp;
-    pl_look_prefetch(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node);
+    pl_look_prefetch(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node, second_f);
 }
 
 // Late adoption (round 5). A pop goes the long way when its node's record is not there at the moment the node is popped -- for a
@@ -2027,29 +2175,25 @@ __device__ __noinline__ void plk_look_prefetch(AVP_LDS PlShared* sp, int64_t pid
 // record exactly as pl_look_load does. The pop then leaves the long way at that barrier -- nothing it has done so far has
 // touched a counter, the arena, the heap or the hash -- and is resolved from the record like any record pop. Whether and when
 // a record lands changes the time of a pop, never a result (tests/test_gpu_lookahead.py).
-__device__ __noinline__ void plk_look_late(AVP_LDS PlShared* sp, int64_t pid)
+// The two polls publish through flags of their own (second = 0: s.late_rec, read by every wave behind the barrier of exit #1;
+// second = 1: s.late_rec2, read behind the barrier of exit #2). With ONE flag wave 0 could run ahead through its Reeds-Shepp
+// words (no barrier inside on the one-pass path) and set it at the second poll while a slower wave had not yet read it for
+// exit #1: that wave would leave the long way alone and the workgroup's barrier sequences would no longer match. A flag is
+// only ever written before the barrier its readers sit behind, and cleared a barrier later (pl_look_fetch).
+__device__ __noinline__ void plk_look_late(AVP_LDS PlShared* sp, int64_t pid, int second)
 {
     PlShared& s = *(PlShared*)sp;
-    if (!s.poll_on || s.late_rec) return;                              // (uniform)
+    if (!s.poll_on || s.late_rec || s.late_rec2) return;               // (uniform: only wave 0 writes the three, and only here / in pl_look_fetch)
     const PlLook& look = s.klook;
     const int lane = threadIdx.x & 63;
     const size_t ri = (size_t)s.poll_ri;
-    uint32_t st = 0;
-    if (lane == 0) st = PL_FLAG_LD32(look.state + ri);
+    unsigned long long st = 0;
+    if (lane == 0) st = PL_FLAG_LD64(look.state + ri);
     st = __shfl(st, 0, 64);
-    if ((st & 6u) != 6u) return;
-    const unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
-    unsigned long long* rec = s.recb[s.rec_cur];                       // (the buffer of the popped node's record: free on the long way; the other one is the prefetch target)
-    rec[lane] = pl_ld64(rp + lane);
-    if (lane + 64 < PL_REC_WORDS) rec[lane + 64] = pl_ld64(rp + lane + 64);
-    wave_sync();
-    const PlNode& nn = s.kw.nodes[s.cur];
-    const unsigned long long fl = rec[84];
-    const bool r_in = fl & 1ull, r_err = (fl >> 8) & 0xffull, r_hit = (fl >> 1) & 1ull;
-    const bool ok = rec[80] == pl_bits(nn.x) && rec[81] == pl_bits(nn.y) && rec[82] == pl_bits(nn.th) &&
-                    rec[83] == pl_look_key3(pid, s.goal[2]) && rec[86] == pl_bits(s.goal[0]) && rec[87] == pl_bits(s.goal[1]) &&
-                    !(r_in && (r_err || !r_hit)) && s.nheap >= 1;      // (as pl_look_load / pl_look_fetch: not the record of the only open node)
-    if (lane == 0) { s.poll_on = 0; if (ok) { s.late_rec = 1; s.n_hits += 1; s.n_late += 1; } }
+    if (PL_ST_TAG(st) != s.poll_tag || !PL_ST_READY(st)) return;      // (not there yet -- or finished AND taken over by another tag since: gone)
+    // (the buffer of the popped node's record: free on the long way; the other one is the prefetch target. As pl_look_load / pl_look_fetch: not the record of the only open node)
+    const bool ok = pl_look_copy(look, s.kw, s, pid, s.cur, lane, ri, st, s.recb[s.rec_cur]) && s.nheap >= 1;
+    if (lane == 0) { s.poll_on = 0; if (ok) { if (second) s.late_rec2 = 1; else s.late_rec = 1; s.n_hits += 1; s.n_late += 1; } }
 }
 
 template <bool STAGE, bool PROFILE, bool LOOK = false>
@@ -2074,18 +2218,16 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         w.rsdir = (int8_t*)(look.hrs + (size_t)((int32_t)blockIdx.x - look.main_blocks) * PL_LOOK_HRS + pl_al((size_t)PL_RS_CAP * 3 * 8));
     }
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.look_calm = 0; s.look_live = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; s.poll_on = 0; s.late_rec = 0; s.n_late = 0; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.look_calm = 0; s.look_live = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; s.poll_on = 0; s.late_rec = 0; s.late_rec2 = 0; s.n_late = 0; s.n_pred = 0; s.n_busy = 0; s.n_torn = 0; s.poll_tag = 0; s.fetch_second = INFINITY; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll
     for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
-        s.k_steer[k] = p.steer[k]; s.k_dth_dt[k] = p.dth_dt[k];
-#pragma unroll
-        for (int j = 0; j < 4; j++) s.k_dth_ddt[k][j] = p.dth_ddt[k][j];
+        s.k_steer[k] = p.steer[k]; s.k_dth_dt[k] = p.dth_dt[k]; s.k_dth_ddt1[k] = p.dth_ddt1[k];
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) if (tid == k) s.k_travel_ddt[k] = p.travel_ddt[k];
-    if (tid < PL_MAXCHILD * 4 && p.n_sub > 0 && p.n_steer > 0) { const int ci = tid / p.n_sub; s.sub_child[tid] = (int8_t)ci; s.sub_j[tid] = (int8_t)(tid - ci * p.n_sub); s.sub_steer[tid] = (int8_t)(ci % p.n_steer); }
+    if (tid == 0) s.k_travel_ddt1 = p.travel_ddt1;
+    if (p.n_sub > 0 && p.n_steer > 0)
+        for (int t = tid; t < PL_MAXSUBS && t < 2 * p.n_steer * p.n_sub; t += PL_THREADS) { const int ci = t / p.n_sub; s.sub_child[t] = (int8_t)ci; s.sub_j[t] = (int8_t)(t - ci * p.n_sub); s.sub_steer[t] = (int8_t)(ci % p.n_steer); }
     // STAGE: the column bitmaps and node coordinates of the map live in LDS behind PlShared for the whole
     // (persistent) lifetime of the workgroup; otherwise they are read through L1/L2
     MapTabs mt;
@@ -2217,6 +2359,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             bool can_fast = false;
             long long t_f = 0;
             int32_t pre_cand = -1;
+            double pre_second = INFINITY;
             bool late = false;                 // (PL_LOOK_LATE) the long way was left for the node's record, which landed meanwhile
             if (!use_rec) {
             if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = hC ? 2 : 0; }
@@ -2245,8 +2388,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             else if (one_pass && tid == PL_THREADS - 1 && s.sched_cnt != nq_all) pl_rs_build_schedule(s, nq_all);
             if (PROFILE && tid == 0) s.phase[PH_CHILD_W0] += clock64() - t_d;
             if constexpr (LOOK) if (!helper && look.on && wave == 0) {
-                plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, pl_look_prefetch_node(w, s));   // (wave 0 idles until the sub-step checks are done)
-                if (PL_LOOK_LATE) plk_look_late((AVP_LDS PlShared*)&s, pid);                             // ... and looks for this node's pending record again
+                double sec_f;
+                const int32_t top = pl_look_prefetch_node(w, s, sec_f);
+                plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, top, sec_f);                   // (wave 0 idles until the sub-step checks are done)
+                if (PL_LOOK_LATE) plk_look_late((AVP_LDS PlShared*)&s, pid, 0);                           // ... and looks for this node's pending record again
             }
             // Meanwhile waves 1 .. nwave-2 check the sub-step poses of every child (:185-204): they depend on the
             // popped node only, not on the children stage that keeps wave 0 (and the last wave) busy.
@@ -2260,8 +2405,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         pl_check_wave<STAGE>(s.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
                             const int t = base + k;
                             const int ci = s.sub_child[t], j = s.sub_j[t], si = s.sub_steer[t];
-                            const double td = ci < p.n_steer ? s.k_travel_ddt[j] : -s.k_travel_ddt[j];
-                            th = avp_pi_2_pi(cn.th + s.k_dth_ddt[si][j]);
+                            const double tj = s.k_travel_ddt1 * (double)(j + 1);      // speed * ddt * (i + 1), :188
+                            const double td = ci < p.n_steer ? tj : -tj;
+                            th = avp_pi_2_pi(cn.th + s.k_dth_ddt1[si] * (double)(j + 1));      // ... / lw * ddt * (i + 1), :189-191
                             avp_sincos(th, sn, cs);
                             x = cn.x + td * cs;
                             y = cn.y + td * sn;
@@ -2293,12 +2439,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         else { x = s.child[g - qoff].x; y = s.child[g - qoff].y; th = s.child[g - qoff].th; }
                     }, one_pass);
 #if PL_LOOK_LATE
-                    if constexpr (LOOK) if (!helper && look.on && wave == 0 && base == 0) plk_look_late((AVP_LDS PlShared*)&s, pid);      // (wave 0 is done with its words ~5 k cycles before the others)
+                    if constexpr (LOOK) if (!helper && look.on && wave == 0 && base == 0) plk_look_late((AVP_LDS PlShared*)&s, pid, 1);      // (wave 0 is done with its words ~5 k cycles before the others)
 #endif
                     if (base == 0) PH_MARK(1);
                     __syncthreads();
 #if PL_LOOK_LATE
-                    if constexpr (LOOK) if (!helper && base == 0 && s.late_rec) { late = true; goto pl_late_record; }
+                    if constexpr (LOOK) if (!helper && base == 0 && s.late_rec2) { late = true; goto pl_late_record; }
 #endif
                     if (PROFILE && tid == 0) s.phase[PH_RS_WORDS] += clock64() - t_e;
                     // set_path and arg-min, a whole query per wave (20 lanes run its type groups, then the wave folds):
@@ -2377,7 +2523,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     wave_sync();
                     if (can_fast) {
                         pl_resolve_fast_wave<PROFILE>(m, p, w, s, dims, cn, nchild, n_pops < max_pops);
-                        if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0); }
+                        if constexpr (LOOK) if (look.on) { wave_sync(); if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 2); }
                     }
                 }
                 if (wave >= w0 && wave < w0 + nw) {
@@ -2446,7 +2592,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 // publish this half of the record: payload, then the half's ready bit
                 if (wave == 0) {
                     const unsigned long long j0 = s.job[0];
-                    const size_t ri = pl_look_idx(PL_JOB_PID(j0), maxNodes, PL_JOB_NODE(j0), PL_JOB_SLOT(j0));
+                    const size_t ri = pl_look_ent(look, PL_JOB_TAG(j0));      // (the entry is this job's until both halves are there: pl_look_claim)
                     unsigned long long* rp = look.recs + ri * PL_REC_WORDS;
                     if (hC && lane < nchild) {
                         const PlChild& c = s.child[lane];
@@ -2465,7 +2611,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     }
                     PL_LOOK_DRAIN();
                     wave_sync();
-                    if (lane == 0) { PL_FLAG_OR32(look.state + ri, hS ? 4u : 2u); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
+                    if (lane == 0) { PL_FLAG_OR64(look.state + ri, hS ? 4ull : 2ull); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
                     if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
                 }
                 continue;
@@ -2478,7 +2624,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (use_rec || late) {
                 // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
                 const unsigned long long* rec = s.recb[s.rec_cur];
-                if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s);      // (its record is fetched beside the resolution)
+                if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s, pre_second);      // (its record is fetched beside the resolution)
                 const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
                 if (wave == 2 && lane < nchild) {
                     // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
@@ -2528,17 +2674,17 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                             if (lane == 0 && *(volatile int32_t*)&s.wr_go == 0) *(volatile int32_t*)&s.wr_go = 2;
                             if (lane == 0 && *(volatile int32_t*)&s.fetch_go == 0) *(volatile int32_t*)&s.fetch_go = 2;
                         }
-                        else if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 0);
+                        else if (s.have_next) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.nheap, 0, 2);
                     }
                 } else if (LOOK && rec && wave == 1) {
                     // record pop: the other waves are idle, so this one fetches the next node's record as soon as wave 0
                     // knows that node (before it sifts the heap), and does the bounded wait for a pending record
                     if constexpr (LOOK) {
-                        plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, pre_cand);
+                        plk_look_prefetch((AVP_LDS PlShared*)&s, pid, maxNodes, pre_cand, pre_second);
                         if (lane == 0) while (*(volatile int32_t*)&s.fetch_go == 0) __builtin_amdgcn_s_sleep(2);
                         wave_sync();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        if (*(volatile int32_t*)&s.fetch_go == 1) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.fetch_nheap, nchild, 1);
+                        if (*(volatile int32_t*)&s.fetch_go == 1) plk_look_fetch((AVP_LDS PlShared*)&s, pid, maxNodes, s.next_cur, s.fetch_nheap, nchild, 3);
                     }
                 } else if (LOOK && rec && wave == 2) {
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
@@ -2643,7 +2789,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
         if (tid == 0) {
             plk_write_result<PROFILE>((AVP_LDS PlShared*)&s, pid, n_pops, (int32_t)blockIdx.x, t_fin);
-            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } if (s.n_late) { atomicAdd(look.ctrl + 76, (unsigned long long)s.n_late); s.n_late = 0; } }   // ([8]: records used, [76]: of which adopted late -- diagnostics)
+            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } if (s.n_late) { atomicAdd(look.ctrl + 76, (unsigned long long)s.n_late); s.n_late = 0; } if (s.n_pred) { atomicAdd(look.ctrl + 77, (unsigned long long)s.n_pred); s.n_pred = 0; } if (s.n_busy) { atomicAdd(look.ctrl + 78, (unsigned long long)s.n_busy); s.n_busy = 0; } if (s.n_torn) { atomicAdd(look.ctrl + 79, (unsigned long long)s.n_torn); s.n_torn = 0; } }   // ([8]: records used, [76]: of which adopted late -- diagnostics)
         }
         __syncthreads();
     }

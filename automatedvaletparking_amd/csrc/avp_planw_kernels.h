@@ -87,7 +87,7 @@ static __device__ const int8_t PW_ITEM_M[46] = { 0, 0,  0, 1, 0, 1,  0, 1, 0, 1,
 // by-value kernel argument would be copied to every lane's scratch), the sub-step index tables, and COPIES of the
 // kernel's arguments -- the phases of a pop are called functions (below) that take two LDS addresses, nothing else.
 struct PwCommon {
-    double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt[AVP_MAX_STEER][4], k_travel_ddt[4];
+    double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt1[AVP_MAX_STEER], k_travel_ddt1;      // (sub-step j: x (j + 1))
     int8_t sub_child[PW_MAXCHILD * 4], sub_j[PW_MAXCHILD * 4], sub_steer[PW_MAXCHILD * 4];
     int8_t item_word[46], item_g[46], item_m[46], sg_l[8], sg_shift[8], sg_off[8], sg_gmax[8];
     PlChkEnv env;                     // what the called collision passes read of the map and the vehicle
@@ -251,6 +251,7 @@ struct PwSharedT {
     int32_t wr_go, wr_done;
     static constexpr bool HEAP_POS = true;
     static constexpr int HEAP_LDS = 0;         // (no LDS heap top in these forms: the whole open list stays in the workspace)
+    static constexpr bool LOOK_SECOND = false; // (no expansion lookahead in these forms)
     uint32_t phase[PW_PH_COUNT];               // instrumented instantiation only: shader cycles per phase (lane 0)
     int64_t snap[5];                           // counters saved before a resolution that runs beside the shot (pw_ph_shot_resolve)
     int32_t resume, fresh_done, park_now, sl_pad;   // time slicing: this problem continues a parked search / no unstarted problem is left / park decision
@@ -405,7 +406,7 @@ __device__ __noinline__ void pw_ph_init(PW_PHASE_ARGS)
     for (int64_t i = gtid; i < c.dims.hashCap; i += G::N) w.hash[i] = 0;
     if (gtid == 0) {
         const bool pose_ok = pl_pose_ok(sx, sy, sth) && pl_pose_ok(gx, gy, gth);
-        s.status = !pose_ok ? 7 /* AVP_PLAN_BAD_POSE */ : (c.nchild > PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;
+        s.status = !pose_ok ? 7 /* AVP_PLAN_BAD_POSE */ : (c.nchild > PW_MAXCHILD || c.nsubs > 4 * PW_MAXCHILD) ? AVP_PLAN_RETRY : 0; s.done = 0;      // (more children / sub-step poses than a group holds: plan_kernel plans it)
         s.nnodes = 0; s.nheap = 0; s.nclosed = 0; s.closed_nonempty = 0; s.have_next = 0; s.next_cur = -1;
         s.global_index = 0; s.cur = -1; s.n_checks = 0; s.n_rs = 0; s.n_pops = 0;
         s.goal[0] = gx; s.goal[1] = gy; s.goal[2] = pose_ok ? avp_pi_2_pi(gth) : 0.0;
@@ -532,8 +533,9 @@ __device__ __noinline__ void pw_ph_substeps(PW_PHASE_ARGS)
         pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
             const int t = s.sub_t[base + k];
             const int ci = c.sub_child[t], j = c.sub_j[t], si = c.sub_steer[t];
-            const double td = ci < p.n_steer ? c.k_travel_ddt[j] : -c.k_travel_ddt[j];
-            th = avp_pi_2_pi(cnth + c.k_dth_ddt[si][j]);
+            const double tj = c.k_travel_ddt1 * (double)(j + 1);
+            const double td = ci < p.n_steer ? tj : -tj;
+            th = avp_pi_2_pi(cnth + c.k_dth_ddt1[si] * (double)(j + 1));
             avp_sincos(th, sn, cs);
             x = cnx + td * cs;
             y = cny + td * sn;
@@ -929,7 +931,7 @@ __device__ __noinline__ void pw_ph_finish(PW_PHASE_ARGS)
     }
     if (gtid == 0) {
         if (s.status == AVP_PLAN_RETRY) { c.results[s.pid].status = AVP_PLAN_RETRY; if (c.deferred) atomicAdd(c.deferred, 1u); }
-        else pl_write_result<false>(p, w, s, c.k_travel_ddt, c.k_dth_ddt, c.results, c.paths, c.max_path, s.pid, s.n_pops, s.slot, 0ll);
+        else pl_write_result<false>(p, w, s, c.k_travel_ddt1, c.k_dth_ddt1, c.results, c.paths, c.max_path, s.pid, s.n_pops, s.slot, 0ll);
     }
     G::sync();
 }
@@ -975,12 +977,9 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
     }
 #pragma unroll
     for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
-        c.k_steer[k] = p.steer[k]; c.k_dth_dt[k] = p.dth_dt[k];
-#pragma unroll
-        for (int j = 0; j < 4; j++) c.k_dth_ddt[k][j] = p.dth_ddt[k][j];
+        c.k_steer[k] = p.steer[k]; c.k_dth_dt[k] = p.dth_dt[k]; c.k_dth_ddt1[k] = p.dth_ddt1[k];
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) if (tid == k) c.k_travel_ddt[k] = p.travel_ddt[k];
+    if (tid == 0) c.k_travel_ddt1 = p.travel_ddt1;
     if (tid < PW_MAXCHILD * 4 && p.n_sub > 0 && p.n_steer > 0) { const int ci = tid / p.n_sub; c.sub_child[tid] = (int8_t)ci; c.sub_j[tid] = (int8_t)(tid - ci * p.n_sub); c.sub_steer[tid] = (int8_t)(ci % p.n_steer); }
     if (tid < 46) { c.item_word[tid] = PW_ITEM_WORD[tid]; c.item_g[tid] = PW_ITEM_G[tid]; c.item_m[tid] = PW_ITEM_M[tid]; }
     if (tid < 8) { c.sg_l[tid] = PW_SG_L[tid]; c.sg_shift[tid] = PW_SG_SHIFT[tid]; c.sg_off[tid] = PW_SG_OFF[tid]; c.sg_gmax[tid] = PW_SG_GMAX[tid]; }

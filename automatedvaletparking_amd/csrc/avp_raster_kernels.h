@@ -59,12 +59,13 @@ __global__ void rasterize_kernel(RasterGrid g, const double* __restrict__ edges,
 // all maps concatenated, edge e belongs to map emap[e]; a map is a grid descriptor (its node tables inside one packed buffer) and
 // the offset of its occupancy bytes inside one packed, zeroed buffer; multi[k] counts map k's multi-match samples.
 struct RasterGridB { RasterGrid g; int64_t occ_off; };
-__global__ void rasterize_batch_kernel(const RasterGridB* __restrict__ grids, const double* __restrict__ edges, const int32_t* __restrict__ emap,
+__global__ void rasterize_batch_kernel(const RasterGridB* __restrict__ grids, int32_t n_maps, const double* __restrict__ edges, const int32_t* __restrict__ emap,
                                        int64_t n_edges, uint8_t* __restrict__ occ, int32_t* __restrict__ multi)
 {
     const int64_t ei = (int64_t)blockIdx.y + (int64_t)blockIdx.z * 65535;
     if (ei >= n_edges) return;
     const int32_t k = emap[ei];
+    if (k < 0 || k >= n_maps) return;        // (edge_map lives in device memory: the host cannot validate it; an edge of no map is skipped, never an out-of-bounds access)
     const RasterGridB gb = grids[k];
     const double* e = edges + ei * 6;
     const int count = (int)e[5];

@@ -126,7 +126,7 @@ class BatchPlanner:
         self._look = None
         self.last_lookahead = False
 
-    LOOK_BYTES_MAX = 24 << 30          # (512 problems x 16 384 nodes x 4 x 708 B = 23.8 GB of MI355X's 288)
+    LOOK_BYTES_MAX = 1 << 30           # (the record store has a fixed size since round 6 -- 262 144 records, 0.2 GB -- whatever the batch and the node arena)
     LOOK_FREE_FRAC = 0.25              # ... and at most this share of the device memory that is free right now
     SLICE_FREE_FRAC = 0.5              # time slicing: one workspace slot per problem, at most this share of the free memory
     SLICE_MIN_RATIO = 6                # ... and by default only from this many problems per group on (measured on the Case1 sets:
@@ -151,8 +151,8 @@ class BatchPlanner:
     def _look_workspace(self, n):
         """The lookahead's record store, or None. lookahead=None (the default) is conservative: never for a single problem
         (a lone a_star_plan() leaves the other compute units to whoever else uses the device: the helpers would park a
-        spinning workgroup on each), never when the store would take more than LOOK_BYTES_MAX or LOOK_FREE_FRAC of the
-        free device memory, and an allocation failure falls back to planning without it. lookahead=True asks for it
+        spinning workgroup on each), never when the store (a fixed 0.2 GB: avp_plan_look_bytes) would take more than LOOK_FREE_FRAC
+        of the free device memory, and an allocation failure falls back to planning without it. lookahead=True asks for it
         whenever the library supports it for the batch (and raises if the store cannot be allocated)."""
         if self.lookahead is False:
             return None
@@ -402,6 +402,12 @@ class PathPlanner:
                 raise AttributeError("'NoneType' object has no attribute 'x'")       # path_planner.py:104
         elif r.status == 3:
             raise AssertionError("path.L >= 0.01")                                   # rs_curve.py:153
+        elif r.status == 7:
+            # AVP_PLAN_BAD_POSE is this library's refusal, not a planner failure: its own exception type, so that a caller that
+            # treats "any status but 0 / 1" as "no plan found" does not mistake it for one. The reference itself would still
+            # return on a finite heading up to ~1e16 rad (rs_curve.py:648-655 needs |theta| / 2 pi loop trips: > 1.6e5 beyond 1e6 rad).
+            raise ValueError("start / goal pose refused (AVP_PLAN_BAD_POSE): a coordinate or heading that is not finite, or a heading "
+                             "beyond 1e6 rad (the reference's pi_2_pi loop needs more than 1.6e5 iterations there and never returns beyond ~1e16)")
         else:
             raise RuntimeError(f"hybrid A* stopped with status {r.status_name}")
         final_path = [[float(p[0]), float(p[1]), float(p[2])] for p in r.final_path]

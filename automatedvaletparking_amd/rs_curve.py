@@ -66,7 +66,7 @@ def _paths_from_result(r) -> List[PATH]:
         if st == 1:
             raise IndexError("list index out of range")     # paths[0] on an empty candidate list, rs_curve.py:103
         if st == 7:
-            raise ValueError("Reeds-Shepp query with a non-finite or absurd pose (a coordinate that is not finite or |yaw| > 1e6 rad): the reference's pi_2_pi loop never returns on it")
+            raise ValueError("Reeds-Shepp query refused (AVP_PLAN_BAD_POSE): a coordinate or yaw that is not finite, or |yaw| > 1e6 rad (the reference's pi_2_pi loop needs more than 1.6e5 iterations there and never returns beyond ~1e16)")
         if st:
             raise RuntimeError(f"Reeds-Shepp capacity (status {st}); raise maxpts")
         k = int(r["npts"][i])

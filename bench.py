@@ -179,6 +179,27 @@ def same_results(ra, pa, rb, pb):
     return bool(ok and all(np.array_equal(pa[i, :ra["n_final"][i]], pb[i, :ra["n_final"][i]]) for i in range(len(ra))))
 
 
+def collective_proof(torch, dist, rank, local, world, dev):
+    """What RCCL itself saw: every rank's (rank, local device index, device uuid, PCI address, host name, device name) travels
+    through ONE all-gather on the nccl group -- the line then shows the backend, the world size the process group reports and
+    the number of DISTINCT devices among the ranks (which must equal the world size: a rank per GPU), not just the --gpus
+    argument echoed back."""
+    import socket
+    pr = torch.cuda.get_device_properties(local)
+    pci = "%04x:%02x:%02x" % (int(getattr(pr, "pci_domain_id", 0)), int(getattr(pr, "pci_bus_id", 0)), int(getattr(pr, "pci_device_id", 0)))
+    ident = "|".join([str(rank), str(local), str(getattr(pr, "uuid", "")), pci, socket.gethostname(), str(pr.name)]).encode()[:256]
+    mine = torch.zeros(256, dtype=torch.uint8, device=dev)
+    mine[:len(ident)] = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+    allr = torch.empty(world * 256, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allr, mine)
+    rows = [bytes(allr[i * 256:(i + 1) * 256].cpu().numpy().tolist()).rstrip(b"\0").decode() for i in range(world)]
+    devices = [dict(zip(("rank", "local_device", "uuid", "pci", "host", "name"), r.split("|"))) for r in rows]
+    distinct = len({(d["host"], d["uuid"] or d["pci"]) for d in devices})
+    return {"backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()), "devices": devices, "distinct_devices": distinct,
+            "ranks_in_order": [int(d["rank"]) for d in devices] == list(range(world)),
+            "note": "gathered through all_gather_into_tensor on the process group the bench's collectives use"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +233,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    proof = collective_proof(torch, dist, rank, local, world, dev) if use_dist else None
+    if proof is not None:
+        assert proof["world_size"] == world and proof["distinct_devices"] == world and proof["ranks_in_order"], f"RCCL saw {proof}"
     workload = a.workload if a.workload != "auto" else "c2"
     weak = use_dist and workload in ("c2", "c5")          # N > 1: every rank its own block (weak scaling); else the two-stage deal of one set
 
@@ -458,6 +482,12 @@ def main():
         elt, rt, _, gt = run_weak(tb[3], tb[1], tb[2], 2, 1)
         if rank == 0:
             x = summarize(rt, [gt.slots * world], elt / 2, time_sliced=bool(gt.bp.last_time_sliced))
+            # the N = 1 in-run value of the same per-GPU work: this rank's 16 384 problems alone, no collective
+            sec1, o1 = time_group(gt, reps=2)
+            x1 = summarize([records(o1[0], gt.n)], [gt.slots], sec1, time_sliced=bool(gt.bp.last_time_sliced))
+            x.update({"one_gpu_block_ms_without_gather": sec1 * 1e3, "one_gpu_expansions_per_s": x1["expansions_per_s"], "one_gpu_plans_per_s": x1["plans_per_s"],
+                      "weak_scaling_efficiency_in_run": x["expansions_per_s"] / (world * x1["expansions_per_s"]) if x1["expansions_per_s"] else None,
+                      "one_gpu_note": "rank 0's own 16 384-problem block planned alone right after the timed steps (no gather): the per-GPU rate the %d-rank figure is to be held against" % world})
             x.update({"workload": tb[0], "scaling": "weak", "kernel_form": FORM_NAMES.get(gt.mode), "time_sliced": bool(gt.bp.last_time_sliced),
                       "note": "every rank plans its own 16 384 problems in one launch (long searches time-sliced), records + way-points gathered to rank 0 at the end of the step"})
             extra_dist["throughput"] = x
@@ -531,6 +561,8 @@ def main():
             "roofline": rl,
         }
         out.update(extra_dist)
+        if proof is not None:
+            out["collective"] = proof
         if "strong_scaling_4096" in extra_dist:
             # the strong-scaling point of the fixed 4 096 set beside the weak headline, at the top level (comparable with earlier rounds' multi-GPU lines)
             out["speedup_vs_1gpu"] = extra_dist["strong_scaling_4096"].get("speedup_vs_1gpu")
@@ -543,6 +575,7 @@ def main():
             gn = Group(g0.m, veh, wcfg, g0.starts, g0.goals, local, cap, mode=1, lookahead=False)
             sec, o0 = time_group(gn, reps=3)
             x0 = summarize([records(o0[0], g0.n)], [g0.slots], sec)
+            x0["lookahead"] = bool(gn.bp.last_lookahead)
             x0["identical_results"] = same_results(recs[0], outs[0][1].cpu().numpy(), records(o0[0], g0.n), o0[1].cpu().numpy())
             out["without_lookahead"] = x0
             del gn
@@ -563,6 +596,9 @@ def main():
                 xs = summarize([records(o[0], g.n) for o, g in zip(xo, xg)], [g.slots for g in xg], xe, time_sliced=any(g.bp.last_time_sliced for g in xg))
                 xs["workload"] = lab
                 xs["kernel_form"] = FORM_NAMES.get(xg[0].mode)
+                xs["lookahead"] = any(bool(g.bp.last_lookahead) for g in xg)
+                if len(xg) > 1:
+                    xs["lookahead_note"] = "%d launches on %d streams share the device: each one's helpers would hold compute units the others' problems wait for (measured 133 vs 83 ms), so the lookahead is off here" % (len(xg), len(xg))
                 out[name] = xs
                 del xg
             if not a.pmc_mode:
@@ -577,6 +613,7 @@ def main():
                     forms[mode] = summarize([r4], [g4.slots], sec, time_sliced=bool(g4.bp.last_time_sliced))
                     forms[mode]["kernel_form"] = FORM_NAMES[mode]
                     forms[mode]["time_sliced"] = bool(g4.bp.last_time_sliced)
+                    forms[mode]["lookahead"] = bool(g4.bp.last_lookahead)
                     if ref_rp is None:
                         ref_rp = (r4, p4)
                     else:
@@ -607,6 +644,7 @@ def main():
                     sec, o16 = time_group(g16, reps=1)
                     sat[key] = summarize([records(o16[0], g16.n)], [g16.slots], sec, time_sliced=bool(g16.bp.last_time_sliced))
                     sat[key]["time_sliced"] = bool(g16.bp.last_time_sliced)
+                    sat[key]["lookahead"] = bool(g16.bp.last_lookahead)
                     del g16
                 st32, go32 = np.concatenate([st16] * 2), np.concatenate([go16, np.roll(go16, 5, axis=0)])
                 for key, ts in (("wave_per_problem", None), ("wave_per_problem_unsliced", False)):
@@ -614,6 +652,7 @@ def main():
                     sec, o32 = time_group(g32, reps=1)
                     sat["n32768_" + key] = summarize([records(o32[0], g32.n)], [g32.slots], sec, time_sliced=bool(g32.bp.last_time_sliced))
                     sat["n32768_" + key]["time_sliced"] = bool(g32.bp.last_time_sliced)
+                    sat["n32768_" + key]["lookahead"] = bool(g32.bp.last_lookahead)
                     del g32
                 out["saturating_batch"] = sat
                 # ---- cap sensitivity: the headline set and config[4] at pop caps 300 / 1000 / 3000 -----------------------------
@@ -628,6 +667,8 @@ def main():
                         sec, os_ = time_group(gs, reps=1)
                         x = summarize([records(os_[0], gs.n)], [gs.slots], sec, time_sliced=bool(gs.bp.last_time_sliced))
                         sweep[wname][str(cap_s)] = {k: x[k] for k in ("plans_per_s", "expansions_per_s", "completed", "problems", "iter_limit_frac", "capacity_frac", "ms_per_step")}
+                        sweep[wname][str(cap_s)].update({"lookahead": bool(gs.bp.last_lookahead), "us_per_pop_of_the_longest_search": sec * 1e6 / max(int(records(os_[0], gs.n)["n_pops"].max()), 1),
+                                                         "kernel_form": FORM_NAMES.get(gs.mode), "max_nodes": gs.bp.max_nodes})
                         del gs
                 sweep["note"] = ("completed plans/s is a function of the cap only through the searches the cap stops: on Case1 a fifth of the random pairs never "
                                  "connects (the reference would not terminate); on config[4] most searches need thousands of pops")
@@ -642,7 +683,7 @@ def main():
                     sec, ok_ = time_group(gk, reps=1)
                     rk = records(ok_[0], 1)[0]
                     c20[f"Case{k}"] = {"status": path_planner.STATUS_NAMES.get(int(rk["status"]), int(rk["status"])), "pops": int(rk["n_pops"]),
-                                       "ms": sec * 1e3, "way_points": int(rk["n_final"]), "reference_s": REFERENCE_SECONDS.get(k)}
+                                       "ms": sec * 1e3, "way_points": int(rk["n_final"]), "reference_s": REFERENCE_SECONDS.get(k), "lookahead": bool(gk.bp.last_lookahead)}
                     del gk
                 tot = sum(v["ms"] for v in c20.values())
                 out["cases20"] = {"cases": c20, "total_ms_one_after_the_other": tot, "plans_per_s": 20.0 / (tot * 1e-3),

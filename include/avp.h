@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-#define AVP_VERSION 100
-#define AVP_MAX_STEER 16
+#define AVP_VERSION 110
+#define AVP_MAX_STEER 32                 /* steering angles: 2 x 32 = 64 children per expansion, one lane of a wave each */
+#define AVP_MAX_SUBS 512                 /* children x sub-steps checked per expansion (default: 10 x 3)             */
 #define AVP_RS_MAXSEG 5
 
 /* status codes of the library calls */
@@ -44,10 +45,13 @@ enum {
     AVP_PLAN_ITER_LIMIT = 4,    /* params.max_pops reached (the reference has no cap)           */
     AVP_PLAN_CAPACITY = 5,      /* node arena / path buffer / sweep queue exhausted             */
     AVP_PLAN_LATTICE = 6,       /* goal outside the map or goal-anchored lattice not regular     */
-    AVP_PLAN_BAD_POSE = 7       /* a start / goal coordinate that is not finite, a heading that is not finite or
-                                   beyond 1e6 rad: the reference never returns on an infinite heading (rs_curve.pi_2_pi's
-                                   subtract-2-pi loop, hybrid_a_star.py:72-124) and neither would the device -- refused before
-                                   the first loop; headings up to 1e6 rad are wrapped by that very loop, bit for bit */
+    AVP_PLAN_BAD_POSE = 7       /* a start / goal coordinate that is not finite, or a heading that is not finite or beyond
+                                   1e6 rad. NARROWER than the reference's domain: rs_curve.pi_2_pi's subtract-2-pi loop
+                                   (rs_curve.py:648-655, called from hybrid_a_star.py:72-124) does return on any finite
+                                   heading below ~1e16 rad (it stops terminating where theta - 2 pi == theta) -- after
+                                   |theta| / 2 pi trips: more than 1.6e5 beyond 1e6 rad, 1.6e8 at 1e9. The device runs that
+                                   very loop, bit for bit, for |theta| <= 1e6 and refuses the rest before its first loop
+                                   (tests/test_gpu_edge_inputs.py: 1e6 and its two neighbours against the oracle). */
 };
 
 /*
@@ -65,12 +69,14 @@ typedef struct avp_params {
     double circ_rd, circ_cf, circ_cr;
     /* hybrid A* (hybrid_a_star.py:81-83,145-151,188-194) */
     int32_t n_steer;
-    int32_t n_sub;                       /* ceil(dt / trajectory_dt)                                */
+    int32_t n_sub;                       /* ceil(dt / trajectory_dt); 2 * n_steer * n_sub <= AVP_MAX_SUBS */
     double steer[AVP_MAX_STEER];         /* np.linspace(-max_steer, max_steer, n)                   */
     double dth_dt[AVP_MAX_STEER];        /* (max_v*np.tan(steer))/lw*dt                             */
-    double dth_ddt[AVP_MAX_STEER][4];    /* (max_v*np.tan(steer))/lw*ddt*(j+1), j < n_sub <= 4      */
+    double dth_ddt1[AVP_MAX_STEER];      /* (max_v*np.tan(steer))/lw*ddt: sub-step j turns by dth_ddt1 * (j+1) -- the reference's
+                                            left-to-right product (hybrid_a_star.py:189-191), its last factor applied on the
+                                            device (an IEEE multiplication by an exact small integer), so n_sub is free        */
     double travel_dt;                    /* max_v*dt (sign applied per gear)                        */
-    double travel_ddt[4];                /* max_v*ddt*(j+1)                                         */
+    double travel_ddt1;                  /* max_v*ddt: sub-step j travels travel_ddt1 * (j+1) (:188) */
     double flag_radius;
     double cost_gear, cost_heading, cost_scale;
     double maxc;                         /* 1 / min_radius                                          */

@@ -67,8 +67,8 @@ typedef struct {
     /* config: config/config.yaml */
     double safe_side, safe_fr;
     int32_t n_steer;
-    double steer[16];        /* np.linspace(-max_steer, max_steer, n)  hybrid_a_star.py:81-83 */
-    double steer_tan[16];    /* np.tan(steer[i]) computed on the host in numpy                 */
+    double steer[64];        /* np.linspace(-max_steer, max_steer, n)  hybrid_a_star.py:81-83 (the reference takes any n; 64 here) */
+    double steer_tan[64];    /* np.tan(steer[i]) computed on the host in numpy                 */
     double dt, ddt, flag_radius;
     double cost_gear, cost_heading, cost_scale;
     int32_t extended_num;

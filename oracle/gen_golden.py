@@ -494,6 +494,9 @@ VARIANTS = {
     "dt08": {"dt": 0.8, "trajectory_dt": 0.2, "cost_gear": 3, "cost_heading_change": 1.5},
     "circle": {"collision_check": "circle"},
     "margins_rsall": {"flag_radius": 1e9, "safe_side_dis": 0.05, "safe_fr_dis": 0.2},
+    # round 6: motion-primitive sets beyond rounds 1 - 5's device limits (16 steering angles, 4 sub-steps)
+    "steer17": {"steering_angle_num": 17},                       # 34 children per expansion (hybrid_a_star.py:81-83,133)
+    "dt10_ddt02": {"dt": 1.0, "trajectory_dt": 0.2},             # ceil(dt / trajectory_dt) = 5 sub-steps (:185)
 }
 
 
@@ -609,8 +612,8 @@ if __name__ == "__main__":
         gen_hfield(tuple(int(a) for a in sys.argv[2:]) or (1, 4))
     elif what == "trace":
         gen_trace([int(a) for a in sys.argv[2:]])
-    elif what == "variants":
-        gen_variants(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+    elif what == "variants":           # variants <case> [name ...]
+        gen_variants(int(sys.argv[2]) if len(sys.argv) > 2 else 4, names=sys.argv[3:] or None)
     elif what == "random":
         gen_random(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0,
                    timeout=int(sys.argv[5]) if len(sys.argv) > 5 else 1200)

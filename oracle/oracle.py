@@ -26,7 +26,7 @@ class OrcCtx(C.Structure):
                 ("lw", C.c_double), ("lf", C.c_double), ("lr", C.c_double), ("lb", C.c_double),
                 ("max_v", C.c_double), ("max_steer", C.c_double), ("min_radius", C.c_double),
                 ("safe_side", C.c_double), ("safe_fr", C.c_double),
-                ("n_steer", C.c_int32), ("steer", C.c_double * 16), ("steer_tan", C.c_double * 16),
+                ("n_steer", C.c_int32), ("steer", C.c_double * 64), ("steer_tan", C.c_double * 64),
                 ("dt", C.c_double), ("ddt", C.c_double), ("flag_radius", C.c_double),
                 ("cost_gear", C.c_double), ("cost_heading", C.c_double), ("cost_scale", C.c_double),
                 ("extended_num", C.c_int32), ("checker_kind", C.c_int32), ("max_pops", C.c_int64)]
@@ -121,10 +121,20 @@ class device_arithmetic:
     def __enter__(self):
         self.b = exact_dijkstra_order()
         self.b.__enter__()
-        # a host whose libm is NOT the glibc 2.35 FMA build the device restates: compare against the restated mode (what
-        # the device implements by specification) instead of failing every parity test -- loudly
+        # A host whose libm is NOT the glibc 2.35 FMA build the device restates: comparing the device against the restated
+        # header it compiles would be self-referential -- a regression in the restatement would pass unnoticed. So that
+        # switch is OPT-IN (AVP_ORACLE_ALLOW_RESTATED_LIBM=1, and the report then says so); by default such a host raises,
+        # and the GPU parity tests show up as errors with the reason instead of as green.
         self.r = None
         if not platform_libm_is_the_restated_one():
+            if os.environ.get("AVP_ORACLE_ALLOW_RESTATED_LIBM", "0") != "1":
+                self.b.__exit__(None, None, None)
+                raise RuntimeError("oracle.device_arithmetic(): this host's libm is not the glibc 2.35 build the goldens were captured with, so "
+                                   "reference-libm parity cannot be verified here. Set AVP_ORACLE_ALLOW_RESTATED_LIBM=1 to compare against "
+                                   "the restated libm instead (a weaker, self-referential check).")
+            import warnings
+            warnings.warn("oracle.device_arithmetic(): AVP_ORACLE_ALLOW_RESTATED_LIBM=1 -- comparing against the RESTATED libm; "
+                          "reference-libm parity is NOT verified on this host")
             self.r = restated_libm()
             self.r.__enter__()
         return self

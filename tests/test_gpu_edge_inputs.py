@@ -52,9 +52,10 @@ def test_result_does_not_depend_on_the_batch_it_travels_in(vehicle, cfg, n):
 
 
 @pytest.mark.timeout(300)
-def test_poses_the_reference_never_returns_on_are_refused_not_hung(vehicle, cfg):
+def test_non_finite_poses_and_headings_beyond_1e6_rad_are_refused_not_hung(vehicle, cfg):
     """rs_curve.pi_2_pi is a subtract-2-pi loop: on an infinite heading the reference never returns (hybrid_a_star.__init__ wraps
-    the goal heading, :72-124), on 1e300 rad not in a lifetime. A device loop that does not end is a dead GPU, so the planner
+    the goal heading, :72-124), on 1e300 rad not in a lifetime (beyond ~1e16 rad theta - 2 pi == theta). Between 1e6 and ~1e16 rad the
+    reference DOES return, after |theta| / 2 pi trips: the cap at 1e6 is this library's choice, a narrower domain than the reference's. A device loop that does not end is a dead GPU, so the planner
     kernels refuse such poses before their first loop with AVP_PLAN_BAD_POSE (7): coordinates that are not finite (the
     BenchmarkCases' own run to 9e9 m), headings that are not finite or beyond 1e6 rad -- in every kernel form, other problems of the batch untouched. A
     goal that is finite but far outside the map is LATTICE (6) at once (the lattice walk used to take |g - b| / dx trips), a
@@ -88,3 +89,30 @@ def test_poses_the_reference_never_returns_on_are_refused_not_hung(vehicle, cfg)
     assert [int(v) for v in r["status"]] == [0, 7, 7]
     with pytest.raises(ValueError):
         rs_curve.calc_optimal_path(0.0, 0.0, float("inf"), 1.0, 1.0, 0.0, 0.2)
+
+
+@pytest.mark.timeout(300)
+def test_heading_cap_boundary_1e6_rad_vs_oracle(vehicle, cfg):
+    """The heading cap of pl_pose_ok, to the ulp: 1e6 rad and the double below it are planned -- pi_2_pi's subtract-2-pi loop
+    runs its 159 155 trips on the device exactly as in the reference (rs_curve.py:648-655), so the search equals the oracle's
+    on every observable field --, the double above 1e6 is AVP_PLAN_BAD_POSE (the reference would still plan it: the cap is this
+    library's, include/avp.h). Start and goal heading, both signs, every kernel form."""
+    import _parity
+    from automatedvaletparking_amd import _native, path_planner
+    from oracle import oracle
+    m = case_map_from_gold(1)
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=60)
+    c = m.case
+    below, at, above = float(np.nextafter(1e6, 0.0)), 1e6, float(np.nextafter(1e6, np.inf))
+    ok_s, ok_g = [c.x0, c.y0, c.theta0], [c.xf, c.yf, c.thetaf]
+    st = [[c.x0, c.y0, below], [c.x0, c.y0, at], [c.x0, c.y0, -at], ok_s, ok_s, [c.x0, c.y0, above], [c.x0, c.y0, -above], ok_s]
+    go = [ok_g, ok_g, ok_g, [c.xf, c.yf, at], [c.xf, c.yf, -below], ok_g, ok_g, [c.xf, c.yf, above]]
+    with oracle.device_arithmetic():
+        orc = oracle.Oracle(m, vehicle, cfg, max_pops=60)
+        want = [orc.plan(a, b, max_trace=60) for a, b in zip(st[:5], go[:5])]
+    for mode in (1, 2, 3, 4):
+        res = path_planner.BatchPlanner(dm, max_nodes=4096, mode=mode, n_slots=64 if mode > 1 else None).plan(st, go, max_trace=60)
+        assert [r.status for r in res[5:]] == [7, 7, 7], mode
+        for k, (r, w) in enumerate(zip(res[:5], want)):
+            d = _parity.observable_diff(r, w)
+            assert not d and r.counters["h_misses"] == w["n_dij_calls"], (mode, k, d)

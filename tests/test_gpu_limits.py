@@ -1,7 +1,8 @@
 """The limits the device planner has and the reference does not (include/avp.h): every one is a status code or a raised
 error, never a wrong answer, and each is shown here -- together with what still works on the same input and, for the one
-DATA-dependent limit, what the reference does (golden G11). Two limits of rounds 1 - 4 are gone and their tests are parity
-tests now: map_discrete_size below 0.088 m (a footprint wider than 64 map columns) and maps of more than 4 095 nodes per axis."""
+DATA-dependent limit, what the reference does (golden G11). The limits of rounds 1 - 5 that are gone are parity tests now:
+map_discrete_size below 0.088 m (a footprint wider than 64 map columns), maps of more than 4 095 nodes per axis, and (round 6)
+more than 16 steering angles / 4 sub-steps per motion primitive."""
 import os
 
 import numpy as np
@@ -19,47 +20,69 @@ def _plan_one(m, vehicle, cfg, **bp_kw):
     return path_planner.BatchPlanner(dm, max_nodes=4096, **bp_kw).plan([[c.x0, c.y0, c.theta0]], [[c.xf, c.yf, c.thetaf]])
 
 
-@pytest.mark.parametrize("over, what", [({"steering_angle_num": 17}, "steering_angle_num"),          # 34 children > 32 (hybrid_a_star.py:81-83 takes any)
-                                        ({"dt": 1.0, "trajectory_dt": 0.2}, "trajectory_dt")])        # 5 sub-steps > 4 (hybrid_a_star.py:185)
-def test_too_many_motion_primitives_is_an_error(over, what, vehicle, cfg):
-    """Refused where the parameter block is built (_native.make_params: ValueError); a C caller that fills avp_params
-    itself gets AVP_ERR_ARG "too many motion primitives" from avp_plan_batch (csrc/avp_capi_plan.inc)."""
-    import ctypes as C
-    from automatedvaletparking_amd import _native
+@pytest.mark.parametrize("over", [{"steering_angle_num": 17},                      # 34 children (hybrid_a_star.py:81-83,133 takes any number)
+                                  {"dt": 1.0, "trajectory_dt": 0.2},                  # 5 sub-steps (hybrid_a_star.py:185)
+                                  {"steering_angle_num": 32},                         # 64 children: every lane of the resolving wave
+                                  {"steering_angle_num": 9, "dt": 2.0, "trajectory_dt": 0.1},   # 18 children x 20 sub-steps = 360 poses per expansion
+                                  {"steering_angle_num": 6, "dt": 1.0, "trajectory_dt": 0.2},   # 12 children x 5 = 60 poses: what a group of waves still holds itself (64)
+                                  {"dt": 1.4, "trajectory_dt": 0.2}])                           # 10 children x 7 = 70 poses: a group hands it to the workgroup form
+def test_motion_primitive_sets_beyond_the_old_limits_plan_like_the_reference(over, vehicle, cfg):
+    """Until round 5 more than 16 steering angles or 4 sub-steps was an error. Now the workgroup form holds 64 children (32
+    steering angles) and any number of sub-steps up to 512 poses per expansion; the group forms hold 16 children / 64 sub-step
+    poses and hand anything larger to the workgroup form inside the same call -- so EVERY kernel form plans such a configuration,
+    with the same result. Case1's own problem and 12 random pairs against the pinned oracle, every observable field (the
+    reference itself on two of these sets: goldens g10_variant_steer17 / g10_variant_dt10_ddt02, tests/test_gpu_plan.py)."""
+    import _parity
+    from automatedvaletparking_amd import _native, path_planner
+    from oracle import oracle
+    m = case_map_from_gold(1)
     c2 = dict(cfg)
     c2.update(over)
-    with pytest.raises(ValueError, match=what):
-        _plan_one(case_map_from_gold(1), vehicle, c2)
-    # the C-ABI guard behind it: a parameter block edited after the Python check
+    cap = 40
+    dm = _native.DeviceMap(m, vehicle, c2, max_pops=cap)
+    st, go = _pairs(m, dm, 12, 5)
+    st = np.concatenate([st, [[m.case.x0, m.case.y0, m.case.theta0]]])
+    go = np.concatenate([go, [[m.case.xf, m.case.yf, m.case.thetaf]]])
+    o = oracle.Oracle(m, vehicle, c2, max_pops=cap)
+    for mode in (1, 2, 3, 4, path_planner.STAGED):
+        res = path_planner.BatchPlanner(dm, max_nodes=8192, mode=mode, n_slots=64 if mode in (2, 3, 4) else None).plan(st, go, max_trace=cap)
+        bad, _ = _parity.compare_pinned(o, res, st, go, cap)
+        assert not bad, (over, mode, bad[:3])
+
+
+def test_motion_primitive_limits_that_are_left(vehicle, cfg):
+    """What is still refused (the reference has no limit): more than 32 steering angles (a child is a lane of the resolving
+    wave) and more than 512 sub-step poses per expansion -- ValueError where the parameter block is built, AVP_ERR_ARG from the
+    C-ABI for a block edited behind it."""
+    import ctypes as C
+    from automatedvaletparking_amd import _native
+    for over in ({"steering_angle_num": 33}, {"steering_angle_num": 10, "dt": 2.6, "trajectory_dt": 0.1}):
+        c2 = dict(cfg)
+        c2.update(over)
+        with pytest.raises(ValueError, match="steering_angle_num"):
+            _plan_one(case_map_from_gold(1), vehicle, c2)
     m = case_map_from_gold(1)
     dm = _native.DeviceMap(m, vehicle, cfg)
     pk = dict(dm.pack)
-    p2 = _native.make_params(cfg, vehicle, 50)
-    if "steering_angle_num" in over:
-        p2.n_steer = 17
-    else:
-        p2.n_sub = 5
-    h = C.c_void_p()
-    bnd = np.ascontiguousarray(pk["boundary"], dtype=np.float64)
-    L = _native.lib()
-    rc = L.avp_map_create(C.byref(p2), pk["occ"].ctypes.data_as(C.c_void_p), C.c_int32(pk["nx"]), C.c_int32(pk["ny"]),
-                          pk["xs"].ctypes.data_as(C.c_void_p), pk["ys"].ctypes.data_as(C.c_void_p), bnd.ctypes.data_as(C.c_void_p),
-                          pk["obs_ix"].ctypes.data_as(C.c_void_p), pk["obs_iy"].ctypes.data_as(C.c_void_p), C.c_int32(len(pk["obs_ix"])), C.c_int32(0), C.byref(h))
-    if rc == 0:
-        st = dm.dev_tensor(np.array([[m.case.x0, m.case.y0, m.case.theta0]]))
-        ws = dm.empty(64 << 20, dm.torch.uint8)
-        res = dm.empty(4096, dm.torch.uint8)
-        rc2 = L.avp_plan_batch(h, C.c_void_p(st.data_ptr()), C.c_void_p(st.data_ptr()), C.c_int64(1), C.c_int32(1), C.c_int32(4096),
-                               C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()), None, 0, None, 0)
-        assert rc2 == -1 and "motion primitives" in _native.last_error()
-        L.avp_map_destroy(h)
-    else:
-        assert rc == -1                                   # (the map constructor may already refuse the block)
-    # the largest sets that are accepted: 16 steering angles (32 children: the workgroup form; the group forms hold 16
-    # children and hand such a configuration over), 4 sub-steps
-    ok = dict(cfg)
-    ok.update({"steering_angle_num": 16} if "steering_angle_num" in over else {"dt": 0.8, "trajectory_dt": 0.2})
-    assert _plan_one(case_map_from_gold(1), vehicle, ok)[0].status in (0, 4)
+    for field, val in (("n_steer", 33), ("n_sub", 60)):
+        p2 = _native.make_params(cfg, vehicle, 50)
+        setattr(p2, field, val)
+        h = C.c_void_p()
+        bnd = np.ascontiguousarray(pk["boundary"], dtype=np.float64)
+        L = _native.lib()
+        rc = L.avp_map_create(C.byref(p2), pk["occ"].ctypes.data_as(C.c_void_p), C.c_int32(pk["nx"]), C.c_int32(pk["ny"]),
+                              pk["xs"].ctypes.data_as(C.c_void_p), pk["ys"].ctypes.data_as(C.c_void_p), bnd.ctypes.data_as(C.c_void_p),
+                              pk["obs_ix"].ctypes.data_as(C.c_void_p), pk["obs_iy"].ctypes.data_as(C.c_void_p), C.c_int32(len(pk["obs_ix"])), C.c_int32(0), C.byref(h))
+        if rc == 0:
+            st = dm.dev_tensor(np.array([[m.case.x0, m.case.y0, m.case.theta0]]))
+            ws = dm.empty(64 << 20, dm.torch.uint8)
+            res = dm.empty(4096, dm.torch.uint8)
+            rc2 = L.avp_plan_batch(h, C.c_void_p(st.data_ptr()), C.c_void_p(st.data_ptr()), C.c_int64(1), C.c_int32(1), C.c_int32(4096),
+                                   C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(res.data_ptr()), None, 0, None, 0)
+            assert rc2 == -1 and "motion primitives" in _native.last_error()
+            L.avp_map_destroy(h)
+        else:
+            assert rc == -1                                   # (the map constructor may already refuse the block)
 
 
 def _pairs(m, dm, n, seed):

@@ -212,6 +212,8 @@ def test_random_pairs_other_maps_vs_oracle(k, vehicle, cfg):
 
 @pytest.mark.parametrize("over", [{"steering_angle_num": 3}, {"steering_angle_num": 7, "flag_radius": 6.0},
                                   {"steering_angle_num": 8},          # 16 children + the shot: two Reeds-Shepp passes per pop
+                                  {"steering_angle_num": 17},         # 34 children: four Reeds-Shepp passes per pop (round 6; rounds 1 - 5 refused it)
+                                  {"dt": 1.0, "trajectory_dt": 0.2},  # 5 sub-steps (round 6)
                                   {"dt": 0.8, "trajectory_dt": 0.2, "cost_gear": 3, "cost_heading_change": 1.5},
                                   {"flag_radius": 1e9, "safe_side_dis": 0.05, "safe_fr_dis": 0.2}])
 def test_config_variants_vs_oracle(over, vehicle, cfg):

@@ -94,11 +94,13 @@ def test_wave_form_auto_mode_and_slots(vehicle, cfg):
 
 @pytest.mark.parametrize("name", ["g6_trace_case1.npz", "g6_trace_case13.npz", "g6_trace_case5.npz", "g6_trace_case20.npz", "g8_synth_c5_plan0.npz",
                                   "g10_variant_circle_case4_0.npz", "g10_variant_steer7_r6_case4_1.npz", "g10_variant_dt08_case4_0.npz",
-                                  "g10_variant_margins_rsall_case4_2.npz"])
+                                  "g10_variant_margins_rsall_case4_2.npz", "g10_variant_steer17_case4_0.npz", "g10_variant_dt10_ddt02_case4_0.npz"])
 @pytest.mark.parametrize("form", FORMS)
 def test_wave_form_golden_problems(form, name, vehicle, cfg):
     """Single golden problems through the wave form (8 slots, 7 idle): long searches (Case13: 5 681 pops), NO_PATH
-    (Case20), the two-circle checker, 7 steering angles (14 children), other time steps, RS shot at every pop."""
+    (Case20), the two-circle checker, 7 steering angles (14 children), other time steps, RS shot at every pop; round 6: 5 sub-steps
+    (10 x 5 = 50 poses per expansion: a group holds 64) and 17 steering angles (34 children: more than a group's 16 -- such a
+    problem is handed to the workgroup form inside the same call)."""
     import json
     from automatedvaletparking_amd import path_planner, _native
     from oracle import oracle
