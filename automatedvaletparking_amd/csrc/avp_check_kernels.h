@@ -387,7 +387,7 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
 #define COR_QCAP 2048            // queue entries per wave
 #define COR_WAVES 6               // waves per workgroup, at most (the host launches as many as fit the LDS)
 #define COR_COLS 4                // map columns per broad-phase step (up to 3 bitmap words each: the AABB is grown by expand_dis)
-struct CorPose { double ac, as, expand; int32_t cs, pad; unsigned long long mn[4]; double pad2; };   // |cos|, |sin|, heading case, minima {x_max, y_max, x_min, y_min}; 9 doubles: an ODD record stride, like CHK_FPW
+struct CorPose { double ac, as, expand; int32_t cs, pad; unsigned long long mn[4]; double pad2; };   // |cos|, |sin|, heading case, per EDGE AREA the smallest point-line numerator |k x + b - y| seen (round 6; until round 5: the four minima themselves); 9 doubles: an ODD record stride, like CHK_FPW
 
 static inline size_t corridor_lds_bytes(const DevMap& m, bool stage, int waves)
 {
@@ -420,7 +420,6 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
         for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
         __syncthreads();
     }
-    const unsigned long long ebits = (unsigned long long)__double_as_longlong(expand);
     const int64_t tiles = (n + 63) / 64;
     const int nwaves = (int)(blockDim.x >> 6);
     for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < tiles; tile += (int64_t)gridDim.x * nwaves) {
@@ -454,7 +453,7 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
             double sth_, cth_;
             avp_sincos(theta, sth_, cth_);
             cp.ac = fabs(cth_); cp.as = fabs(sth_); cp.expand = expand; cp.cs = cs;
-            cp.mn[0] = cp.mn[1] = cp.mn[2] = cp.mn[3] = ebits;
+            cp.mn[0] = cp.mn[1] = cp.mn[2] = cp.mn[3] = 0x7ff0000000000000ull;      // +inf: no point in this area yet (inf / den / |cos| is inf or NaN: never below expand)
         }
         wave_sync();
         int ncol = ixhi - ixlo + 1;
@@ -468,12 +467,15 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
         for (int d = 32; d > 0; d >>= 1) maxword = max(maxword, __shfl_xor(maxword, d, 64));
         int qtail = 0;
 
-        // Narrow phase: one lane per candidate, the four running minima of a way-point as LDS atomicMin on the bit patterns.
-        // 42 % of the kernel's LDS cycles are same-address conflicts of those atomics (the queue is ordered by way-point: the
-        // 64 candidates of a trip mostly share their four words). Measured and dropped in round 4: a lane taking a RUN of
-        // consecutive entries with the minima in registers, one atomic per (lane, way-point) -- 4.19e8 way-points/s against
-        // 4.74e8 with the atomics (same box, same run): the conflicts are not what the phase waits for, the three divisions
-        // and the area tests of a candidate are, and a run serialises them per lane.
+        // Narrow phase: one lane per candidate. Until round 5 a candidate cost three IEEE divisions -- sd = |k x + b - y| / den,
+        // hor = sd / |sin|, ver = sd / |cos| (path_optimazition.py:266-280) -- and two LDS atomicMin on the way-point's four
+        // running minima (42 % of the kernel's LDS cycles were same-address conflicts of those atomics; round 4 measured that
+        // the divisions and the area tests, not the conflicts, are what the phase waits for). But den, |sin| and |cos| are
+        // constants of the (way-point, edge area), and a correctly rounded division by a fixed positive divisor is MONOTONE
+        // (a <= b => fl(a / d) <= fl(b / d), also for d = inf or 0: every result that is not smaller is inf or NaN, which the
+        // reference's "<" scan never takes either), so the smallest hor / ver of an edge area are the images of the smallest
+        // numerator: the phase keeps ONE running minimum per (way-point, area) on the numerators' bit patterns (>= +0, NaN never
+        // wins) and the three divisions run once per (way-point, area) at the end of the tile, on full waves.
         auto drain = [&]() {
             wave_sync();
             for (int base = 0; base < qtail; base += 64) {
@@ -500,14 +502,11 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
                     if (hitk >= 0) {
                         const double fk = hitk == 0 ? f.k[0] : hitk == 1 ? f.k[1] : hitk == 2 ? f.k[2] : f.k[3];
                         const double fb = hitk == 0 ? f.b[0] : hitk == 1 ? f.b[1] : hitk == 2 ? f.b[2] : f.b[3];
-                        const double fd = hitk == 0 ? f.den[0] : hitk == 1 ? f.den[1] : hitk == 2 ? f.den[2] : f.den[3];
-                        const double sd = fabs(fk * ox + fb - oy) / fd;
-                        const double ver = sd / cp.ac, hor = sd / cp.as;
-                        // "if (v < cur) cur = v" over non-negative doubles and NaN == atomicMin on the bit patterns, except
-                        // that a NaN with a clear sign bit is excluded explicitly (it never compares less)
-                        if (hor == hor) atomicMin(&cp.mn[xpos ? 0 : 2], (unsigned long long)__double_as_longlong(hor));
-                        if (ver == ver) atomicMin(&cp.mn[ypos ? 1 : 3], (unsigned long long)__double_as_longlong(ver));
+                        const double num = fabs(fk * ox + fb - oy);
+                        // (a NaN numerator -- an axis-aligned edge: inf - inf -- gives NaN distances, which never compare less: skipped)
+                        if (num == num) atomicMin(&cp.mn[hitk], (unsigned long long)__double_as_longlong(num));
                     }
+                    (void)xpos; (void)ypos;
                 }
             }
             qtail = 0;
@@ -577,9 +576,20 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
         }
         drain();
         if (valid) {
+            // the scan's updates (:266-280) in area order on the areas' smallest numerators: x_max / x_min take hor, y_max / y_min ver
             const CorPose& cp = sPose[lane];
-            out[4 * i] = __longlong_as_double((long long)cp.mn[0]) + px; out[4 * i + 1] = __longlong_as_double((long long)cp.mn[1]) + py;
-            out[4 * i + 2] = px - __longlong_as_double((long long)cp.mn[2]); out[4 * i + 3] = py - __longlong_as_double((long long)cp.mn[3]);
+            const Footprint& f = *(const Footprint*)(sFp + (size_t)lane * CHK_FPW);
+            double x_max = expand, y_max = expand, x_min = expand, y_min = expand;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int quad = (kk + cp.cs - 1) & 3;
+                const bool xp = quad == 0 || quad == 1, yp = quad == 1 || quad == 2;
+                const double sd = __longlong_as_double((long long)cp.mn[kk]) / f.den[kk];
+                const double ver = sd / cp.ac, hor = sd / cp.as;
+                if (xp) { if (hor < x_max) x_max = hor; } else { if (hor < x_min) x_min = hor; }
+                if (yp) { if (ver < y_max) y_max = ver; } else { if (ver < y_min) y_min = ver; }
+            }
+            out[4 * i] = x_max + px; out[4 * i + 1] = y_max + py; out[4 * i + 2] = px - x_min; out[4 * i + 3] = py - y_min;
         }
         wave_sync();
     }

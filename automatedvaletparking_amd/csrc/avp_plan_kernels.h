@@ -180,7 +180,8 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 #define PL_LOOK_TOP 16                // heap slots an owner posts per pop
 #endif
 #ifndef PL_LOOK_SLEEP
-#define PL_LOOK_SLEEP 64                // s_sleep argument of a helper waiting for its job (x 64 cycles; 16 .. 127 measured alike)
+#define PL_LOOK_SLEEP 8                 // s_sleep argument of a helper waiting for its job (x 64 cycles). Rounds 2 - 5: 64 (16 .. 127 measured alike); with predicted
+                                        // children in the rings a record's lead is ~2 pops and the half a sleep a job waits for its helper shows: 8 measures 0.5 % faster
 #endif
 #define PL_LOOK_HRS (pl_al((size_t)PL_RS_CAP * 3 * 8) + pl_al((size_t)PL_RS_CAP))   // sample scratch of a helper-only workgroup
 #ifndef PL_LOOK_KSPAN
@@ -200,7 +201,7 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 #define PL_LOOK_LATE 1                // a long pop adopts its node's record when that lands while the pop is under way (pl_look_late)
 #endif
 #ifndef PL_LOOK_WAIT
-#define PL_LOOK_WAIT 10000            // cycles an owner waits for a record that is posted but not finished (0 / 10 k / 20 k: 21.4 / 20.7 / 20.7 ms)
+#define PL_LOOK_WAIT 15000            // cycles an owner waits for a record that is posted but not finished (round 3: 0 / 10 k / 20 k: 21.4 / 20.7 / 20.7 ms; round 6, with predicted children: 10 k / 15 k / 20 k within 0.5 %)
 #endif
 struct PlLook {
     unsigned long long* ctrl;         // ring r (0: children halves, 1: shot halves): [64 r] tail, [64 r + 16] head; [32] problems finished,
@@ -245,9 +246,8 @@ static inline __host__ __device__ size_t pl_look_bytes(int32_t helper_blocks)
     return 1024 + 2 * (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_look_state_bytes() +
            (size_t)PL_LOOK_ENTRIES * PL_REC_WORDS * 8 + (size_t)helper_blocks * PL_LOOK_HRS;
 }
-#define PL_LOOK_NODE_MAX (1 << 24)     // tag fields: node 24 bits, problem 16 bits, slot 8 bits
-#define PL_LOOK_PID_MAX (1 << 16)
-__device__ __forceinline__ unsigned long long pl_look_tag(int64_t pid, int64_t node, int slot) { return (unsigned long long)node | ((unsigned long long)pid << 24) | ((unsigned long long)slot << 40); }
+#define PL_LOOK_NODE_MAX (1 << 30)     // (records are named by pose, not by arena index: no limit of their own)
+#define PL_LOOK_PID_MAX (1 << 30)
 __device__ __forceinline__ size_t pl_look_ent(const PlLook& look, unsigned long long tag)
 {
     unsigned long long z = tag * 0x9E3779B97F4A7C15ULL;
@@ -255,9 +255,6 @@ __device__ __forceinline__ size_t pl_look_ent(const PlLook& look, unsigned long 
     return (size_t)(z & (unsigned long long)look.emask);
 }
 #define PL_JOB_TAG(w0) ((w0) & 0xffffffffffffull)
-#define PL_JOB_NODE(w0) ((uint32_t)((w0) & 0xffffffull))
-#define PL_JOB_PID(w0) ((int64_t)(((w0) >> 24) & 0xffffull))
-#define PL_JOB_SLOT(w0) ((int)(((w0) >> 40) & 255ull))
 // agent-scope relaxed accesses (sc1): payload stores, s_waitcnt vmcnt(0), flag store on the producer side; flag load,
 // then payload loads on the consumer side -- the "sc1 payload -> drained -> sc1 flag" hand-off of MI355X_MICROARCH.md
 // (every access of both sides bypasses the non-coherent L1). PL_LOOK_ATOMICS = 1 builds the same protocol from
@@ -502,7 +499,7 @@ struct PlShared {
     uint32_t chk_hit[PL_MAXSUBS];   // hit flag per sub-step pose of the current pop
     int32_t next_cur, have_next;      // node popped ahead by wave 0 at the end of its resolution (see pl_resolve_fast_wave)
     // expansion lookahead
-    unsigned long long recb[2][PL_REC_WORDS];   // records (owner): [rec_cur] = the popped node's, the other = the prefetch target
+    unsigned long long recb[3][PL_REC_WORDS];   // records (owner): [rec_cur] (0 / 1) = the popped node's, the other of the two = the prefetch target; [2] = the open list's second-best node's (pl_look_second)
     int32_t fetch_go, fetch_nheap;              // pop-ahead -> record fetch hand-over (see pl_resolve_fast_wave)
     int32_t wr_go, wr_done;                     // classification -> writer wave hand-over
     int32_t nf_node, nf_found[16]; int8_t nf_state[16];   // the popped-ahead node's children: pose-hash look-ups done by the fetching wave
@@ -1674,12 +1671,13 @@ AVP_D void pl_resolve_fast_wave(const DevMap& m, const avp_params& p, const Plan
         // another wave fetches its expansion record (and waits for a pending one) while this wave walks the heap.
         // (lanes 1 and 2 read the root's children in the same instruction: the smaller key is the list's second best, which the
         //  lookahead's dive prediction compares a child's cost with, pl_look_predict)
-        const PlHeapEnt top3 = pl_heap_get(w, s, (S::LOOK_SECOND && lane < 3 && lane < nheap) ? lane : 0);
-        const uint32_t root = (uint32_t)__builtin_amdgcn_readfirstlane((int)top3.node);
+        uint32_t root;
         if constexpr (S::LOOK_SECOND) {
+            const PlHeapEnt top3 = pl_heap_get(w, s, (lane < 3 && lane < nheap) ? lane : 0);
+            root = (uint32_t)__builtin_amdgcn_readfirstlane((int)top3.node);
             const double k1 = pl_readlane_f64(top3.f, 1), k2 = pl_readlane_f64(top3.f, 2);
             if (lane == 0) s.fetch_second = nheap < 2 ? INFINITY : (nheap < 3 || k1 < k2) ? k1 : k2;
-        }
+        } else root = pl_heap_get(w, s, 0).node;          // (the group forms: exactly the code of rounds 3 - 5)
         if (lane == 0) {
             s.next_cur = (int32_t)root; s.have_next = 1; s.fetch_nheap = nheap - 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1803,7 +1801,16 @@ AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const dou
             else { for (int k = 0; k < PH_COUNT; k++) r.phase_cycles[k] = 0; }
 }
 
-// ---- the record store: state words ---------------------------------------------------------------------------------------
+// ---- the record store: tags and state words ------------------------------------------------------------------------------
+// A record is named by the POSE it expands (and the problem): tag = 48 bits of the pose hash mixed with the problem index. So a
+// node that does not exist yet -- a child somebody expects the search to pop soon -- has the same name as the arena node it
+// will be, whoever posts it: the owner from the parent's record, or a HELPER from the children it has just computed (it knows no
+// arena index). Two poses that share a tag share an entry: the second post is skipped, the record's key words (exact pose bits)
+// turn a wrong reader down.
+__device__ __forceinline__ unsigned long long pl_look_tag(int64_t pid, double x, double y, double th)
+{
+    return (pl_pose_hash(x, y, th) ^ ((unsigned long long)(pid + 1) * 0xD1B54A32D192ED03ULL)) >> 16;
+}
 #define PL_ST_TAG(st) ((st) >> 8)
 #define PL_ST_POSTED(st) (((st) & 1ull) != 0ull)
 #define PL_ST_READY(st) (((st) & 6ull) == 6ull)
@@ -1813,8 +1820,19 @@ AVP_D void pl_write_result(const avp_params& p, const PlanWs& w, S& s, const dou
 #ifndef PL_LOOK_PREDICT_FETCH
 #define PL_LOOK_PREDICT_FETCH 0       // ... also from a record that only arrives with the fetch at the end of the pop before (one pop of lead instead of two): measured 18.3 vs 18.0 ms -- those jobs come too late and load the helpers
 #endif
-// Owner (one lane per tag): take the tag's entry for a new pair of jobs. True = this lane posts them. False: the tag has its
-// jobs already (in flight or done), or the entry is busy with another tag's jobs in flight (*busy counts those).
+#ifndef PL_LOOK_SECOND
+#define PL_LOOK_SECOND 1              // ... and from the record of the open list's SECOND-best node (one more pop of lead, pl_look_second)
+#endif
+#ifndef PL_LOOK_CHAIN
+#define PL_LOOK_CHAIN 2               // a helper that has computed a predicted child's children posts the next level of the dive itself, this many levels deep (<= 3)
+#endif
+// job word 0: tag | owner's workgroup << 48 | gear of the node << 60 | chain depth << 61
+#define PL_JOB_W0(tag, blk, gear, depth) ((tag) | ((unsigned long long)(blk) << 48) | ((unsigned long long)((gear) ? 1 : 0) << 60) | ((unsigned long long)(depth) << 61))
+#define PL_JOB_BLOCK(w0) ((int)(((w0) >> 48) & 0xfffull))
+#define PL_JOB_GEAR(w0) ((int)(((w0) >> 60) & 1ull))
+#define PL_JOB_DEPTH(w0) ((int)(((w0) >> 61) & 3ull))
+// Owner or helper (one lane per tag): take the tag's entry for a new pair of jobs. True = this lane posts them. False: the tag
+// has its jobs already (in flight or done), or the entry is busy with another tag's jobs in flight (*busy counts those).
 __device__ __forceinline__ bool pl_look_claim(const PlLook& look, unsigned long long tag, int32_t* busy)
 {
     unsigned long long* q = look.state + pl_look_ent(look, tag);
@@ -1848,36 +1866,26 @@ __device__ __forceinline__ int pl_look_copy(const PlLook& look, const PlanWs& w,
            !(r_in && (r_err || !r_hit));
 }
 // Owner side of the lookahead (one wave): the expansion record of `node`, if both halves are finished, is copied to
-// s.recb[buf]; returns whether it is there and valid (pl_look_copy). A node without jobs of its own is looked up under its
-// parent (slot 1 + child index). Consumer order: state word, payload, state word.
+// s.recb[buf]; returns whether it is there and valid (pl_look_copy). Consumer order: state word, payload, state word.
 template <class S>
 __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int32_t node, int lane, int buf, bool wait)
 {
     int ok = 0;
     if (node >= 0) {
-        unsigned long long tag = 0, st = 0;
+        unsigned long long st = 0;
         size_t ri = 0;
         if (lane == 0) {
-            tag = pl_look_tag(pid, node, 0);
+            const PlNode& nn = w.nodes[node];
+            const unsigned long long tag = pl_look_tag(pid, nn.x, nn.y, nn.th);
             ri = pl_look_ent(look, tag);
             st = PL_FLAG_LD64(look.state + ri);
-            bool mine = PL_ST_TAG(st) == tag && PL_ST_POSTED(st);
-            if (!mine) {
-                const PlNode& nn = w.nodes[node];
-                if (nn.parent_pos >= 0 && nn.steer_i >= 0) {
-                    tag = pl_look_tag(pid, nn.parent_pos, 1 + (nn.forward ? 0 : s.kp.n_steer) + nn.steer_i);
-                    ri = pl_look_ent(look, tag);
-                    st = PL_FLAG_LD64(look.state + ri);
-                    mine = PL_ST_TAG(st) == tag && PL_ST_POSTED(st);
-                    s.n_sec[!mine ? 0 : PL_ST_READY(st) ? 2 : 1] += 1;
-                }
-            }
-            if (!mine) st = 0ull;
+            if (!(PL_ST_TAG(st) == tag && PL_ST_POSTED(st))) st = 0ull;
+            if (wait) atomicAdd(&s.n_sec[st == 0ull ? 0 : PL_ST_READY(st) ? 2 : 1], 1);      // (diagnostics: the next pop's node was not posted / pending / ready)
             if (PL_LOOK_WAIT > 0 && wait && s.look_calm && st != 0ull && !PL_ST_READY(st)) {
                 // (an entry whose jobs are in flight is nobody else's to claim: the tag stays while we wait)
                 const long long t0 = clock64();
                 while (!PL_ST_READY(st) && clock64() - t0 < PL_LOOK_WAIT) { __builtin_amdgcn_s_sleep(4); st = PL_FLAG_LD64(look.state + ri); }
-                s.n_sec[3] += 1;
+                atomicAdd(&s.n_sec[3], 1);
             }
             // (the next pop's own look-up: a record that is posted but not finished is polled again while that pop goes the long way)
             if (PL_LOOK_LATE && wait) { s.poll_ri = (unsigned long long)ri; s.poll_tag = tag; s.poll_on = (st != 0ull && !PL_ST_READY(st)) ? 1 : 0; }
@@ -1890,7 +1898,9 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
 }
 
 // One wave posts the jobs of its lanes that `want` one to BOTH rings (children half, shot half): one ticket range per ring.
-__device__ __forceinline__ void pl_ring_post2(const PlLook& look, int lane, bool want, unsigned long long w0, double x, double y, double th, const double* goal)
+// Job words: w0 (PL_JOB_W0), pose, thr = the cost below which a child of this node would be the open list's next root
+// (chained prediction, pl_look_chain; +inf for a job that is not part of a predicted dive), the problem.
+__device__ __forceinline__ void pl_ring_post2(const PlLook& look, int lane, bool want, unsigned long long w0, double x, double y, double th, double thr, int64_t pid)
 {
     const unsigned long long mask = __ballot(want);
     if (!mask) return;
@@ -1901,25 +1911,41 @@ __device__ __forceinline__ void pl_ring_post2(const PlLook& look, int lane, bool
         const unsigned long long k = (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
         unsigned long long* e0 = look.jobs + ((size_t)((t0 + k) & (PL_JCAP - 1))) * PL_JOB_WORDS;
         unsigned long long* e1 = look.jobs + ((size_t)PL_JCAP + (size_t)((t1 + k) & (PL_JCAP - 1))) * PL_JOB_WORDS;
-        const unsigned long long bx = pl_bits(x), by = pl_bits(y), bt = pl_bits(th), g0 = pl_bits(goal[0]), g1 = pl_bits(goal[1]), g2 = pl_bits(goal[2]);
-        pl_st64(e0 + 0, w0); pl_st64(e0 + 1, bx); pl_st64(e0 + 2, by); pl_st64(e0 + 3, bt); pl_st64(e0 + 4, g0); pl_st64(e0 + 5, g1); pl_st64(e0 + 6, g2);
-        pl_st64(e1 + 0, w0); pl_st64(e1 + 1, bx); pl_st64(e1 + 2, by); pl_st64(e1 + 3, bt); pl_st64(e1 + 4, g0); pl_st64(e1 + 5, g1); pl_st64(e1 + 6, g2);
+        const unsigned long long bx = pl_bits(x), by = pl_bits(y), bt = pl_bits(th), b4 = pl_bits(thr), b5 = (unsigned long long)pid;
+        pl_st64(e0 + 0, w0); pl_st64(e0 + 1, bx); pl_st64(e0 + 2, by); pl_st64(e0 + 3, bt); pl_st64(e0 + 4, b4); pl_st64(e0 + 5, b5); pl_st64(e0 + 6, 0ull);
+        pl_st64(e1 + 0, w0); pl_st64(e1 + 1, bx); pl_st64(e1 + 2, by); pl_st64(e1 + 3, bt); pl_st64(e1 + 4, b4); pl_st64(e1 + 5, b5); pl_st64(e1 + 6, 0ull);
         PL_LOOK_DRAIN();
         PL_FLAG_ST64(e0 + 7, t0 + k + 1ull);
         PL_FLAG_ST64(e1 + 7, t1 + k + 1ull);
     }
 }
 
+// Among the lanes' candidate costs (key = bit pattern of a cost >= +0, ~0 = no candidate): the cheapest (the first in lane
+// order among equals: child order), and the second-cheapest cost. Uniform results.
+__device__ __forceinline__ void pl_look_best2(unsigned long long key, int lane, unsigned long long& mn, int& best, unsigned long long& mn2)
+{
+    mn = key;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_xor(mn, d, 64); if (o < mn) mn = o; }
+    best = mn == ~0ull ? -1 : __ffsll((unsigned long long)__ballot(key == mn)) - 1;
+    mn2 = lane == best ? ~0ull : key;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_xor(mn2, d, 64); if (o < mn2) mn2 = o; }
+}
+
 // Dive prediction (round 6; one wave, with the validated record of `node` in s.recb[buf]). A quarter of all pops expand a child
 // of the node popped just before; until round 5 such a child had a record only if its parent's pop took the long way (which
 // posts three likely children) -- three quarters of the long pops that were left were dives below RECORD pops. But a parent's
 // record already names its children: poses, first colliding sub-step, Reeds-Shepp length. So as soon as the owner holds the
-// record of the node on top of its open list (prefetched during the pop before: two pops of lead; or fetched at the end of the pop
-// before: one) it costs the children as expand_node will (g from calc_node_cost, h = max(field distance / 100, RS length):
-// hybrid_a_star.py:243-283) and, when the cheapest new child would be the list's next root -- its f below the list's
-// second-best key --, posts THAT child through its parent (slot 1 + child index). A guess: children equal to existing nodes,
-// queries that would miss the closed frontier and the children of the pop in progress are ignored; a wrong guess is a wasted
-// job, a right one turns the dive's long pop (~70 k cycles) into a record pop (~26 k).
+// record of the node on top of its open list (prefetched during the pop before: two pops of lead) -- or of the list's second-best
+// node (three) -- it costs the children as expand_node will (g from calc_node_cost, h = max(field distance / 100, RS length):
+// hybrid_a_star.py:243-283) and, when the cheapest new child would be the list's next root -- its f below `second_f`, the
+// cheapest key that will be left --, posts THAT child, named by its pose. The job carries the cost its own children have to
+// beat (the smaller of second_f and this node's second-cheapest child) and a depth: the helper that computes the child's
+// children applies the same rule and posts the next level itself (pl_look_chain) -- a dive of several levels is served at the
+// helpers' pace instead of one long pop per level. A guess: children equal to existing nodes, queries that would miss the closed
+// frontier and the children of the pop in progress are ignored; a wrong guess is a wasted job, a right one turns the dive's
+// long pop (~70 k cycles) into a record pop (~26 k).
 template <class S>
 __device__ __forceinline__ void pl_look_predict(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int lane, int32_t node, int buf, double second_f)
 {
@@ -1947,24 +1973,22 @@ __device__ __forceinline__ void pl_look_predict(const PlLook& look, const PlanWs
             f = pl_node_cost(p, lane < p.n_steer ? 1 : 0, cth, tth, tfw) + (L > hv1 ? L : hv1);
         }
     }
-    // the smallest f (costs are >= +0: the bit patterns order like the values), the first in child order among equals
-    const unsigned long long key = valid ? pl_bits(f) : ~0ull;
-    unsigned long long mn = key;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_xor(mn, d, 64); if (o < mn) mn = o; }
-    if (mn == ~0ull) return;
-    if (!(pl_unbits(mn) < second_f)) return;                 // (uniform) another open node would be popped before it
-    const int best = __ffsll((unsigned long long)__ballot(key == mn)) - 1;
+    unsigned long long mn, mn2;
+    int best;
+    pl_look_best2(valid ? pl_bits(f) : ~0ull, lane, mn, best, mn2);
+    if (best < 0 || !(pl_unbits(mn) < second_f)) return;     // (uniform) no candidate / another open node would be popped before it
+    const double f2 = mn2 == ~0ull ? INFINITY : pl_unbits(mn2);
     bool want = false;
     unsigned long long w0 = 0;
     if (lane == best) {
-        w0 = pl_look_tag(pid, node, 1 + best);
+        const unsigned long long tag = pl_look_tag(pid, cx, cy, cth);
         int32_t busy = 0;
-        want = pl_look_claim(look, w0, &busy);
+        want = pl_look_claim(look, tag, &busy);
         if (busy) atomicAdd(&s.n_busy, busy);
         if (want) atomicAdd(&s.n_pred, 1);
+        w0 = PL_JOB_W0(tag, blockIdx.x, best < p.n_steer, PL_LOOK_CHAIN);
     }
-    pl_ring_post2(look, lane, want, w0, cx, cy, cth, s.goal);
+    pl_ring_post2(look, lane, want, w0, cx, cy, cth, f2 < second_f ? f2 : second_f, pid);
 }
 
 // The record of the node the next pop expands (wave 0, once that node is known): the prefetched one if it is that node's,
@@ -1978,7 +2002,7 @@ __device__ __forceinline__ void pl_look_fetch(const PlLook& look, const PlanWs& 
     bool fresh = false;
     if (PL_LOOK_LATE && lane == 0) { s.poll_on = 0; s.late_rec = 0; s.late_rec2 = 0; }
     if (s.look_live && s.status == 0 && nheap_after >= 1 && node >= 0) {       // (no helper yet: no record to look for)
-        if (node == s.pre_node && s.pre_ok) ok = 1;
+        if (node == s.pre_node && s.pre_ok) { ok = 1; if (lane == 0) atomicAdd(&s.n_sec[2], 1); }
         else { ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, s.rec_cur ^ 1, true); fresh = true; }
     }
     wave_sync();
@@ -2026,6 +2050,71 @@ __device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanW
     if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
     if (PL_LOOK_PREDICT && ok && s.look_calm) pl_look_predict(look, w, s, pid, lane, node, s.rec_cur ^ 1, second_f);
 }
+// ... and one more pop ahead: the open list's SECOND-best node (the smaller of the root's two children; the other one's key is
+// what ITS cheapest child has to beat). Its record, if there, goes to the third record buffer and is looked at for a dive only.
+template <class S>
+__device__ __forceinline__ int32_t pl_look_second_node(const PlanWs& w, S& s, double& thr)       // (reads the heap: while nobody changes it)
+{
+    int32_t node = -1;
+    thr = INFINITY;
+    if (PL_LOOK_SECOND && s.look_live && s.look_calm && s.nheap >= 3) {
+        const PlHeapEnt e1 = pl_heap_get(w, s, 1), e2 = pl_heap_get(w, s, 2);
+        if (e2.f < e1.f) { node = (int32_t)e2.node; thr = e1.f; } else { node = (int32_t)e1.node; thr = e2.f; }
+    }
+    return node;
+}
+template <class S>
+__device__ __forceinline__ void pl_look_second(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane, int32_t node, double thr)
+{
+    if (node < 0) return;
+    const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, 2, false);
+    if (ok && s.look_calm) pl_look_predict(look, w, s, pid, lane, node, 2, thr);
+}
+
+// Helper side of a predicted dive (one wave of a children-half helper whose job carries a chain depth; the children of the job's
+// node are in s.child[]: poses, first colliding sub-step, Reeds-Shepp length). The same rule as pl_look_predict with what a helper
+// can see: the owner's distance field through its workspace slot (agent-scope loads; whether a query would hit the closed frontier is the
+// owner's knowledge -- any distance the sweep has reached counts), the cost `thr` a child has to beat from the job. Posts the
+// cheapest such child with the depth counted down.
+__device__ __forceinline__ void pl_look_chain(const PlLook& look, PlShared& s, const uint32_t* owner_dist, int lane, double nth, int ngear, double thr, int depth, int owner_block, int64_t pid)
+{
+    const DevMap& m = s.km;
+    const avp_params& p = s.kp;
+    const int nchild = 2 * p.n_steer;
+    // ring counters: only while the helpers keep up (as the owner's posting rounds)
+    unsigned long long c = 0;
+    if (lane < 4) c = pl_ld64(look.ctrl + (lane == 0 ? 0 : lane == 1 ? 16 : lane == 2 ? 64 : 80));
+    const long long backlog = max((long long)(__shfl(c, 0, 64) - __shfl(c, 1, 64)), (long long)(__shfl(c, 2, 64) - __shfl(c, 3, 64)));
+    if (backlog > PL_LOOK_BACKLOG) return;
+    bool valid = lane < nchild;
+    double f = 0.0, cx = 0.0, cy = 0.0, cth = 0.0;
+    if (valid) {
+        const PlChild& ch = s.child[lane];
+        cx = ch.x; cy = ch.y; cth = ch.th;
+        valid = !ch.oob && ch.first_coll == 0x7fffffff && !ch.rs_err && pl_id_in_range(m, ch.id);
+        if (valid) {
+            const uint32_t d = pl_ld32(owner_dist + ch.id);
+            valid = d != PL_UNSEEN;
+            const double hv1 = (double)d / 100;
+            f = pl_node_cost(p, lane < p.n_steer ? 1 : 0, cth, nth, ngear) + (ch.L > hv1 ? ch.L : hv1);
+        }
+    }
+    unsigned long long mn, mn2;
+    int best;
+    pl_look_best2(valid ? pl_bits(f) : ~0ull, lane, mn, best, mn2);
+    if (best < 0 || !(pl_unbits(mn) < thr)) return;
+    const double f2 = mn2 == ~0ull ? INFINITY : pl_unbits(mn2);
+    bool want = false;
+    unsigned long long w0 = 0;
+    if (lane == best) {
+        const unsigned long long tag = pl_look_tag(pid, cx, cy, cth);
+        int32_t busy = 0;
+        want = pl_look_claim(look, tag, &busy);
+        if (want) atomicAdd(look.ctrl + 71, 1ull);           // ([71]: children posted by helpers)
+        w0 = PL_JOB_W0(tag, owner_block, best < p.n_steer, depth - 1);
+    }
+    pl_ring_post2(look, lane, want, w0, cx, cy, cth, f2 < thr ? f2 : thr, pid);
+}
 
 // Owner side of the lookahead: one wave posts, in ONE round (one look at the ring counters, one ticket range per ring,
 // one drain of the payload stores),
@@ -2051,39 +2140,40 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     unsigned long long c = 0;
     if (lane < 5) c = pl_ld64(look.ctrl + (lane == 0 ? 48 : lane == 1 ? 0 : lane == 2 ? 16 : lane == 3 ? 64 : 80));
     const int d = lane - 32 - PL_LOOK_KSPAN, sc = (int)cn.steer_i + d;
-    const bool kid = kids && lane >= 32 && lane < 32 + PL_LOOK_KIDS && cn.steer_i >= 0 && sc >= 0 && sc < p.n_steer;
+    bool kid = kids && lane >= 32 && lane < 32 + PL_LOOK_KIDS && cn.steer_i >= 0 && sc >= 0 && sc < p.n_steer;
     const bool cand = lane < 32 && node != 0xffffffffu;
     const unsigned long long helpers = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
     const long long backlog = max((long long)(ta - ha), (long long)(tb - hb));
     if (lane == 0) { s.look_calm = (helpers != 0 && backlog <= PL_LOOK_BACKLOG) ? 1 : 0; s.look_live = helpers != 0 ? 1 : 0; }   // (calm: the helpers keep up, a pending record is worth a short wait)
-    // nobody to serve / a ring is nearly full: every owner may post up to PL_LOOK_TOP + PL_LOOK_KIDS + 1 jobs from the same (stale)
-    // reading of the counters, so the margin is several times owners x jobs (512 x 20 = 10 240) -- an unread entry is never overwritten
+    // nobody to serve / a ring is nearly full: every owner may post up to PL_LOOK_TOP + PL_LOOK_KIDS + 2 jobs from the same (stale)
+    // reading of the counters, so the margin is several times owners x jobs (512 x 21 = 10 752) -- an unread entry is never overwritten
     if (helpers == 0 || backlog > PL_JCAP - 16384) return;
-    // does the tag have its jobs already? else claim its entry (the children of the node being expanded: slot 1 + child index)
+    if (backlog > PL_LOOK_BACKLOG) kid = false;
+    // the pose names the record: a node's own, or the child's the children stage will compute (hybrid_a_star.py:134-151)
+    double x = 0.0, y = 0.0, th = 0.0;
+    int gear = 1;
+    if (kid) {
+        const double travel = cn.forward ? p.travel_dt : -p.travel_dt;
+        th = avp_pi_2_pi(cn.th + s.k_dth_dt[sc]);
+        double sth, cth;
+        avp_sincos(th, sth, cth);
+        x = cn.x + travel * cth;
+        y = cn.y + travel * sth;
+        gear = cn.forward;
+    } else if (cand) {
+        const PlNode& nd = w.nodes[node];
+        x = nd.x; y = nd.y; th = nd.th; gear = nd.forward;
+    }
     bool want = false;
     unsigned long long w0 = 0;
-    if ((kid && backlog <= PL_LOOK_BACKLOG) || cand) {
-        w0 = kid ? pl_look_tag(pid, s.cur, 1 + (cn.forward ? 0 : p.n_steer) + sc) : pl_look_tag(pid, node, 0);
+    if (kid || cand) {
+        const unsigned long long tag = pl_look_tag(pid, x, y, th);
         int32_t busy = 0;
-        want = pl_look_claim(look, w0, &busy);
+        want = pl_look_claim(look, tag, &busy);
         if (busy) atomicAdd(&s.n_busy, busy);
+        w0 = PL_JOB_W0(tag, blockIdx.x, gear, 0);
     }
-    double x = 0.0, y = 0.0, th = 0.0;
-    if (want) {
-        if (kid) {
-            // (the children stage's expressions, hybrid_a_star.py:134-151)
-            const double travel = cn.forward ? p.travel_dt : -p.travel_dt;
-            th = avp_pi_2_pi(cn.th + s.k_dth_dt[sc]);
-            double sth, cth;
-            avp_sincos(th, sth, cth);
-            x = cn.x + travel * cth;
-            y = cn.y + travel * sth;
-        } else {
-            const PlNode& nd = w.nodes[node];
-            x = nd.x; y = nd.y; th = nd.th;
-        }
-    }
-    pl_ring_post2(look, lane, want, w0, x, y, th, s.goal);
+    pl_ring_post2(look, lane, want, w0, x, y, th, INFINITY, pid);
 }
 
 // ---- called parts of plan_kernel (whole workgroup; they read the kernel's arguments through PlShared's LDS copies) ------------
@@ -2165,6 +2255,12 @@ __device__ __noinline__ void plk_look_prefetch(AVP_LDS PlShared* sp, int64_t pid
 {
     PlShared& s = *(PlShared*)sp;
     pl_look_prefetch(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node, second_f);
+}
+
+__device__ __noinline__ void plk_look_second(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node, double thr)
+{
+    PlShared& s = *(PlShared*)sp;
+    pl_look_second(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node, thr);
 }
 
 // Late adoption (round 5). A pop goes the long way when its node's record is not there at the moment the node is popped -- for a
@@ -2311,7 +2407,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                         if (got == 1) {
                             for (int k = 0; k < 7; k++) s.job[k] = pl_ld64(e + k);
                             if (pl_ld64(e + 7) != ticket + 1ull) s.job_skip = 1;
-                            s.goal[0] = pl_unbits(s.job[4]); s.goal[1] = pl_unbits(s.job[5]); s.goal[2] = pl_unbits(s.job[6]);
+                            // (the goal is the problem's: the heading wrapped as plk_init wraps it -- owners of refused poses post nothing)
+                            const int64_t jp = (int64_t)s.job[5];
+                            s.goal[0] = goals[3 * jp]; s.goal[1] = goals[3 * jp + 1]; s.goal[2] = avp_pi_2_pi(goals[3 * jp + 2]);
                         } else if (got == 2) s.job_skip = 1;
                         else s.done = 1;
                     }
@@ -2329,7 +2427,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             if (!helper) cn = w.nodes[s.cur];
             else {
                 cn.x = pl_unbits(s.job[1]); cn.y = pl_unbits(s.job[2]); cn.th = pl_unbits(s.job[3]);
-                cn.g = 0; cn.h = 0; cn.f = 0; cn.index = 0; cn.parent_index = -1; cn.parent_pos = -1; cn.forward = 1; cn.steer_i = -1; cn.state = 3; cn.heap_pos = -1;
+                cn.g = 0; cn.h = 0; cn.f = 0; cn.index = 0; cn.parent_index = -1; cn.parent_pos = -1; cn.forward = (int8_t)PL_JOB_GEAR(s.job[0]); cn.steer_i = -1; cn.state = 3; cn.heap_pos = -1;      // (the gear: what a chained prediction costs this node's children with)
             }
             const bool use_rec = LOOK && !helper && s.use_rec;
 #ifndef PL_PH_LONG
@@ -2340,7 +2438,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             uint32_t look_node = 0xffffffffu;
             if constexpr (LOOK) if (!helper && look.on && wave == nwave - 1) {
                 look_node = pl_look_candidate(w, s, lane);
-                if (!use_rec) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, 1, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);      // (hidden behind the sub-step checks)
+                if (!use_rec) {
+                    plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, 1, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);      // (hidden behind the sub-step checks)
+                    if (PL_LOOK_PREDICT && PL_LOOK_SECOND) { double thr2; const int32_t sn = pl_look_second_node(w, s, thr2); plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, sn, thr2); }
+                }
             }
             if (trace && tid == 0 && !helper && n_pops < max_trace) {
                 double* t = trace + ((size_t)pid * max_trace + n_pops) * PL_TRACE_W;
@@ -2359,7 +2460,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             bool can_fast = false;
             long long t_f = 0;
             int32_t pre_cand = -1;
-            double pre_second = INFINITY;
+            double pre_second = INFINITY, sec_thr = INFINITY;
+            int32_t sec_cand = -1;
             bool late = false;                 // (PL_LOOK_LATE) the long way was left for the node's record, which landed meanwhile
             if (!use_rec) {
             if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = hC ? 2 : 0; }
@@ -2602,8 +2704,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     }
                     if (lane == 63) {
                         // (the key words are written by both halves, with the same values)
-                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, pl_look_key3(PL_JOB_PID(j0), pl_unbits(s.job[6])));
-                        pl_st64(rp + 86, s.job[4]); pl_st64(rp + 87, s.job[5]);
+                        pl_st64(rp + 80, s.job[1]); pl_st64(rp + 81, s.job[2]); pl_st64(rp + 82, s.job[3]); pl_st64(rp + 83, pl_look_key3((int64_t)s.job[5], s.goal[2]));
+                        pl_st64(rp + 86, pl_bits(s.goal[0])); pl_st64(rp + 87, pl_bits(s.goal[1]));
                         if (hS) {
                             pl_st64(rp + 84, (unsigned long long)(in_radius ? 1 : 0) | ((unsigned long long)(s.collision ? 1 : 0) << 1) | ((unsigned long long)(uint8_t)s.rs_status << 8));
                             pl_st64(rp + 85, (unsigned long long)(uint32_t)s.rs_first_coll | ((unsigned long long)(uint32_t)s.rs_npts << 32));
@@ -2612,7 +2714,14 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     PL_LOOK_DRAIN();
                     wave_sync();
                     if (lane == 0) { PL_FLAG_OR64(look.state + ri, hS ? 4ull : 2ull); atomicAdd(look.ctrl + (hS ? 88 : 24), 1ull); }      // ([24], [88]: halves made)
-                    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_NODE(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
+                    if (PL_LOOK_FAULT > 0 && lane == 0 && PL_JOB_TAG(j0) % (PL_LOOK_FAULT > 0 ? PL_LOOK_FAULT : 1) == 0) pl_st64(rp + 81, s.job[2] ^ 1ull);   // (fault injection: the y key, last bit)
+                }
+                else if (PL_LOOK_CHAIN > 0 && wave == 1 && hC) {
+                    // a predicted dive goes on below this node: post its cheapest child under the job's threshold (beside wave 0's publishing)
+                    const unsigned long long j0 = s.job[0];
+                    if (PL_JOB_DEPTH(j0) > 0)
+                        pl_look_chain(look, s, (const uint32_t*)(workspace + (size_t)PL_JOB_BLOCK(j0) * dims.bytes), lane, cn.th, cn.forward, pl_unbits(s.job[4]),
+                                      PL_JOB_DEPTH(j0), PL_JOB_BLOCK(j0), (int64_t)s.job[5]);
                 }
                 continue;
             }
@@ -2625,6 +2734,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
                 const unsigned long long* rec = s.recb[s.rec_cur];
                 if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s, pre_second);      // (its record is fetched beside the resolution)
+                if constexpr (LOOK) if (PL_LOOK_PREDICT && PL_LOOK_SECOND && wave == 3 && !late) sec_cand = pl_look_second_node(w, s, sec_thr);      // (the long way has looked already)
                 const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
                 if (wave == 2 && lane < nchild) {
                     // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
@@ -2688,6 +2798,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                     }
                 } else if (LOOK && rec && wave == 2) {
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
+                } else if (LOOK && rec && wave == 3) {
+                    if constexpr (LOOK) if (PL_LOOK_PREDICT && PL_LOOK_SECOND) plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, sec_cand, sec_thr);      // (an idle wave of a record pop)
                 } else if (LOOK && rec && wave == nwave - 1) {
                     if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
                 }

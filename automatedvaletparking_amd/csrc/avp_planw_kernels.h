@@ -89,6 +89,7 @@ static __device__ const int8_t PW_ITEM_M[46] = { 0, 0,  0, 1, 0, 1,  0, 1, 0, 1,
 struct PwCommon {
     double k_steer[AVP_MAX_STEER], k_dth_dt[AVP_MAX_STEER], k_dth_ddt1[AVP_MAX_STEER], k_travel_ddt1;      // (sub-step j: x (j + 1))
     int8_t sub_child[PW_MAXCHILD * 4], sub_j[PW_MAXCHILD * 4], sub_steer[PW_MAXCHILD * 4];
+    double sub_dth[PW_MAXCHILD * 4], sub_td[PW_MAXCHILD * 4];   // per sub-step pose t: the heading change ... / lw * ddt * (j + 1) and the signed travel speed * ddt * (j + 1) (hybrid_a_star.py:188-191)
     int8_t item_word[46], item_g[46], item_m[46], sg_l[8], sg_shift[8], sg_off[8], sg_gmax[8];
     PlChkEnv env;                     // what the called collision passes read of the map and the vehicle
     DevMap m;
@@ -255,6 +256,7 @@ struct PwSharedT {
     uint32_t phase[PW_PH_COUNT];               // instrumented instantiation only: shader cycles per phase (lane 0)
     int64_t snap[5];                           // counters saved before a resolution that runs beside the shot (pw_ph_shot_resolve)
     int32_t resume, fresh_done, park_now, sl_pad;   // time slicing: this problem continues a parked search / no unstarted problem is left / park decision
+    int64_t slice_end;                          // ... the pop count at which this slice ends (kept here, not in a register across the phase calls)
     static constexpr bool POINT_FAST = NW == 1;       // (pl_check_narrow: the first look pays where the CU is issue bound)
     __device__ __forceinline__ PlWaveChkT<PW_WQCAP>& wave_chk() { return wchk[PwGroup<NW>::wv()]; }
 };
@@ -532,10 +534,8 @@ __device__ __noinline__ void pw_ph_substeps(PW_PHASE_ARGS)
         uint32_t* hits = &s.wave_chk().hit[0];
         pl_check_wave<STAGE>(c.env, s, cnt, [&](int k, double& x, double& y, double& th, double& cs, double& sn) {
             const int t = s.sub_t[base + k];
-            const int ci = c.sub_child[t], j = c.sub_j[t], si = c.sub_steer[t];
-            const double tj = c.k_travel_ddt1 * (double)(j + 1);
-            const double td = ci < p.n_steer ? tj : -tj;
-            th = avp_pi_2_pi(cnth + c.k_dth_ddt1[si] * (double)(j + 1));
+            const double td = c.sub_td[t];
+            th = avp_pi_2_pi(cnth + c.sub_dth[t]);
             avp_sincos(th, sn, cs);
             x = cnx + td * cs;
             y = cny + td * sn;
@@ -975,8 +975,9 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
         if (gtid == 0) s.fresh_done = 0;
         if (tid < PW_WAVES) { PW_BAR_CNT[tid] = 0; PW_BAR_GEN[tid] = 0; PW_SUB_CNT[tid] = 0; PW_SUB_GEN[tid] = 0; }
     }
+    // (a group holds PW_MAXCHILD children = PW_MAXCHILD / 2 steering angles: a configuration with more is handed to plan_kernel)
 #pragma unroll
-    for (int k = 0; k < AVP_MAX_STEER; k++) if (tid == k) {
+    for (int k = 0; k < PW_MAXCHILD / 2; k++) if (tid == k) {
         c.k_steer[k] = p.steer[k]; c.k_dth_dt[k] = p.dth_dt[k]; c.k_dth_ddt1[k] = p.dth_ddt1[k];
     }
     if (tid == 0) c.k_travel_ddt1 = p.travel_ddt1;
@@ -995,6 +996,15 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
     } else { mt.X = m.X; mt.Y = m.Y; mt.bits = m.colBits; }
     if (gtid == 0) s.mt = mt;
     if (tid == 0) pl_chk_env_fill(c.env, m, p, STAGE ? mt.X : nullptr, STAGE ? mt.Y : nullptr, STAGE ? mt.bits : nullptr);
+    __syncthreads();
+    // per sub-step pose t = child * n_sub + j: heading change and signed travel, from the LDS copies above (the reference's
+    // left-to-right products, hybrid_a_star.py:188-191: ... * ddt * (j + 1), speed * ddt * (j + 1))
+    if (tid < PW_MAXCHILD * 4 && p.n_sub > 0 && p.n_steer > 0 && p.n_steer <= PW_MAXCHILD / 2) {
+        const int ci = c.sub_child[tid], j = c.sub_j[tid], si = c.sub_steer[tid];
+        const double tj = c.k_travel_ddt1 * (double)(j + 1);
+        c.sub_td[tid] = ci < p.n_steer ? tj : -tj;
+        c.sub_dth[tid] = c.k_dth_ddt1[si] * (double)(j + 1);
+    }
     __syncthreads();                                   // the last workgroup barrier: from here on every group is on its own
 
     // Time slicing (slice_pops > 0; the host gives every problem its own workspace slot): a search that is still running
@@ -1020,18 +1030,21 @@ __global__ __launch_bounds__(PW_THREADS) PW_OCC void plan_wave_kernel(DevMap m, 
         if (sliced && s.resume) pw_ph_restore<NW>(sp, cp);
         else pw_ph_init<NW>(sp, cp);
         PW_T(PW_PH_INIT);
-        int64_t slice_end = sliced ? s.n_pops + slice_pops : (int64_t)1 << 62;
+        if (gtid == 0) s.slice_end = sliced ? s.n_pops + slice_pops : (int64_t)1 << 62;
+        G::sync_lds();
         bool parked = false;
         // ---- main loop: path_planner.py:68-98 ------------------------------------------------------
         while (s.status == 0 && !s.done) {
-            if (s.n_pops >= slice_end) {
+            if (s.n_pops >= s.slice_end) {
                 if (gtid == 0) {
                     const uint32_t h = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tl = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s.park_now = ((int64_t)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n || (int32_t)(tl - h) > 0) ? 1 : 0;
                 }
                 G::sync_lds();
                 if (s.park_now) { pw_ph_park<NW>(sp, cp); parked = true; break; }
-                slice_end += slice_pops;
+                G::sync_lds();                          // (every wave has compared before the end of the slice moves)
+                if (gtid == 0) s.slice_end += slice_pops;
+                G::sync_lds();
             }
             pw_ph_pop<NW>(sp, cp);
             if (s.status != 0) break;

@@ -69,7 +69,9 @@ def test_golden_problems(path, vehicle, cfg):
         cfgp.update(json.loads(str(g["cfg_json"])))
     cap = 30000
     dm = _native.DeviceMap(m, vehicle, cfgp, max_pops=cap)
-    bp = path_planner.BatchPlanner(dm, n_slots=1, max_nodes=1 << 19)
+    # (the arena holds every node a search creates: up to 2 x steering_angle_num per pop -- the unfinished 30 000-pop runs of the
+    #  17-angle variant make a million)
+    bp = path_planner.BatchPlanner(dm, n_slots=1, max_nodes=1 << (19 if cfgp["steering_angle_num"] <= 8 else 21))
     res = bp.plan(st[None, :], go[None, :], max_trace=cap)[0]
     o = oracle.Oracle(m, vehicle, cfgp, max_pops=cap)
     bad, _ = _parity.compare_pinned(o, [res], [st], [go], cap, threads=1)
@@ -232,7 +234,8 @@ def test_config_variants_vs_oracle(over, vehicle, cfg):
     starts = np.concatenate([starts, [[m.case.x0, m.case.y0, m.case.theta0]]])
     goals = np.concatenate([goals, [[m.case.xf, m.case.yf, m.case.thetaf]]])
     dm = _native.DeviceMap(m, vehicle, c2, max_pops=cap)
-    res = path_planner.BatchPlanner(dm, max_nodes=8192).plan(starts, goals, max_trace=cap)
+    # (the arena holds every node a search makes: 2 x steering_angle_num per pop)
+    res = path_planner.BatchPlanner(dm, max_nodes=max(8192, cap * 2 * c2["steering_angle_num"] + 64)).plan(starts, goals, max_trace=cap)
     with oracle.device_arithmetic():
         for i, r in enumerate(res):
             _assert_same_as_oracle(r, o.plan(starts[i], goals[i], max_trace=cap))

@@ -106,8 +106,8 @@ def _check_plan(g, m, o, start, goal):
         if str(g["split_error"]) == "":
             pts, seg, cg = o.split_path(r["final_path"])
             assert np.array_equal(pts, g["split_concat"]) and np.array_equal(seg, g["split_len"]) and cg == int(g["change_gear"])
-            # collision checks: search + split extension
-            assert r["n_checks"] <= int(g["n_checks"]) <= r["n_checks"] + 8
+            # collision checks: the search's + the split's (path_planner.py:142-166: extended_num candidate poses behind every gear change, each checked once)
+            assert int(g["n_checks"]) == r["n_checks"] + cg * int(o.ctx.extended_num)
         else:
             with pytest.raises(IndexError):
                 o.split_path(r["final_path"])
