@@ -507,6 +507,7 @@ struct PlShared {
     int32_t rec_cur, pre_node, pre_ok;          // prefetched: the record of node pre_node sits in recb[rec_cur ^ 1] (pre_ok)
     unsigned long long job[PL_JOB_WORDS];   // the job being served (helper)
     int32_t use_rec, job_skip, helper_reg, n_hits, n_sec[4];
+    int32_t n_miss[6];                          // diagnostics (pl_look_load)
     unsigned long long poll_tag; int32_t n_pred, n_busy, n_torn, look_pad;      // the pending record's tag; diagnostics: children posted by pl_look_predict, claims refused (entry busy), copies refused by the seqlock
     static constexpr bool LOOK_SECOND = true;   // (pl_resolve_fast_wave publishes fetch_second)
     double fetch_second;                        // the open list's second-best key as of the pop-ahead that named next_cur (pl_resolve_fast_wave -> pl_look_fetch)
@@ -1823,6 +1824,15 @@ __device__ __forceinline__ unsigned long long pl_look_tag(int64_t pid, double x,
 #ifndef PL_LOOK_SECOND
 #define PL_LOOK_SECOND 1              // ... and from the record of the open list's SECOND-best node (one more pop of lead, pl_look_second)
 #endif
+#ifndef PL_LOOK_CHAIN_TOP
+#define PL_LOOK_CHAIN_TOP 0           // ... also below a node that is posted while it already sits in the first three heap slots (pl_look_post): 2 measured no gain (16.9 ms either way)
+#endif
+#ifndef PL_LOOK_CHAIN_KIDS
+#define PL_LOOK_CHAIN_KIDS 0          // ... and below the likely children posted at the start of a long pop: 1 measured no gain
+#endif
+#ifndef PL_LOOK_ANYSEEN
+#define PL_LOOK_ANYSEEN 0             // pl_look_predict: 1 = any distance the sweep has reached counts (as for a helper), 0 = only a query that hits the closed frontier
+#endif
 #ifndef PL_LOOK_CHAIN
 #define PL_LOOK_CHAIN 2               // a helper that has computed a predicted child's children posts the next level of the dive itself, this many levels deep (<= 3)
 #endif
@@ -1880,7 +1890,11 @@ __device__ __forceinline__ int pl_look_load(const PlLook& look, const PlanWs& w,
             ri = pl_look_ent(look, tag);
             st = PL_FLAG_LD64(look.state + ri);
             if (!(PL_ST_TAG(st) == tag && PL_ST_POSTED(st))) st = 0ull;
-            if (wait) atomicAdd(&s.n_sec[st == 0ull ? 0 : PL_ST_READY(st) ? 2 : 1], 1);      // (diagnostics: the next pop's node was not posted / pending / ready)
+            if (wait) {
+                atomicAdd(&s.n_sec[st == 0ull ? 0 : PL_ST_READY(st) ? 2 : 1], 1);      // (diagnostics: the next pop's node was not posted / pending / ready)
+                // ... and what kind of pop misses: a dive (child of the node being expanded) below a record pop / below a long pop / another node
+                if (st == 0ull || !PL_ST_READY(st)) atomicAdd(&s.n_miss[(st == 0ull ? 0 : 3) + (nn.parent_pos == s.cur ? (s.use_rec ? 0 : 1) : 2)], 1);
+            }
             if (PL_LOOK_WAIT > 0 && wait && s.look_calm && st != 0ull && !PL_ST_READY(st)) {
                 // (an entry whose jobs are in flight is nobody else's to claim: the tag stays while we wait)
                 const long long t0 = clock64();
@@ -1969,6 +1983,7 @@ __device__ __forceinline__ void pl_look_predict(const PlLook& look, const PlanWs
             const uint32_t d = pl_id_in_range(m, id) ? w.dist[id] : PL_UNSEEN;
             uint32_t hd = PL_UNSEEN;
             valid = pl_hquery_hit(m, s, id, d, hd) && hd != PL_UNSEEN;
+            if (PL_LOOK_ANYSEEN && !valid && d != PL_UNSEEN) { valid = true; hd = d; }
             const double hv1 = (double)hd / 100;
             f = pl_node_cost(p, lane < p.n_steer ? 1 : 0, cth, tth, tfw) + (L > hv1 ? L : hv1);
         }
@@ -2125,15 +2140,16 @@ __device__ __forceinline__ void pl_look_chain(const PlLook& look, PlShared& s, c
 //    queues comes too late anyway, and late records mean more long pops, which post more children; without the gate the
 //    system locks into that state (measured: 18 % record pops instead of 75 %).
 template <class S>
-__device__ __forceinline__ uint32_t pl_look_candidate(const PlanWs& w, S& s, int lane)
+__device__ __forceinline__ uint32_t pl_look_candidate(const PlanWs& w, S& s, int lane, double& key)
 {
     uint32_t node = 0xffffffffu;
-    if (lane < PL_LOOK_TOP && lane < s.nheap) { node = pl_heap_get(w, s, lane).node; if (node >= (uint32_t)s.nnodes) node = 0xffffffffu; }
+    key = INFINITY;
+    if (lane < PL_LOOK_TOP && lane < s.nheap) { const PlHeapEnt e = pl_heap_get(w, s, lane); node = e.node; key = e.f; if (node >= (uint32_t)s.nnodes) node = 0xffffffffu; }
     return node;
 }
 template <class S>
 __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w, S& s, const avp_params& p, const PlNode& cn, int64_t pid,
-                                             int32_t maxNodes, int lane, uint32_t node, bool kids)
+                                             int32_t maxNodes, int lane, uint32_t node, double node_key, bool kids)
 {
     static_assert(PL_LOOK_TOP <= 32, "lanes 32 .. 34 post the children");
     // ring counters (head counts the tickets drawn: it runs ahead of the tail while helpers wait for work)
@@ -2164,6 +2180,15 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
         const PlNode& nd = w.nodes[node];
         x = nd.x; y = nd.y; th = nd.th; gear = nd.forward;
     }
+    // A node in the first three heap slots that has no job YET is a fresh arrival at the top of the list -- a child of the node popped
+    // just before, or of the one before that: its own pop will come before its record, but the helper that computes its children can post
+    // the next level of the dive at once (pl_look_chain): the job carries a chain depth and the cost a child has to beat, the cheapest
+    // key among the other two of the three. Likewise a child posted at the start of a long pop: its children have to beat the list's root.
+    const double k0 = __shfl(node_key, 0, 64), k1 = __shfl(node_key, 1, 64), k2 = __shfl(node_key, 2, 64);
+    int depth = 0;
+    double thr = INFINITY;
+    if (PL_LOOK_CHAIN_TOP > 0 && cand && lane < 3) { depth = PL_LOOK_CHAIN_TOP; thr = lane == 0 ? (k1 < k2 ? k1 : k2) : lane == 1 ? (k0 < k2 ? k0 : k2) : (k0 < k1 ? k0 : k1); }
+    if (PL_LOOK_CHAIN_KIDS > 0 && kid) { depth = PL_LOOK_CHAIN_KIDS; thr = k0; }
     bool want = false;
     unsigned long long w0 = 0;
     if (kid || cand) {
@@ -2171,9 +2196,9 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
         int32_t busy = 0;
         want = pl_look_claim(look, tag, &busy);
         if (busy) atomicAdd(&s.n_busy, busy);
-        w0 = PL_JOB_W0(tag, blockIdx.x, gear, 0);
+        w0 = PL_JOB_W0(tag, blockIdx.x, gear, depth);
     }
-    pl_ring_post2(look, lane, want, w0, x, y, th, INFINITY, pid);
+    pl_ring_post2(look, lane, want, w0, x, y, th, thr, pid);
 }
 
 // ---- called parts of plan_kernel (whole workgroup; they read the kernel's arguments through PlShared's LDS copies) ------------
@@ -2236,13 +2261,13 @@ __device__ __noinline__ void plk_write_result(AVP_LDS PlShared* sp, int64_t pid,
 }
 
 // the owner side of the lookahead (one wave each), as called functions: five call sites in the pop loop
-__device__ __noinline__ void plk_look_post(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, uint32_t node, int kids,
+__device__ __noinline__ void plk_look_post(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, uint32_t node, double node_key, int kids,
                                            double cnx, double cny, double cnth, int cn_forward, int cn_steer)
 {
     PlShared& s = *(PlShared*)sp;
     PlNode cn;
     cn.x = cnx; cn.y = cny; cn.th = cnth; cn.forward = (int8_t)cn_forward; cn.steer_i = (int8_t)cn_steer;     // (what pl_look_post reads of the node)
-    pl_look_post(s.klook, s.kw, s, s.kp, cn, pid, maxNodes, threadIdx.x & 63, node, kids != 0);
+    pl_look_post(s.klook, s.kw, s, s.kp, cn, pid, maxNodes, threadIdx.x & 63, node, node_key, kids != 0);
 }
 __device__ __noinline__ void plk_look_fetch(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node, int32_t nheap_after, int nchild, int flags)
 {
@@ -2314,7 +2339,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         w.rsdir = (int8_t*)(look.hrs + (size_t)((int32_t)blockIdx.x - look.main_blocks) * PL_LOOK_HRS + pl_al((size_t)PL_RS_CAP * 3 * 8));
     }
     const int tid = threadIdx.x;
-    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.look_calm = 0; s.look_live = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; s.poll_on = 0; s.late_rec = 0; s.late_rec2 = 0; s.n_late = 0; s.n_pred = 0; s.n_busy = 0; s.n_torn = 0; s.poll_tag = 0; s.fetch_second = INFINITY; }
+    if (tid == 0) { s.sched_cnt = -1; s.sched_n = 0; s.use_rec = 0; s.job_skip = 0; s.helper_reg = 0; s.n_hits = 0; s.look_calm = 0; s.look_live = 0; s.n_sec[0] = s.n_sec[1] = s.n_sec[2] = s.n_sec[3] = 0; s.rec_cur = 0; s.pre_node = -1; s.pre_ok = 0; s.poll_on = 0; s.late_rec = 0; s.late_rec2 = 0; s.n_late = 0; s.n_pred = 0; s.n_busy = 0; s.n_torn = 0; s.poll_tag = 0; s.fetch_second = INFINITY; for (int k = 0; k < 6; k++) s.n_miss[k] = 0; }
     // The lane-indexed constants of avp_params are read through LDS copies only: a dynamically indexed member of the
     // by-value kernel argument would make the compiler copy the whole struct (1 KB) to every lane's scratch.
 #pragma unroll
@@ -2436,10 +2461,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             const bool ph_on = !LOOK || (PL_PH_LONG ? !use_rec : use_rec);      // (instrumented lookahead run: the per-wave timeline covers the record pops only; PL_PH_LONG: the long pops only)
             if (PROFILE && LOOK && tid == 0 && ph_on) s.phase[PH_X0 + 7] += 1;
             uint32_t look_node = 0xffffffffu;
+            double look_key = INFINITY;
             if constexpr (LOOK) if (!helper && look.on && wave == nwave - 1) {
-                look_node = pl_look_candidate(w, s, lane);
+                look_node = pl_look_candidate(w, s, lane, look_key);
                 if (!use_rec) {
-                    plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, 1, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);      // (hidden behind the sub-step checks)
+                    plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, look_key, 1, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);      // (hidden behind the sub-step checks)
                     if (PL_LOOK_PREDICT && PL_LOOK_SECOND) { double thr2; const int32_t sn = pl_look_second_node(w, s, thr2); plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, sn, thr2); }
                 }
             }
@@ -2765,7 +2791,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 __syncthreads();
                 can_fast = s.closed_nonempty && (s.nnodes + nchild <= maxNodes);
                 t_f = PH_NOW();
-                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);
+                if constexpr (LOOK) if (!can_fast && wave == nwave - 1) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, look_key, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);
             }
 
             // ---- sequential resolution in child order (:153-232). Thread 0 runs alone; when a heuristic
@@ -2801,7 +2827,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 } else if (LOOK && rec && wave == 3) {
                     if constexpr (LOOK) if (PL_LOOK_PREDICT && PL_LOOK_SECOND) plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, sec_cand, sec_thr);      // (an idle wave of a record pop)
                 } else if (LOOK && rec && wave == nwave - 1) {
-                    if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
+                    if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, look_key, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
                 }
                 if (LOOK && rec) PH_MARK(3);
                 __syncthreads();
@@ -2901,7 +2927,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         // ---- finish_path (:351-389) + assembly (path_planner.py:100-108) -----------------------------
         if (tid == 0) {
             plk_write_result<PROFILE>((AVP_LDS PlShared*)&s, pid, n_pops, (int32_t)blockIdx.x, t_fin);
-            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } if (s.n_late) { atomicAdd(look.ctrl + 76, (unsigned long long)s.n_late); s.n_late = 0; } if (s.n_pred) { atomicAdd(look.ctrl + 77, (unsigned long long)s.n_pred); s.n_pred = 0; } if (s.n_busy) { atomicAdd(look.ctrl + 78, (unsigned long long)s.n_busy); s.n_busy = 0; } if (s.n_torn) { atomicAdd(look.ctrl + 79, (unsigned long long)s.n_torn); s.n_torn = 0; } }   // ([8]: records used, [76]: of which adopted late -- diagnostics)
+            if constexpr (LOOK) { atomicAdd(look.ctrl + 32, 1ull); if (s.n_hits) { atomicAdd(look.ctrl + 8, (unsigned long long)s.n_hits); s.n_hits = 0; } for (int k = 0; k < 4; k++) if (s.n_sec[k]) { atomicAdd(look.ctrl + 72 + k, (unsigned long long)s.n_sec[k]); s.n_sec[k] = 0; } if (s.n_late) { atomicAdd(look.ctrl + 76, (unsigned long long)s.n_late); s.n_late = 0; } if (s.n_pred) { atomicAdd(look.ctrl + 77, (unsigned long long)s.n_pred); s.n_pred = 0; } if (s.n_busy) { atomicAdd(look.ctrl + 78, (unsigned long long)s.n_busy); s.n_busy = 0; } if (s.n_torn) { atomicAdd(look.ctrl + 79, (unsigned long long)s.n_torn); s.n_torn = 0; } for (int k = 0; k < 6; k++) if (s.n_miss[k]) { atomicAdd(look.ctrl + 96 + k, (unsigned long long)s.n_miss[k]); s.n_miss[k] = 0; } }   // ([8]: records used, [76]: of which adopted late -- diagnostics)
         }
         __syncthreads();
     }

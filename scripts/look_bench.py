@@ -47,6 +47,7 @@ def main():
             e.update(jobs_posted=int(c[0]), children_halves_made=int(c[24]), shot_halves_made=int(c[88]), records_used=int(c[8]),
                      helper_workgroups=int(c[48]), record_pop_frac=float(c[8]) / max(int(rec["n_pops"].sum()), 1),
                      next_node_lookups={"not_posted": int(c[72]), "pending": int(c[73]), "ready": int(c[74]), "waited": int(c[75])}, records_adopted_late=int(c[76]),
+                     misses_by_kind={"not_posted": {"dive_below_record_pop": int(c[96]), "dive_below_long_pop": int(c[97]), "other": int(c[98])}, "pending": {"dive_below_record_pop": int(c[99]), "dive_below_long_pop": int(c[100]), "other": int(c[101])}},
                      children_posted_by_dive_prediction=int(c[77]), children_posted_by_helpers=int(c[71]), claims_refused_entry_busy=int(c[78]), copies_refused_by_seqlock=int(c[79]),
                      records_never_used_frac=1.0 - float(c[8]) / max(int(c[0]), 1),
                      lookahead_workspace_bytes=int(bp._look.numel()))
