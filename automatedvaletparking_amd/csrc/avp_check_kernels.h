@@ -384,15 +384,69 @@ __global__ __launch_bounds__(128) void corridor_kernel(DevMap m, avp_params p, d
 // 64 lanes are compacted into a per-wave LDS queue, so the per-point work -- first matching edge area, point-line
 // distance, two divisions -- runs on full waves however unevenly the points are spread; the four running minima of a
 // way-point are LDS atomicMin on the bit patterns (all candidates are >= 0, NaN never wins: same as the "<" scan).
-#define COR_QCAP 2048            // queue entries per wave
-#define COR_WAVES 6               // waves per workgroup, at most (the host launches as many as fit the LDS)
+#ifndef COR_QCAP
+#define COR_QCAP 1024            // queue entries per wave (round 6: 2048 -> 1024 and 6 -> 8 waves per workgroup: 6.0 -> 6.9e8 way-points/s)
+#endif
+#ifndef COR_WAVES
+#define COR_WAVES 8               // waves per workgroup, at most (the host launches as many as fit the LDS)
+#endif
 #define COR_COLS 4                // map columns per broad-phase step (up to 3 bitmap words each: the AABB is grown by expand_dis)
-struct CorPose { double ac, as, expand; int32_t cs, pad; unsigned long long mn[4]; double pad2; };   // |cos|, |sin|, heading case, per EDGE AREA the smallest point-line numerator |k x + b - y| seen (round 6; until round 5: the four minima themselves); 9 doubles: an ODD record stride, like CHK_FPW
+// Per way-point record in LDS (round 6): what the narrow phase and the closing step read, nothing else. The four edge areas' boxes are
+// evaluated ONCE per way-point in the set-up, with expand_dis folded in (until round 5 every candidate rebuilt them from the corners:
+// 16 min / max, 8 selects, 8 additions per candidate); mn[k] = the smallest point-line numerator |k x + b - y| seen in area k.
+// 35 doubles: an ODD stride, so that the same field of neighbouring way-points falls into different LDS banks.
+struct CorRec { double box[4][4]; double k[4], b[4], den[4]; double ac, as; unsigned long long mn[4]; double cs; };   // box[k] = {x lo, x hi, y lo, y hi} (strict); cs: the heading case 0 .. 4
+static_assert(sizeof(CorRec) == 35 * 8, "CorRec: odd stride in doubles");
 
 static inline size_t corridor_lds_bytes(const DevMap& m, bool stage, int waves)
 {
-    const size_t perWave = 64 * CHK_FPW * 8 + 64 * sizeof(CorPose) + COR_QCAP * 4;
+    const size_t perWave = 64 * sizeof(CorRec) + COR_QCAP * 4;
     return (stage ? ((size_t)m.nx * m.wpc + m.nx + m.ny) * 8 : 0) + (size_t)waves * perWave;
+}
+
+// Set-up of one way-point (the lane's), a CALLED function on an LDS copy of the parameters and the record's LDS address (round 6, as
+// check_distance_kernel's chk_setup: inlined, its footprint arithmetic and the by-value arguments it reads kept 19 - 24 SGPRs spilled
+// across the tile loop): the footprint, the node ranges under its AABB grown by expand_dis, the four edge areas' boxes.
+// Returns ixlo | ixhi << 16 | iylo << 32 | iyhi << 48 (an empty column range for an invalid lane or a heading outside [-pi, pi]).
+__device__ __noinline__ uint64_t cor_setup(AVP_LDS const avp_params* pp, double expand, double px, double py, double theta, int valid, AVP_LDS CorRec* crp,
+                                           const double* sX, const double* sY, int nx, int ny, double b0, double dx, double b2, double dy)
+{
+    CorRec& cr = *(CorRec*)crp;
+    Footprint f;
+    avp_footprint_setup(*(const avp_params*)pp, px, py, theta, f);
+    double xlo, xhi, ylo, yhi;
+    avp_footprint_aabb(f, xlo, xhi, ylo, yhi);
+    xhi = xhi + expand; xlo = xlo - expand; yhi = yhi + expand; ylo = ylo - expand;
+    int cs = 0;
+    if (theta >= -AVP_PI && theta < -AVP_PI / 2) cs = 3;
+    else if (theta >= -AVP_PI / 2 && theta < 0) cs = 4;
+    else if (theta >= 0 && theta < AVP_PI / 2) cs = 1;
+    else if (theta >= AVP_PI / 2 && theta <= AVP_PI) cs = 2;
+    int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
+    if (valid && cs) {
+        ixlo = avp_first_ge(sX, nx, b0, dx, xlo);
+        ixhi = avp_last_le(sX, nx, b0, dx, xhi);
+        iylo = avp_first_ge(sY, ny, b2, dy, ylo);
+        iyhi = avp_last_le(sY, ny, b2, dy, yhi);
+        if (iylo > iyhi) ixhi = ixlo - 1;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        // edge area kk (corner kk -> corner kk + 1), grown by expand_dis away from the vehicle (:235-264: the 4 heading cases x 4 areas)
+        const int j = (kk + 1) & 3;
+        const double a0 = f.cx[kk] < f.cx[j] ? f.cx[kk] : f.cx[j], a1 = f.cx[kk] > f.cx[j] ? f.cx[kk] : f.cx[j];
+        const double a2 = f.cy[kk] < f.cy[j] ? f.cy[kk] : f.cy[j], a3 = f.cy[kk] > f.cy[j] ? f.cy[kk] : f.cy[j];
+        const int quad = (kk + cs - 1) & 3;
+        const bool xp = quad == 0 || quad == 1, yp = quad == 1 || quad == 2;
+        cr.box[kk][0] = xp ? a0 : a0 - expand; cr.box[kk][1] = xp ? a1 + expand : a1;
+        cr.box[kk][2] = yp ? a2 : a2 - expand; cr.box[kk][3] = yp ? a3 + expand : a3;
+        cr.k[kk] = f.k[kk]; cr.b[kk] = f.b[kk]; cr.den[kk] = f.den[kk];
+        cr.mn[kk] = 0x7ff0000000000000ull;      // +inf: no point in this area yet (inf / den / |cos| is inf or NaN: never below expand)
+    }
+    double sth_, cth_;
+    avp_sincos(theta, sth_, cth_);
+    cr.ac = fabs(cth_); cr.as = fabs(sth_); cr.cs = (double)cs;
+    return (uint64_t)(uint16_t)ixlo | ((uint64_t)(uint16_t)ixhi << 16) | ((uint64_t)(uint16_t)iylo << 32) | ((uint64_t)(uint16_t)iyhi << 48);
 }
 
 template <bool STAGE>
@@ -401,6 +455,8 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
                                                                           const double* __restrict__ th, int64_t n, double* __restrict__ out)
 {
     avp_lds_tables_fill<false>();
+    __shared__ avp_params sCorP;                              // (the called set-up reads the parameters through LDS: no by-value argument crosses the call)
+    if (threadIdx.x == 0) sCorP = p;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* lBits = (uint64_t*)smem;
     double* lX = (double*)(lBits + (STAGE ? (size_t)m.nx * m.wpc : 0));
@@ -410,51 +466,23 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
     const double* sX = STAGE ? lX : m.X;
     const double* sY = STAGE ? lY : m.Y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t perWave = 64 * CHK_FPW * 8 + 64 * sizeof(CorPose) + COR_QCAP * 4;
-    double* sFp = (double*)(sWave + (size_t)wave * perWave);
-    CorPose* sPose = (CorPose*)(sFp + 64 * CHK_FPW);
-    uint32_t* sQ = (uint32_t*)(sPose + 64);
+    const size_t perWave = 64 * sizeof(CorRec) + COR_QCAP * 4;
+    CorRec* sRec = (CorRec*)(sWave + (size_t)wave * perWave);
+    uint32_t* sQ = (uint32_t*)(sRec + 64);
     if (STAGE) {
         for (int i = threadIdx.x; i < m.nx * m.wpc; i += blockDim.x) lBits[i] = m.colBits[i];
         for (int i = threadIdx.x; i < m.nx; i += blockDim.x) lX[i] = m.X[i];
         for (int i = threadIdx.x; i < m.ny; i += blockDim.x) lY[i] = m.Y[i];
-        __syncthreads();
     }
+    __syncthreads();                                   // (the staged tables and sCorP)
     const int64_t tiles = (n + 63) / 64;
     const int nwaves = (int)(blockDim.x >> 6);
     for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < tiles; tile += (int64_t)gridDim.x * nwaves) {
         const int64_t i = tile * 64 + lane;
         const bool valid = i < n;
         const double px = valid ? x[i] : 0.0, py = valid ? y[i] : 0.0, theta = valid ? th[i] : 0.0;
-        int ixlo = 0, ixhi = -1, iylo = 0, iyhi = -1;
-        {
-            Footprint f;
-            avp_footprint_setup(p, px, py, theta, f);
-            double xlo, xhi, ylo, yhi;
-            avp_footprint_aabb(f, xlo, xhi, ylo, yhi);
-            xhi = xhi + expand; xlo = xlo - expand; yhi = yhi + expand; ylo = ylo - expand;
-            int cs = 0;
-            if (theta >= -AVP_PI && theta < -AVP_PI / 2) cs = 3;
-            else if (theta >= -AVP_PI / 2 && theta < 0) cs = 4;
-            else if (theta >= 0 && theta < AVP_PI / 2) cs = 1;
-            else if (theta >= AVP_PI / 2 && theta <= AVP_PI) cs = 2;
-            if (valid && cs) {
-                ixlo = avp_first_ge(sX, m.nx, m.b0, m.dx, xlo);
-                ixhi = avp_last_le(sX, m.nx, m.b0, m.dx, xhi);
-                iylo = avp_first_ge(sY, m.ny, m.b2, m.dy, ylo);
-                iyhi = avp_last_le(sY, m.ny, m.b2, m.dy, yhi);
-                if (iylo > iyhi) ixhi = ixlo - 1;
-            }
-            const double* src = (const double*)&f;
-            double* dst = sFp + (size_t)lane * CHK_FPW;
-#pragma unroll
-            for (int k = 0; k < CHK_FPN; k++) dst[k] = src[k];
-            CorPose& cp = sPose[lane];
-            double sth_, cth_;
-            avp_sincos(theta, sth_, cth_);
-            cp.ac = fabs(cth_); cp.as = fabs(sth_); cp.expand = expand; cp.cs = cs;
-            cp.mn[0] = cp.mn[1] = cp.mn[2] = cp.mn[3] = 0x7ff0000000000000ull;      // +inf: no point in this area yet (inf / den / |cos| is inf or NaN: never below expand)
-        }
+        const uint64_t rg = cor_setup((AVP_LDS const avp_params*)&sCorP, expand, px, py, theta, valid ? 1 : 0, (AVP_LDS CorRec*)&sRec[lane], sX, sY, m.nx, m.ny, m.b0, m.dx, m.b2, m.dy);
+        const int ixlo = (int16_t)(rg & 0xffff), ixhi = (int16_t)((rg >> 16) & 0xffff), iylo = (int16_t)((rg >> 32) & 0xffff), iyhi = (int16_t)(rg >> 48);
         wave_sync();
         int ncol = ixhi - ixlo + 1;
         if (ncol < 0) ncol = 0;
@@ -483,30 +511,18 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
                 if (e < qtail) {
                     const uint32_t ent = sQ[e];
                     const int pl = ent >> 26, ix = (ent >> 13) & 0x1fff, iy = ent & 0x1fff;
-                    const Footprint& f = *(const Footprint*)(sFp + (size_t)pl * CHK_FPW);
-                    CorPose& cp = sPose[pl];
-                    const double ox = sX[ix], oy = sY[iy], ex = cp.expand;
+                    CorRec& cr = sRec[pl];
+                    const double ox = sX[ix], oy = sY[iy];
+                    // the first edge area whose grown box holds the point (strictly), as the reference's if / elif chain
                     int hitk = -1;
-                    bool xpos = false, ypos = false;
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int j = (kk + 1) & 3;
-                        const double a0 = f.cx[kk] < f.cx[j] ? f.cx[kk] : f.cx[j], a1 = f.cx[kk] > f.cx[j] ? f.cx[kk] : f.cx[j];
-                        const double a2 = f.cy[kk] < f.cy[j] ? f.cy[kk] : f.cy[j], a3 = f.cy[kk] > f.cy[j] ? f.cy[kk] : f.cy[j];
-                        const int quad = (kk + cp.cs - 1) & 3;
-                        const bool xp = quad == 0 || quad == 1, yp = quad == 1 || quad == 2;
-                        const double ax0 = xp ? a0 : a0 - ex, ax1 = xp ? a1 + ex : a1;
-                        const double ay0 = yp ? a2 : a2 - ex, ay1 = yp ? a3 + ex : a3;
-                        if (hitk < 0 && ox > ax0 && ox < ax1 && oy > ay0 && oy < ay1) { hitk = kk; xpos = xp; ypos = yp; }
-                    }
+                    for (int kk = 3; kk >= 0; kk--)
+                        if (ox > cr.box[kk][0] && ox < cr.box[kk][1] && oy > cr.box[kk][2] && oy < cr.box[kk][3]) hitk = kk;
                     if (hitk >= 0) {
-                        const double fk = hitk == 0 ? f.k[0] : hitk == 1 ? f.k[1] : hitk == 2 ? f.k[2] : f.k[3];
-                        const double fb = hitk == 0 ? f.b[0] : hitk == 1 ? f.b[1] : hitk == 2 ? f.b[2] : f.b[3];
-                        const double num = fabs(fk * ox + fb - oy);
+                        const double num = fabs(cr.k[hitk] * ox + cr.b[hitk] - oy);
                         // (a NaN numerator -- an axis-aligned edge: inf - inf -- gives NaN distances, which never compare less: skipped)
-                        if (num == num) atomicMin(&cp.mn[hitk], (unsigned long long)__double_as_longlong(num));
+                        if (num == num) atomicMin(&cr.mn[hitk], (unsigned long long)__double_as_longlong(num));
                     }
-                    (void)xpos; (void)ypos;
                 }
             }
             qtail = 0;
@@ -577,14 +593,14 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
         drain();
         if (valid) {
             // the scan's updates (:266-280) in area order on the areas' smallest numerators: x_max / x_min take hor, y_max / y_min ver
-            const CorPose& cp = sPose[lane];
-            const Footprint& f = *(const Footprint*)(sFp + (size_t)lane * CHK_FPW);
+            const CorRec& cp = sRec[lane];
+            const int csi = (int)cp.cs;
             double x_max = expand, y_max = expand, x_min = expand, y_min = expand;
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                const int quad = (kk + cp.cs - 1) & 3;
+                const int quad = (kk + csi - 1) & 3;
                 const bool xp = quad == 0 || quad == 1, yp = quad == 1 || quad == 2;
-                const double sd = __longlong_as_double((long long)cp.mn[kk]) / f.den[kk];
+                const double sd = __longlong_as_double((long long)cp.mn[kk]) / cp.den[kk];
                 const double ver = sd / cp.ac, hor = sd / cp.as;
                 if (xp) { if (hor < x_max) x_max = hor; } else { if (hor < x_min) x_min = hor; }
                 if (yp) { if (ver < y_max) y_max = ver; } else { if (ver < y_min) y_min = ver; }
