@@ -1830,6 +1830,10 @@ __device__ __forceinline__ unsigned long long pl_look_tag(int64_t pid, double x,
 #ifndef PL_LOOK_CHAIN_KIDS
 #define PL_LOOK_CHAIN_KIDS 0          // ... and below the likely children posted at the start of a long pop: 1 measured no gain
 #endif
+#ifndef PL_LOOK_PRED2
+#define PL_LOOK_PRED2 2               // pl_look_predict / pl_look_chain also post the node's OTHER children that beat the rest of the list (they are popped within a few pops and would be
+                                      // posted one pop before their own): 1 = the second-cheapest, 2 = every one of them. They are jobs the owner would post anyway, a pop or two later.
+#endif
 #ifndef PL_LOOK_ANYSEEN
 #define PL_LOOK_ANYSEEN 0             // pl_look_predict: 1 = any distance the sweep has reached counts (as for a helper), 0 = only a query that hits the closed frontier
 #endif
@@ -1993,15 +1997,18 @@ __device__ __forceinline__ void pl_look_predict(const PlLook& look, const PlanWs
     pl_look_best2(valid ? pl_bits(f) : ~0ull, lane, mn, best, mn2);
     if (best < 0 || !(pl_unbits(mn) < second_f)) return;     // (uniform) no candidate / another open node would be popped before it
     const double f2 = mn2 == ~0ull ? INFINITY : pl_unbits(mn2);
+    // (the second-cheapest child: when it beats the rest of the list as well it is popped right behind the first one's dive -- a node that
+    //  would otherwise be posted one pop before its own)
+    const int best2 = (PL_LOOK_PRED2 == 1 && f2 < second_f) ? __ffsll((unsigned long long)__ballot(lane != best && valid && pl_bits(f) == mn2)) - 1 : -1;
     bool want = false;
     unsigned long long w0 = 0;
-    if (lane == best) {
+    if (lane == best || lane == best2 || (PL_LOOK_PRED2 >= 2 && valid && f < second_f)) {
         const unsigned long long tag = pl_look_tag(pid, cx, cy, cth);
         int32_t busy = 0;
         want = pl_look_claim(look, tag, &busy);
         if (busy) atomicAdd(&s.n_busy, busy);
         if (want) atomicAdd(&s.n_pred, 1);
-        w0 = PL_JOB_W0(tag, blockIdx.x, best < p.n_steer, PL_LOOK_CHAIN);
+        w0 = PL_JOB_W0(tag, blockIdx.x, lane < p.n_steer, lane == best ? PL_LOOK_CHAIN : 0);
     }
     pl_ring_post2(look, lane, want, w0, cx, cy, cth, f2 < second_f ? f2 : second_f, pid);
 }
@@ -2065,18 +2072,25 @@ __device__ __forceinline__ void pl_look_prefetch(const PlLook& look, const PlanW
     if (lane == 0) { s.pre_node = node; s.pre_ok = ok; }
     if (PL_LOOK_PREDICT && ok && s.look_calm) pl_look_predict(look, w, s, pid, lane, node, s.rec_cur ^ 1, second_f);
 }
-// ... and one more pop ahead: the open list's SECOND-best node (the smaller of the root's two children; the other one's key is
-// what ITS cheapest child has to beat). Its record, if there, goes to the third record buffer and is looked at for a dive only.
+// ... and one or two more pops ahead: the root's two heap children -- the list's SECOND-best node (the smaller one; the other one's key
+// is what its cheapest child has to beat) and, PL_LOOK_SECOND = 2, the other one too (its children have to beat the four nodes of the
+// next heap level). Their records, if there, go to the third record buffer one after the other and are looked at for a dive only.
 template <class S>
-__device__ __forceinline__ int32_t pl_look_second_node(const PlanWs& w, S& s, double& thr)       // (reads the heap: while nobody changes it)
+__device__ __forceinline__ void pl_look_second_nodes(const PlanWs& w, S& s, int32_t& n1, double& t1, int32_t& n2, double& t2)       // (reads the heap: while nobody changes it)
 {
-    int32_t node = -1;
-    thr = INFINITY;
+    n1 = n2 = -1;
+    t1 = t2 = INFINITY;
     if (PL_LOOK_SECOND && s.look_live && s.look_calm && s.nheap >= 3) {
         const PlHeapEnt e1 = pl_heap_get(w, s, 1), e2 = pl_heap_get(w, s, 2);
-        if (e2.f < e1.f) { node = (int32_t)e2.node; thr = e1.f; } else { node = (int32_t)e1.node; thr = e2.f; }
+        const bool sw = e2.f < e1.f;
+        n1 = (int32_t)(sw ? e2.node : e1.node); t1 = sw ? e1.f : e2.f;
+        if (PL_LOOK_SECOND >= 2) {
+            n2 = (int32_t)(sw ? e1.node : e2.node);
+            double m = INFINITY;
+            for (int k = 3; k < 7 && k < s.nheap; k++) { const double f = pl_heap_get(w, s, k).f; if (f < m) m = f; }
+            t2 = m;
+        }
     }
-    return node;
 }
 template <class S>
 __device__ __forceinline__ void pl_look_second(const PlLook& look, const PlanWs& w, S& s, int64_t pid, int32_t maxNodes, int lane, int32_t node, double thr)
@@ -2084,6 +2098,7 @@ __device__ __forceinline__ void pl_look_second(const PlLook& look, const PlanWs&
     if (node < 0) return;
     const int ok = pl_look_load(look, w, s, pid, maxNodes, node, lane, 2, false);
     if (ok && s.look_calm) pl_look_predict(look, w, s, pid, lane, node, 2, thr);
+    wave_sync();
 }
 
 // Helper side of a predicted dive (one wave of a children-half helper whose job carries a chain depth; the children of the job's
@@ -2121,12 +2136,12 @@ __device__ __forceinline__ void pl_look_chain(const PlLook& look, PlShared& s, c
     const double f2 = mn2 == ~0ull ? INFINITY : pl_unbits(mn2);
     bool want = false;
     unsigned long long w0 = 0;
-    if (lane == best) {
+    if (lane == best || (PL_LOOK_PRED2 >= 2 && valid && f < thr)) {
         const unsigned long long tag = pl_look_tag(pid, cx, cy, cth);
         int32_t busy = 0;
         want = pl_look_claim(look, tag, &busy);
         if (want) atomicAdd(look.ctrl + 71, 1ull);           // ([71]: children posted by helpers)
-        w0 = PL_JOB_W0(tag, owner_block, best < p.n_steer, depth - 1);
+        w0 = PL_JOB_W0(tag, owner_block, lane < p.n_steer, lane == best ? depth - 1 : 0);
     }
     pl_ring_post2(look, lane, want, w0, cx, cy, cth, f2 < thr ? f2 : thr, pid);
 }
@@ -2282,10 +2297,11 @@ __device__ __noinline__ void plk_look_prefetch(AVP_LDS PlShared* sp, int64_t pid
     pl_look_prefetch(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node, second_f);
 }
 
-__device__ __noinline__ void plk_look_second(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t node, double thr)
+__device__ __noinline__ void plk_look_second(AVP_LDS PlShared* sp, int64_t pid, int32_t maxNodes, int32_t n1, double t1, int32_t n2, double t2)
 {
     PlShared& s = *(PlShared*)sp;
-    pl_look_second(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, node, thr);
+    pl_look_second(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, n1, t1);
+    pl_look_second(s.klook, s.kw, s, pid, maxNodes, threadIdx.x & 63, n2, t2);
 }
 
 // Late adoption (round 5). A pop goes the long way when its node's record is not there at the moment the node is popped -- for a
@@ -2466,7 +2482,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 look_node = pl_look_candidate(w, s, lane, look_key);
                 if (!use_rec) {
                     plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, look_key, 1, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);      // (hidden behind the sub-step checks)
-                    if (PL_LOOK_PREDICT && PL_LOOK_SECOND) { double thr2; const int32_t sn = pl_look_second_node(w, s, thr2); plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, sn, thr2); }
+                    if (PL_LOOK_PREDICT && PL_LOOK_SECOND) { double ta, tb; int32_t na, nb; pl_look_second_nodes(w, s, na, ta, nb, tb); plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, na, ta, nb, tb); }
                 }
             }
             if (trace && tid == 0 && !helper && n_pops < max_trace) {
@@ -2486,8 +2502,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
             bool can_fast = false;
             long long t_f = 0;
             int32_t pre_cand = -1;
-            double pre_second = INFINITY, sec_thr = INFINITY;
-            int32_t sec_cand = -1;
+            double pre_second = INFINITY, sec_thr = INFINITY, sec_thr2 = INFINITY;
+            int32_t sec_cand = -1, sec_cand2 = -1;
             bool late = false;                 // (PL_LOOK_LATE) the long way was left for the node's record, which landed meanwhile
             if (!use_rec) {
             if (tid == 0) { s.in_radius = in_radius ? 1 : 0; s.collision = 0; s.rs_first_coll = 0x7fffffff; s.rs_npts = 0; s.rs_status = 0; s.rs.n = 0; s.chk_arrived = 0; s.shot_ready = hC ? 2 : 0; }
@@ -2760,7 +2776,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 // ---- the expansion record of a helper stands in for everything up to the resolution ---------------
                 const unsigned long long* rec = s.recb[s.rec_cur];
                 if constexpr (LOOK) if (wave == 1) pre_cand = pl_look_prefetch_node(w, s, pre_second);      // (its record is fetched beside the resolution)
-                if constexpr (LOOK) if (PL_LOOK_PREDICT && PL_LOOK_SECOND && wave == 3 && !late) sec_cand = pl_look_second_node(w, s, sec_thr);      // (the long way has looked already)
+                if constexpr (LOOK) if (PL_LOOK_PREDICT && PL_LOOK_SECOND && wave == 3 && !late) pl_look_second_nodes(w, s, sec_cand, sec_thr, sec_cand2, sec_thr2);      // (the long way has looked already)
                 const bool nf = s.nf_node == s.cur;              // this node's children were looked up by the fetching wave
                 if (wave == 2 && lane < nchild) {
                     // the children's heuristic distances, read ahead of the classification (nothing moves the field meanwhile)
@@ -2825,7 +2841,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
                 } else if (LOOK && rec && wave == 2) {
                     pl_resolve_writer_wave(p, w, s, dims, cn, nchild);
                 } else if (LOOK && rec && wave == 3) {
-                    if constexpr (LOOK) if (PL_LOOK_PREDICT && PL_LOOK_SECOND) plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, sec_cand, sec_thr);      // (an idle wave of a record pop)
+                    if constexpr (LOOK) if (PL_LOOK_PREDICT && PL_LOOK_SECOND) plk_look_second((AVP_LDS PlShared*)&s, pid, maxNodes, sec_cand, sec_thr, sec_cand2, sec_thr2);      // (an idle wave of a record pop)
                 } else if (LOOK && rec && wave == nwave - 1) {
                     if constexpr (LOOK) plk_look_post((AVP_LDS PlShared*)&s, pid, maxNodes, look_node, look_key, PL_LOOK_KIDS_ON_HIT, cn.x, cn.y, cn.th, cn.forward, cn.steer_i);    // (beside the resolution on wave 0)
                 }
