@@ -521,7 +521,11 @@ __global__ __launch_bounds__(64 * COR_WAVES) void corridor_compact_kernel(DevMap
                     if (hitk >= 0) {
                         const double num = fabs(cr.k[hitk] * ox + cr.b[hitk] - oy);
                         // (a NaN numerator -- an axis-aligned edge: inf - inf -- gives NaN distances, which never compare less: skipped)
-                        if (num == num) atomicMin(&cr.mn[hitk], (unsigned long long)__double_as_longlong(num));
+                        // (a plain load first: the queue is ordered by way-point, so the candidates of a trip mostly share their area's word, and after the
+                        //  first few of them hardly any is a new minimum -- the same-address atomics were a third of the kernel's LDS cycles; the minimum
+                        //  only ever falls, so skipping on a stale larger-or-equal reading is safe)
+                        const unsigned long long nb = (unsigned long long)__double_as_longlong(num);
+                        if (num == num && nb < cr.mn[hitk]) atomicMin(&cr.mn[hitk], nb);
                     }
                 }
             }

@@ -206,7 +206,7 @@ static inline __device__ PlanWs plan_carve(char* base, const PlanDims& d)
 struct PlLook {
     unsigned long long* ctrl;         // ring r (0: children halves, 1: shot halves): [64 r] tail, [64 r + 16] head; [32] problems finished,
                                       // [48] helpers alive (one 128-B line each); [8], [24], [88], [72 ..] diagnostics
-    unsigned long long* jobs;         // [2][PL_JCAP][PL_JOB_WORDS]: tag (node | pid << 24 | slot << 40), pose, goal, sequence number
+    unsigned long long* jobs;         // [2][PL_JCAP][PL_JOB_WORDS]: PL_JOB_W0 (tag, owner's workgroup, gear, chain depth), pose, threshold, problem, -, sequence number
     unsigned long long* state;        // [entries]: tag << 8 | generation << 3 | bit 0 posted, bit 1 children half ready, bit 2 shot half ready
     unsigned long long* recs;         // [entries][PL_REC_WORDS]
     char* hrs;                        // [helper-only workgroups][PL_LOOK_HRS]
@@ -220,13 +220,13 @@ struct PlLook {
 //
 // THE RECORD STORE (round 6) is a direct-mapped table of fixed size -- PL_LOOK_ENTRIES records whatever the batch size and
 // the node arena (until round 5: one slot per (problem, arena node, 4): n x max_nodes x 2 832 B, 26 GB at pop cap 3 000, which
-// silently switched the lookahead off). A record is named by its TAG = (problem, node, slot): slot 0 is the node's own
-// expansion (posted when the node reaches the top of its open list), slot 1 + i belongs to CHILD i the node does not have yet
-// (searches dive: a quarter of all pops expand a child of the node popped just before, too soon after its creation for a job
-// posted then -- so likely children are posted through their parent: the three that keep the gear and steer within one step
-// at the start of a pop that takes the long way, and the ONE child that will be the open list's next root as soon as the
-// parent's own record is in the owner's hands, pl_look_predict). The entry of a tag is hash(tag); its state word carries the
-// tag, so two tags that share an entry never share a record:
+// silently switched the lookahead off). A record is named by its TAG = 48 bits of the hash of the POSE it expands, mixed with the
+// problem (pl_look_tag) -- so a node that does not exist yet has the same name as the arena node it will be, whoever posts it:
+// searches dive (a quarter of all pops expand a child of the node popped just before, too soon after its creation for a job
+// posted then), so children are posted ahead of their creation: the three that keep the gear and steer within one step at the
+// start of a pop that takes the long way, every child that beats the rest of the open list as soon as the parent's own record is
+// in the owner's hands (pl_look_predict), and the next levels of such a dive by the helpers themselves (pl_look_chain).
+// The entry of a tag is hash(tag); its state word carries the tag, so two tags that share an entry never share a record:
 //   * an owner CLAIMS the entry for a tag with a compare-and-swap before it posts the job (pl_look_claim): an empty entry or
 //     one whose record is COMPLETE (both halves there: nobody will write it any more) may be taken over, an entry whose jobs
 //     are still in flight may not (that post is skipped: the pop goes the long way, as it would without the lookahead);

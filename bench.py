@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 
 N_SIMD = 256 * 4                # SIMDs on the chip
 CLOCK_GHZ = 2.4                 # max shader clock
 FP64_PEAK_TFLOPS = 78.6         # vector fp64: 256 CUs x 128 flop/clk x 2.4 GHz
-PMC_FILE = "r05_pmc_summary.json"
+PMC_FILE = "r06_pmc_summary.json"
 CASES = os.path.join(ROOT, "data", "BenchmarkCases")
 # the reference's own wall-clock per case (unmodified reference imported in the build container,
 # one Python thread): seconds for PathPlanner() + a_star_plan(); None = did not finish / raises

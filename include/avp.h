@@ -261,13 +261,16 @@ int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the ker
  * Expansion lookahead (mode 1 only). A batch no larger than the chip leaves compute units without a problem of their
  * own as soon as the short searches finish -- BASELINE config[1] keeps 20 % of the CU time busy. With a lookahead
  * workspace the idle workgroups serve the running searches: the owner of a search posts the nodes at the top of its
- * open list (and, when a pop takes the long way, the three children it is most likely to be followed by), helpers compute
+ * open list (and children it expects to pop next: the three likely ones of a pop that takes the long way, and -- round 6 -- every
+ * child of the list's best nodes that beats the rest of the list, predicted from the parent's record; helpers chain such predictions
+ * down a dive themselves), helpers compute
  * everything the expansion of such a node needs before the sequential resolution (children poses, sub-step collision
  * checks, the Reeds-Shepp length of every child | the sampled and checked analytic shot -- two half-jobs, pure functions
  * of node pose, goal, map and parameters, evaluated by the same device code), and the owner reads the record when it
- * pops the node. The record store takes n x max_nodes x 4 x 708 bytes. Whether a record exists changes the time of a pop, never its result
+ * pops the node. The record store has a FIXED size since round 6 (262 144 records named by pose hash, 0.2 GB with the job rings --
+ * rounds 2 - 5: n x max_nodes x 2 832 bytes, which dropped the lookahead at large pop caps). Whether a record exists changes the time of a pop, never its result
  * (tests/test_gpu_lookahead.py: bit-identical records, paths and traces with and without).
- * avp_plan_look_bytes: bytes of the lookahead workspace for a batch of n (0 = the library would not use one: mode 2
+ * avp_plan_look_bytes: bytes of the lookahead workspace (the same for every n and max_nodes; 0 = the library would not use one: mode 2
  * batch, more than two problems per CU, more than 16 children). The helpers occupy every CU their launch leaves free until its last problem is done:
  * meant for a launch that has the device to itself, not for several concurrent launches on different streams.
  *

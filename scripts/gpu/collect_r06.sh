@@ -32,7 +32,6 @@ cp $O/slice_soak.json $P/r06_time_slicing_soak.json
 cat $O/slice_*_off.json $O/slice_*_on.json > $P/r06_time_slicing.jsonl
 tail -n 6 $O/pytest_gpu.log > $P/r06_pytest_gpu_tail.txt
 ls -la $P | grep r06
-cp $O/libm_microbench.txt $P/r06_libm_microbench.txt
 cp $O/pmc_icache.json $P/r06_pmc_icache.json
 cp $O/config_sweep.jsonl $P/r06_config_sweep.jsonl
 cp $O/cap_growth.jsonl $P/r06_cap_growth.jsonl

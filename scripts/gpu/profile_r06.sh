@@ -33,7 +33,7 @@ python scripts/pmc_sat_summary.py $O/pmc_sat > $O/pmc_saturating_batch.json 2> $
 python scripts/variant_bench.py --big 2048 > $O/phase_profile.json 2> $O/phase_profile.err
 for mode in 2 3 4; do timeout -k 10 300 python scripts/wave_profile.py --n 4096 --mode $mode > $O/wave_profile_m$mode.json 2> $O/wave_profile_m$mode.err; done
 timeout -k 10 300 python scripts/look_bench.py > $O/lookahead.json 2> $O/lookahead.err; head -c 300 $O/lookahead.json
-for v in default look_atomics look_fault5; do
+for v in default look_atomics look_fault5 look_small; do
   L=""; [ $v != default ] && L="--lib $V/libavp_hip_$v.so"
   [ $v = default -o -f $V/libavp_hip_$v.so ] && timeout -k 10 300 python scripts/look_soak.py $L --launches 300 > $O/soak_$v.json 2> $O/soak_$v.err
 done
@@ -42,7 +42,6 @@ for sl in off on; do for cfgs in "16384 3" "32768 2"; do set -- $cfgs
   timeout -k 10 300 python scripts/variant_bench.py --no-profile --big $1 --big-mode $2 --steps 1 --slice $sl > $O/slice_$1_m$2_$sl.json 2>/dev/null
 done; done
 timeout -k 10 400 python scripts/slice_soak.py --launches 60 --slice-pops 4 > $O/slice_soak.json 2> $O/slice_soak.err
-(cd scripts/microbench && for v in 1 2; do [ -x ./lv$v ] && ./lv$v; done > $O/libm_microbench.txt 2>&1)
 timeout -k 10 900 python tests/config_sweep.py > $O/config_sweep.jsonl 2> $O/config_sweep.err; cut -c1-300 $O/config_sweep.jsonl
 timeout -k 10 400 python scripts/cap_growth.py 300 1000 2000 3000 > $O/cap_growth.jsonl 2> $O/cap_growth.err; cut -c1-300 $O/cap_growth.jsonl
 rm -rf $O/pmc/*/*/*.db $O/pmc_sat/*/*/*/*.db $O/pmc_icache/*/*.db 2>/dev/null

@@ -1,6 +1,6 @@
 """A/B of the expansion lookahead (avp_plan_batch_ex) on the bench's config[1] workload: identical results, time with and
 without, the helpers' job counters, and the per-wave timeline of the pops that were served from a record (instrumented
-instantiation). Prints one JSON object (committed as profiles/r05_lookahead.json).
+instantiation). Prints one JSON object (committed as profiles/r06_lookahead.json).
 usage: python scripts/look_bench.py [n_problems] [cap]"""
 import json
 import os

@@ -1,4 +1,4 @@
-"""SQ counters of the planner kernels on a saturating batch (profiles/r05_pmc_saturating_batch.json).
+"""SQ counters of the planner kernels on a saturating batch (profiles/r06_pmc_saturating_batch.json).
 
     python scripts/pmc_sat_summary.py <dir with sub-directories sq/ and lane/, each holding the rocprofv3 csv output of
         rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python scripts/variant_bench.py --big 16384 --big-mode M --no-profile --steps 1>

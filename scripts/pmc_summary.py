@@ -1,6 +1,6 @@
-"""Fold the rocprofv3 PMC passes of `bench.py --pmc-mode` into profiles/r05_pmc_summary.json.
+"""Fold the rocprofv3 PMC passes of `bench.py --pmc-mode` into profiles/r06_pmc_summary.json.
 
-    python scripts/pmc_summary.py <dir with one sub-directory per pass> > profiles/r05_pmc_summary.json
+    python scripts/pmc_summary.py <dir with one sub-directory per pass> > profiles/r06_pmc_summary.json
 
 Passes (each its own run, --kernel-trace --pmc only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes):
   sq    SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS
