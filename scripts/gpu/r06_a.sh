@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r06a; rm -rf $O; mkdir -p $O
 V=automatedvaletparking_amd/variants
 timeout -k 10 600 python -m pytest tests/test_gpu_lookahead.py -q -m gpu > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
   for v in default $VARS; do
     L=""; [ $v != default ] && L="$PWD/$V/libavp_hip_$v.so"
     echo "== rep $rep $v"
