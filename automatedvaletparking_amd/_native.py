@@ -22,7 +22,7 @@ AVP_MAX_SUBS = 512
 EXPORTS = [
     "avp_version", "avp_sizeof_params", "avp_last_error", "avp_map_create", "avp_map_destroy", "avp_map_set_stream", "avp_sync",
     "avp_check_batch", "avp_corridor_batch", "avp_corridor_batch_v", "avp_trig_batch", "avp_libm_batch", "avp_ieee_batch", "avp_rs_optimal_batch",
-    "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch", "avp_plan_batch_profile", "avp_plan_batch_mode", "avp_plan_batch_ex", "avp_plan_look_bytes", "avp_plan_pick_mode", "avp_plan_slots", "avp_plan_group", "avp_plan_batch_staged", "avp_plan_set_slice_pops", "avp_plan_last_launch",
+    "avp_plan_workspace_bytes", "avp_plan_default_slots", "avp_sizeof_plan_result", "avp_plan_batch", "avp_plan_batch_profile", "avp_plan_batch_mode", "avp_plan_batch_ex", "avp_plan_look_bytes", "avp_plan_pick_mode", "avp_plan_slots", "avp_plan_group", "avp_plan_batch_staged", "avp_plan_set_slice_pops", "avp_plan_set_look_entries", "avp_plan_last_launch",
     "avp_hfield_id_capacity", "avp_hfield_queries", "avp_rasterize_edges", "avp_rasterize_edges_batch",
 ]
 

@@ -55,6 +55,7 @@ struct avp_map {
     void* counters;
     int32_t slice_pops;  // time slice of the group forms in pops (0 = never park a search); avp_plan_set_slice_pops
     int32_t last_sliced, last_mode;   // what the last planner call on this handle did: time-sliced? which kernel form (avp_plan_last_launch)
+    int32_t look_ent_log2;            // record store of the expansion lookahead: 2^this entries (avp_plan_set_look_entries)
 };
 
 extern "C" {
@@ -154,7 +155,7 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
     d.occ = (const uint8_t*)(base + oOcc);
     m->counters = base + oCnt;
     m->slice_pops = PW_SLICE_POPS;
-    m->last_sliced = 0; m->last_mode = 0;
+    m->last_sliced = 0; m->last_mode = 0; m->look_ent_log2 = PL_LOOK_ENT_LOG2;
     *out = m;
     return AVP_OK;
 }

@@ -240,11 +240,13 @@ struct PlLook {
 #define PL_LOOK_ENT_LOG2 18            // 262 144 records x 704 B = 184 MB (config[1] keeps ~3 000 alive; a launch zeroes the 2 MB of state words)
 #endif
 #define PL_LOOK_ENTRIES (1u << PL_LOOK_ENT_LOG2)
-static inline __host__ __device__ size_t pl_look_state_bytes() { return pl_al((size_t)PL_LOOK_ENTRIES * 8); }
-static inline __host__ __device__ size_t pl_look_bytes(int32_t helper_blocks)
+// (the number of entries is a property of the launch -- PlLook::emask --: avp_plan_set_look_entries shrinks the store for the tests that
+//  want tags to collide and entries to be taken over all the time; entries = a power of two)
+static inline __host__ __device__ size_t pl_look_state_bytes(uint32_t entries) { return pl_al((size_t)entries * 8); }
+static inline __host__ __device__ size_t pl_look_bytes(uint32_t entries, int32_t helper_blocks)
 {
-    return 1024 + 2 * (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_look_state_bytes() +
-           (size_t)PL_LOOK_ENTRIES * PL_REC_WORDS * 8 + (size_t)helper_blocks * PL_LOOK_HRS;
+    return 1024 + 2 * (size_t)PL_JCAP * PL_JOB_WORDS * 8 + pl_look_state_bytes(entries) +
+           (size_t)entries * PL_REC_WORDS * 8 + (size_t)helper_blocks * PL_LOOK_HRS;
 }
 #define PL_LOOK_NODE_MAX (1 << 30)     // (records are named by pose, not by arena index: no limit of their own)
 #define PL_LOOK_PID_MAX (1 << 30)

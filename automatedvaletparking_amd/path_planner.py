@@ -90,7 +90,7 @@ class BatchPlanner:
     def __init__(self, device_map: _native.DeviceMap, max_nodes: int = 65536, n_slots: Optional[int] = None,
                  max_path: int = 512, mode: int = 0, lookahead: Optional[bool] = None,
                  longest_first: bool = False, stage_pops: int = 16, time_slice: Optional[bool] = None,
-                 slice_pops: Optional[int] = None):
+                 slice_pops: Optional[int] = None, look_entries_log2: int = 0):
         """mode: 0 = the library's choice by batch size, 1 = one workgroup per problem, 2 = one wave, 3 = a pair of waves,
         4 = four waves per problem (include/avp.h: avp_plan_batch_mode), STAGED = avp_plan_batch_staged: every problem in
         the wave form for stage_pops pops, the searches still running then planned again in the form that suits their
@@ -125,6 +125,7 @@ class BatchPlanner:
         self.last_time_sliced = False
         self._look = None
         self.last_lookahead = False
+        self.look_entries_log2 = int(look_entries_log2)      # diagnostics: 2^this records in the lookahead's store (0 = the library's 2^18)
 
     LOOK_BYTES_MAX = 1 << 30           # (the record store has a fixed size since round 6 -- 262 144 records, 0.2 GB -- whatever the batch and the node arena)
     LOOK_FREE_FRAC = 0.25              # ... and at most this share of the device memory that is free right now
@@ -156,6 +157,7 @@ class BatchPlanner:
         whenever the library supports it for the batch (and raises if the store cannot be allocated)."""
         if self.lookahead is False:
             return None
+        _native.chk(_native.lib().avp_plan_set_look_entries(self.dm.h, C.c_int32(self.look_entries_log2)), "avp_plan_set_look_entries")      # (state of the handle: set for every launch)
         nbytes = int(_native.lib().avp_plan_look_bytes(self.dm.h, C.c_int64(n), C.c_int32(self.max_nodes)))
         if nbytes <= 0:
             return None

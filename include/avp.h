@@ -283,6 +283,9 @@ int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the ker
  * avp_plan_batch_ex = avp_plan_batch_mode + the lookahead workspace (look_ws NULL = none) + the order (NULL = none).
  */
 int64_t avp_plan_look_bytes(avp_map* map, int64_t n, int32_t max_nodes);
+/* Diagnostics: 2^log2_entries records in the lookahead's store on this handle from now on (0 = the default, 2^18; else 6 .. 24). With a
+ * small store tags collide and entries are taken over all the time; results must not depend on it. No reference counterpart. */
+int32_t avp_plan_set_look_entries(avp_map* map, int32_t log2_entries);
 int32_t avp_plan_batch_ex(avp_map* map, const double* starts, const double* goals, int64_t n, int32_t n_slots,
                           int32_t max_nodes, void* workspace, int64_t workspace_bytes, avp_plan_result* results,
                           double* paths, int32_t max_path, double* trace, int32_t max_trace, int32_t mode,

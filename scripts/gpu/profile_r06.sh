@@ -33,10 +33,12 @@ python scripts/pmc_sat_summary.py $O/pmc_sat > $O/pmc_saturating_batch.json 2> $
 python scripts/variant_bench.py --big 2048 > $O/phase_profile.json 2> $O/phase_profile.err
 for mode in 2 3 4; do timeout -k 10 300 python scripts/wave_profile.py --n 4096 --mode $mode > $O/wave_profile_m$mode.json 2> $O/wave_profile_m$mode.err; done
 timeout -k 10 300 python scripts/look_bench.py > $O/lookahead.json 2> $O/lookahead.err; head -c 300 $O/lookahead.json
-for v in default look_atomics look_fault5 look_small; do
+for v in default look_atomics look_fault5; do
   L=""; [ $v != default ] && L="--lib $V/libavp_hip_$v.so"
   [ $v = default -o -f $V/libavp_hip_$v.so ] && timeout -k 10 300 python scripts/look_soak.py $L --launches 300 > $O/soak_$v.json 2> $O/soak_$v.err
 done
+# the PRODUCT library with a record store of 1 024 entries (avp_plan_set_look_entries): tags collide, entries change hands all the time
+timeout -k 10 300 python scripts/look_soak.py --entries-log2 10 --launches 300 > $O/soak_look_small.json 2> $O/soak_look_small.err
 timeout -k 10 500 python scripts/large_map_bench.py > $O/large_maps.json 2> $O/large_maps.err
 for sl in off on; do for cfgs in "16384 3" "32768 2"; do set -- $cfgs
   timeout -k 10 300 python scripts/variant_bench.py --no-profile --big $1 --big-mode $2 --steps 1 --slice $sl > $O/slice_$1_m$2_$sl.json 2>/dev/null

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--launches", type=int, default=300)
 ap.add_argument("--n", type=int, default=256)
+ap.add_argument("--entries-log2", type=int, default=0, help="records in the lookahead's store = 2^this (0 = the library's default): a small store makes tags collide and entries change hands")
 a = ap.parse_args()
 if a.lib:
     os.environ["AVP_HIP_LIB"] = os.path.abspath(a.lib)
@@ -48,7 +49,7 @@ off = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=1, looka
 r, p, _ = off.plan_dev(stt, got)
 torch.cuda.synchronize()
 want = digest(r, p)
-on = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=1, lookahead=True)
+on = path_planner.BatchPlanner(dm, max_nodes=16384, max_path=256, mode=1, lookahead=True, look_entries_log2=a.entries_log2)
 bad, used, ms = 0, [], []
 for k in range(a.launches):
     t0 = time.perf_counter()
@@ -60,4 +61,7 @@ for k in range(a.launches):
 print(json.dumps({"lib": os.path.basename(_native.LIB_PATH), "launches": a.launches, "problems": a.n, "digest_without_lookahead": want,
                   "launches_with_a_different_digest": int(bad), "lookahead_used": bool(on.last_lookahead),
                   "ms_median": float(np.median(ms)), "ms_min": float(min(ms)), "ms_max": float(max(ms)),
-                  "records_used_min_median_max": [int(min(used)), int(np.median(used)), int(max(used))]}))
+                  "records_used_min_median_max": [int(min(used)), int(np.median(used)), int(max(used))],
+                  "record_store_entries": 1 << (a.entries_log2 or 18), "lookahead_workspace_bytes": int(on._look.numel()),
+                  "last_launch": {"claims_refused_entry_busy": int(on._look[:1024].cpu().numpy().view(np.uint64)[78]),
+                                  "copies_refused_by_seqlock": int(on._look[:1024].cpu().numpy().view(np.uint64)[79])}}))

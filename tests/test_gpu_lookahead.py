@@ -35,6 +35,32 @@ def test_lookahead_changes_no_result(vehicle, cfg, n):
     _same_results(on.plan(st, go, max_trace=cap), a)        # a second call on the same (re-zeroed) lookahead workspace
 
 
+@pytest.mark.parametrize("log2", [6, 10])
+def test_tiny_record_store_changes_no_result(vehicle, cfg, log2):
+    """The record store is a direct-mapped table named by pose hash: with 64 or 1 024 entries for 256 searches tags collide, claims are
+    refused because an entry's jobs are in flight, complete records are taken over while their owner may be copying them (seqlock), and
+    readers find other poses' records under their tag (key check). None of it may change a result: identical to the launch without the
+    lookahead, twice in a row on the same workspace, and the store does get used."""
+    from automatedvaletparking_amd import _native, path_planner
+    m = case_map_from_gold(1)
+    cap = 400
+    dm = _native.DeviceMap(m, vehicle, cfg, max_pops=cap)
+    st, go = _pairs(m, dm, 256, 4242)
+    off = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1, lookahead=False)
+    tiny = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1, lookahead=True, look_entries_log2=log2)
+    a = off.plan(st, go, max_trace=cap)
+    for _ in range(2):
+        b = tiny.plan(st, go, max_trace=cap)
+        assert tiny.last_lookahead and tiny._look.numel() < (32 << 20)
+        _same_results(a, b)
+        c = tiny._look[:1024].cpu().numpy().view(np.uint64)
+        assert int(c[0]) > 0 and int(c[8]) > 0 and int(c[78]) > 0          # jobs posted, records used, claims refused (entry busy)
+    # back to the default store on the same handle
+    big = path_planner.BatchPlanner(dm, max_nodes=8192, mode=1, lookahead=True)
+    _same_results(a, big.plan(st, go, max_trace=cap))
+    assert big._look.numel() > (128 << 20)
+
+
 def test_lookahead_vs_oracle(vehicle, cfg):
     import os
     from concurrent.futures import ThreadPoolExecutor
