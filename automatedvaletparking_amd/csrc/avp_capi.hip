@@ -76,8 +76,10 @@ AVP_EXPORT int32_t avp_map_create(const avp_params* params, const uint8_t* occ, 
                        const double* ys, const double boundary[4], const int32_t* obs_ix, const int32_t* obs_iy,
                        int32_t P, int32_t device, avp_map** out)
 {
-    if (!params || !occ || !xs || !ys || !boundary || !out || nx < 2 || ny < 2 || nx > 8191 || ny > 8191 || P < 0 ||
-        (P > 0 && (!obs_ix || !obs_iy)))
+    // (round 6: up to AVP_MAX_NODES_PER_AXIS nodes per axis and 2^30 cells; rounds 1 - 5: 8 191 -- the cell indices the compacting kernels pack
+    //  in 13 bits. Those kernels still serve maps up to 8 191 nodes per axis; larger ones take the lane-per-pose forms: same results)
+    if (!params || !occ || !xs || !ys || !boundary || !out || nx < 2 || ny < 2 || nx > AVP_MAX_NODES_PER_AXIS || ny > AVP_MAX_NODES_PER_AXIS ||
+        (int64_t)nx * ny > ((int64_t)1 << 30) || P < 0 || (P > 0 && (!obs_ix || !obs_iy)))
         return set_err(AVP_ERR_ARG, "avp_map_create: bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(AVP_ERR_NOGPU, "no HIP device visible");
@@ -200,7 +202,7 @@ AVP_EXPORT int32_t avp_check_batch(avp_map* map, int32_t kind, const double* x, 
         const double diag = sqrt((map->params.fp_xf - map->params.fp_xr) * (map->params.fp_xf - map->params.fp_xr) +
                                  (map->params.fp_yl - map->params.fp_yr) * (map->params.fp_yl - map->params.fp_yr));
         const bool rows_ok = diag / d.dy + 3.0 < 64.0;
-        if (variant == 1 || !rows_ok) {
+        if (variant == 1 || !rows_ok || d.nx > 8191 || d.ny > 8191) {        // (the production kernel packs cell indices in 13 bits)
             const int64_t blocks = (n + 255) / 256;
             hipLaunchKernelGGL(check_distance_naive_kernel, dim3((unsigned)blocks), dim3(256), 0, map->stream, d, map->params, x, y, th, n, out);
         } else {

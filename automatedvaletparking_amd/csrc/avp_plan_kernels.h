@@ -301,6 +301,7 @@ struct PlChkEnv {
     double fp_xr, fp_xf, fp_yr, fp_yl;                // inflated footprint (map/costmap.py:97-101)
     double circ_rd, circ_cf, circ_cr;                 // two-circle model (collision_check.py:92-98)
     uint32_t lX, lY, lBits, maybe_wide;               // LDS addresses of the staged tables (STAGE); maybe_wide: a footprint's AABB can span > 64 map columns or > 2 bitmap words of rows on this map
+    uint32_t big, big_pad;                            // more than 8 191 nodes on an axis: cell indices do not fit the queue's 13 bits -- the passes take the lane-per-pose form
     const double* gX; const double* gY; const uint64_t* gBits;   // ... or the tables in HBM / L2
 };
 // the map tables as a collision pass reads them: LDS copies (STAGE) or through L1 / L2
@@ -327,14 +328,15 @@ __device__ __forceinline__ void pl_chk_env_fill(PlChkEnv& e, const DevMap& m, co
         const double diag = sqrt((p.fp_xf - p.fp_xr) * (p.fp_xf - p.fp_xr) + (p.fp_yl - p.fp_yr) * (p.fp_yl - p.fp_yr));
         e.maybe_wide = (diag / m.dx + 3.0 < 64.0 && diag / m.dy + 3.0 < 64.0) ? 0u : 1u;
     }
+    e.big = (m.nx > 8191 || m.ny > 8191) ? 1u : 0u; e.big_pad = 0;
     e.gX = m.X; e.gY = m.Y; e.gBits = m.colBits;
 }
 
 // ---- lane-per-pose collision test through the column bitmaps (the fallback of a pass; the two-circle model) -----
-template <class TX, class TB>
+template <int KIND, class TX, class TB>
 __device__ __forceinline__ bool pl_check_pose(const PlChkEnv& e, TX X, TX Y, TB colBits, double x, double y, double th, double cs, double sn)
 {
-    if (e.kind == 1) {
+    if constexpr (KIND == 1) {
         const double Rd = e.circ_rd;
         const AvpRd2 rd2 = avp_circle_rd2(Rd);
         const double fx = x + e.circ_cf * cs, fy = y + e.circ_cf * sn;
@@ -362,7 +364,7 @@ __device__ __forceinline__ bool pl_check_pose(const PlChkEnv& e, TX X, TX Y, TB 
             }
         }
         return false;
-    }
+    } else {
     Footprint f;
     avp_footprint_setup_cs(e, x, y, cs, sn, f);
     double xmin, xmax, ymin, ymax;
@@ -384,6 +386,7 @@ __device__ __forceinline__ bool pl_check_pose(const PlChkEnv& e, TX X, TX Y, TB 
         }
     }
     return false;
+    }
 }
 
 // ---- shared (LDS) state of one problem ----------------------------------------------------------
@@ -425,7 +428,7 @@ struct PlWaveChkT {
     uint32_t hit[PL_WPOSE];
     double pose[PL_WPOSE][5];         // x, y, theta, cos, sin of the poses of the pass (staged by the caller)
     int32_t qn, over;
-    uint32_t q[QCAP];                 // pose << 26 | ix << 13 | iy   (PL_WPOSE <= 8 poses; nx, ny <= 8191: avp_map_create's limit)
+    uint32_t q[QCAP];                 // pose << 26 | ix << 13 | iy   (PL_WPOSE <= 8 poses; nx, ny <= 8191: larger maps take the lane-per-pose form, PlChkEnv::big)
 };
 typedef PlWaveChkT<PL_WQCAP> PlWaveChk;
 
@@ -1373,6 +1376,26 @@ __device__ __noinline__ void pl_check_gather_wide(AVP_LDS const PlChkEnv* envp, 
     }
 }
 
+// The lane-per-pose form of a pass, a called function of its own (round 6: two call sites -- inlined twice it cost the group forms a dozen
+// spill slots): lanes lo .. hi-1 each walk the map columns under their pose's footprint serially (pl_check_pose); wc.hit[lane] = the result.
+// Used for the two-circle model, for maps beyond the queue's 13-bit cell indices, and for a single pose whose candidates overflow the queue.
+template <bool STAGE, int QCAP, int KIND>
+__device__ __noinline__ void pl_check_lanes_k(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp, int lo, int hi)
+{
+    const PlChkEnv& env = *(const PlChkEnv*)envp;
+    PlWaveChkT<QCAP>& wc = *(PlWaveChkT<QCAP>*)wcp;
+    const PlTabs<STAGE> mt(env);
+    const int lane = threadIdx.x & 63;
+    if (lane >= lo && lane < hi)
+        wc.hit[lane] = pl_check_pose<KIND>(env, mt.X, mt.Y, mt.bits, wc.pose[lane][0], wc.pose[lane][1], wc.pose[lane][2], wc.pose[lane][3], wc.pose[lane][4]) ? 1u : 0u;
+}
+template <bool STAGE, int QCAP>
+__device__ __forceinline__ void pl_check_lanes(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp, int lo, int hi)
+{
+    if (((const PlChkEnv*)envp)->kind == 1) pl_check_lanes_k<STAGE, QCAP, 1>(envp, wcp, lo, hi);      // (uniform: a per-map constant)
+    else pl_check_lanes_k<STAGE, QCAP, 0>(envp, wcp, lo, hi);
+}
+
 template <bool STAGE, int QCAP, bool FAST>
 __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS PlWaveChkT<QCAP>* wcp, int count, AVP_LDS uint32_t* out_hit_p)
 {
@@ -1381,8 +1404,10 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
     uint32_t* out_hit = (uint32_t*)out_hit_p;
     const PlTabs<STAGE> mt(env);
     const int lane = threadIdx.x & 63;
-    if (env.kind == 1) {
-        if (lane < count) out_hit[lane] = pl_check_pose(env, mt.X, mt.Y, mt.bits, wc.pose[lane][0], wc.pose[lane][1], wc.pose[lane][2], wc.pose[lane][3], wc.pose[lane][4]) ? 1u : 0u;
+    if (env.kind == 1 || env.big) {          // the two-circle model / a map beyond the queue's 13-bit cell indices: a lane per pose (same booleans)
+        pl_check_lanes<STAGE, QCAP>(envp, wcp, 0, count);
+        wave_sync();
+        if (lane < count) out_hit[lane] = wc.hit[lane];
         wave_sync();
         return;
     }
@@ -1499,7 +1524,7 @@ __device__ __noinline__ void pl_check_pass(AVP_LDS const PlChkEnv* envp, AVP_LDS
         if (wc.over) {
             if (hi - lo > 1) { span = (hi - lo + 1) >> 1; continue; }
             // one pose with more candidates than the queue holds: a lane walks its columns serially
-            if (lane == lo) wc.hit[lane] = pl_check_pose(env, mt.X, mt.Y, mt.bits, wc.pose[lane][0], wc.pose[lane][1], wc.pose[lane][2], wc.pose[lane][3], wc.pose[lane][4]) ? 1u : 0u;
+            pl_check_lanes<STAGE, QCAP>(envp, wcp, lo, lo + 1);
         } else {
             pl_check_narrow<STAGE, QCAP, FAST>(envp, wcp);
         }

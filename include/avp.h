@@ -23,6 +23,8 @@ extern "C" {
 
 #define AVP_VERSION 110
 #define AVP_MAX_STEER 32                 /* steering angles: 2 x 32 = 64 children per expansion, one lane of a wave each */
+#define AVP_MAX_NODES_PER_AXIS 32767      /* nodes per map axis (3.2 km at 0.1 m; and at most 2^30 cells): beyond 8 191 the lane-per-pose kernel forms
+                                            run; the bound keeps heuristic distances (<= 14 per cell) inside the 20 bits of the alias-owner key */
 #define AVP_MAX_SUBS 512                 /* children x sub-steps checked per expansion (default: 10 x 3)             */
 #define AVP_RS_MAXSEG 5
 

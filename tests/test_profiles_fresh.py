@@ -147,7 +147,10 @@ def test_compiler_remarks_of_the_planner_kernels():
         # measured harmless: profiles/r03 vs r04 group-form times), the L2-backed ones -- two more pointers live in every phase -- at 3 .. 5,
         # and the instrumented (PROFILE) instantiations carry their timers in registers across calls and may spill dozens: they are
         # diagnostics, never launched by the product path. A product instantiation above these limits fails here.
-        lim = 1 if k.startswith("plan_wave_kernel<true, false") else 5 if k.startswith("plan_wave_kernel<false, false") else 64
+        # Round 6: the kernel function's own body keeps 0 - 2 (LDS-staged) / 4 - 6 (L2-backed) slots across the phase calls (a value or two per pop);
+        # what matters is inside the phases, and there the scratch traffic FELL: pl_check_pass 51 -> 19 store / reload pairs (all callee-saves now)
+        # once the lane-per-pose form it inlined twice became a called function -- the group forms got 4 - 9 % faster for it (profiles/NOTEBOOK.md).
+        lim = 2 if k.startswith("plan_wave_kernel<true, false") else 6 if k.startswith("plan_wave_kernel<false, false") else 64
         assert rows[k]["VGPRs Spill"] <= lim, (k, rows[k])
     assert rows["plan_kernel<true, false, false>"]["VGPRs Spill"] == 0
     assert rows["plan_kernel<true, false, true>"]["VGPRs Spill"] <= 32
