@@ -194,7 +194,7 @@ def collective_proof(torch, dist, rank, local, world, dev):
     dist.all_gather_into_tensor(allr, mine)
     rows = [bytes(allr[i * 256:(i + 1) * 256].cpu().numpy().tolist()).rstrip(b"\0").decode() for i in range(world)]
     devices = [dict(zip(("rank", "local_device", "uuid", "pci", "host", "name"), r.split("|"))) for r in rows]
-    distinct = len({(d["host"], d["uuid"] or d["pci"]) for d in devices})
+    distinct = len({(d["host"], d["uuid"], d["pci"]) for d in devices})          # (uuid AND PCI address: a runtime that reports one uuid for every device still tells them apart)
     return {"backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()), "devices": devices, "distinct_devices": distinct,
             "ranks_in_order": [int(d["rank"]) for d in devices] == list(range(world)),
             "note": "gathered through all_gather_into_tensor on the process group the bench's collectives use"}
