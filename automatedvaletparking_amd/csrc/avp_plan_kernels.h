@@ -236,6 +236,9 @@ struct PlLook {
 //     trip through the job ring, so a copy framed by two equal state words is a copy of ONE record. The key words inside the
 //     record (exact pose bits, problem, goal) are still checked: they are what ties the record to the node's pose.
 // Whether a record exists, is evicted or is refused changes the time of a pop, never a result (tests/test_gpu_lookahead.py).
+#ifndef PL_LOOK_RATIO_X4
+#define PL_LOOK_RATIO_X4 4           // the owners use the lookahead once 4 x helpers >= this x the workgroups that are no helpers yet (0: from the first helper on; 2 / 4 / 8 / 12 measured, scripts/look_scale.py)
+#endif
 #ifndef PL_LOOK_ENT_LOG2
 #define PL_LOOK_ENT_LOG2 18            // 262 144 records x 704 B = 184 MB (config[1] keeps ~3 000 alive; a launch zeroes the 2 MB of state words)
 #endif
@@ -2200,7 +2203,11 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     const int d = lane - 32 - PL_LOOK_KSPAN, sc = (int)cn.steer_i + d;
     bool kid = kids && lane >= 32 && lane < 32 + PL_LOOK_KIDS && cn.steer_i >= 0 && sc >= 0 && sc < p.n_steer;
     const bool cand = lane < 32 && node != 0xffffffffu;
-    const unsigned long long helpers = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
+    const unsigned long long helpers_all = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
+    // (too few helpers for the searches still running -- a large batch before its tail: their records would all come late, and the
+    //  bookkeeping of a pop that finds none costs more than it gains: as if there were none yet. The count of helpers only grows.)
+    const long long owners_left = (long long)look.main_blocks - (long long)helpers_all;
+    const unsigned long long helpers = 4ll * (long long)helpers_all >= (long long)PL_LOOK_RATIO_X4 * owners_left ? helpers_all : 0ull;
     const long long backlog = max((long long)(ta - ha), (long long)(tb - hb));
     if (lane == 0) { s.look_calm = (helpers != 0 && backlog <= PL_LOOK_BACKLOG) ? 1 : 0; s.look_live = helpers != 0 ? 1 : 0; }   // (calm: the helpers keep up, a pending record is worth a short wait)
     // nobody to serve / a ring is nearly full: every owner may post up to PL_LOOK_TOP + PL_LOOK_KIDS + 2 jobs from the same (stale)

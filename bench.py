@@ -519,6 +519,28 @@ def extra_without_lookahead(b, g0, wcfg, cap, recs, outs):
     return x0
 
 
+def extra_lookahead_batch_sizes(b):
+    """The lookahead on batches LARGER than the chip (workgroup form, config[1]'s sampler, pop cap 1000): helpers exist only in the
+    batch's tail, and the owners use them once they outnumber the workgroups still planning (PL_LOOK_RATIO_X4). Per size: ms with and
+    without, identical results."""
+    from automatedvaletparking_amd import workloads
+    out = {"workload": "Case1 map, n random start/goal pairs (config[1]'s sampler), pop cap %d, one workgroup per problem" % POP_CAP, "sizes": {}}
+    for n in (512, 1024, 1536, 2560):
+        m, st, go = workloads.case1_pairs(b.cfg, b.checker(POP_CAP), n)
+        e, keep = {}, {}
+        for key, look in (("without", False), ("with", None)):
+            g = b.group(m, b.cfg, st, go, POP_CAP, mode=1, lookahead=look)
+            sec, o = b.time_group(g, reps=2)
+            keep[key] = (records(o[0], g.n), o[1].cpu().numpy())
+            e["ms_" + key] = sec * 1e3
+            e["lookahead_" + key] = bool(g.bp.last_lookahead)
+            del g
+        e["identical_results"] = same_results(keep["without"][0], keep["without"][1], keep["with"][0], keep["with"][1])
+        e["pops"] = int(keep["with"][0]["n_pops"].sum())
+        out["sizes"][str(n)] = e
+    return out
+
+
 def extra_workload(b, name):
     """Another BASELINE workload (c3 = config[2], c5 = config[4]) on this GPU."""
     torch = b.torch
@@ -906,6 +928,7 @@ def main():
                         out[name] = extra_workload(b, name)
                 extra_batch4096(b, out)
                 out["cap_sweep"] = extra_cap_sweep(b)
+                out["lookahead_batch_sizes"] = extra_lookahead_batch_sizes(b)
                 out["cases20"] = extra_cases20(b)
                 out["single_plan_latency_ms"] = extra_single_plan_latency(b)
                 out["single_plan_note"] = "PathPlanner.path_planning() on BenchmarkCases/Case1.csv, host call to split path (uploads, launch, download, split_path), mean of 5; reference: 52 s"

@@ -42,7 +42,7 @@ def main():
         ("`check_distance_kernel` checks/s (VALU-busy) · near-miss point tests/s (VALU ceiling)", "2.71·10⁹ (0.44) · 7.4·10¹⁰", "%s (%.2f) · %s (%s)" % (sci(rc["checks_per_s"]), rc["frac"], sci(rc["near_miss_poses"]["point_tests_per_s"], 1), sci(rc["near_miss_poses"]["valu_ceiling_point_tests_per_s"], 1))),
         ("`check_circle_kernel` · `rs_optimal_kernel` · `corridor_compact_kernel` per second", "5.5·10⁹ · 8.2·10⁸ · 4.7·10⁸",
          "%s · %s · **%s**" % (sci(sec[("circle", 0)]["checks_per_s"], 1), sci(sec[("rs_optimal (lengths only)", 0)]["solves_per_s"], 1), sci(sec[("corridor", 0)]["waypoints_per_s"], 1))),
-        ("CPU port (oracle): 1 core · all cores of the container's quota (%d) plans/s · GPU / CPU in expansions/s" % d["cpu_baseline_all_cores"]["cores"], "63 · 986 · 11.0",
+        ("CPU port (oracle): 1 core · %d threads on the container's quota of %d CPUs, plans/s · GPU / CPU in expansions/s" % (d["cpu_baseline_all_cores"]["cores"], d["cpu_baseline_all_cores"].get("cpu_quota", d["cpu_baseline_all_cores"]["cores"])), "63 · 986 · 11.0",
          "%.0f · %.0f · %.1f" % (d["cpu_baseline"]["value"], d["cpu_baseline_all_cores"]["value"], d["cpu_baseline_all_cores"]["gpu_over_cpu_all_cores_expansions"])),
     ]
     tab = "| | round 5 | round 6 |\n|---|---|---|\n" + "\n".join("| %s | %s | %s |" % r_ for r_ in rows) + "\n"

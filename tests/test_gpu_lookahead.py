@@ -19,7 +19,7 @@ def _pairs(m, dm, n, seed):
     return free[0:2 * n:2], free[1:2 * n:2]
 
 
-@pytest.mark.parametrize("n", [1, 5, 40, 256, 300, 512])
+@pytest.mark.parametrize("n", [1, 5, 40, 256, 300, 512, 900, 1600])          # (900, 1 600: helpers only in the batch's tail, behind the helpers : owners gate)
 def test_lookahead_changes_no_result(vehicle, cfg, n):
     from automatedvaletparking_amd import _native, path_planner
     m = case_map_from_gold(1)
@@ -82,7 +82,7 @@ def test_lookahead_vs_oracle(vehicle, cfg):
         _assert_same_as_oracle(r, w)
 
 
-def test_lookahead_not_used_for_large_batches(vehicle, cfg):
+def test_lookahead_only_for_batches_of_the_workgroup_form(vehicle, cfg):
     import ctypes as C
     from automatedvaletparking_amd import _native
     m = case_map_from_gold(1)
@@ -90,7 +90,10 @@ def test_lookahead_not_used_for_large_batches(vehicle, cfg):
     L = _native.lib()
     ncu = int(L.avp_plan_slots(dm.h, C.c_int32(1)))
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu), C.c_int32(4096))) > 0
-    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu + 1), C.c_int32(4096))) == 0       # every CU busy with its own problems
+    # (rounds 2 - 5 stopped at two problems per CU; since round 6 every batch the library plans in the workgroup form gets helpers in its tail)
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(2 * ncu + 1), C.c_int32(4096))) > 0
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(11 * ncu - 1), C.c_int32(4096))) > 0
+    assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(11 * ncu), C.c_int32(4096))) == 0          # quad form: no helpers
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(32 * ncu), C.c_int32(4096))) == 0          # wave form: no helpers
     assert int(L.avp_plan_look_bytes(dm.h, C.c_int64(64 * ncu), C.c_int32(4096))) == 0
 

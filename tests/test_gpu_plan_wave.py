@@ -71,7 +71,7 @@ def test_wave_form_auto_mode_and_slots(vehicle, cfg):
     ncu = int(L.avp_plan_slots(dm.h, C.c_int32(1)))
     assert int(L.avp_plan_slots(dm.h, C.c_int32(2))) == int(L.avp_plan_group(C.c_int32(2))) * ncu
     pick = lambda k: int(L.avp_plan_pick_mode(dm.h, C.c_int64(k * ncu), C.c_int32(0)))
-    assert (pick(2), pick(11), pick(12), pick(23), pick(24), pick(79), pick(80), pick(200)) == (1, 1, 4, 4, 3, 3, 2, 2)
+    assert (pick(2), pick(10), pick(11), pick(23), pick(24), pick(79), pick(80), pick(200)) == (1, 1, 4, 4, 3, 3, 2, 2)
     rng = np.random.default_rng(8)
     b = m.boundary
     n = 600
