@@ -236,8 +236,29 @@ struct PlLook {
 //     trip through the job ring, so a copy framed by two equal state words is a copy of ONE record. The key words inside the
 //     record (exact pose bits, problem, goal) are still checked: they are what ties the record to the node's pose.
 // Whether a record exists, is evicted or is refused changes the time of a pop, never a result (tests/test_gpu_lookahead.py).
+// When helpers are scarce -- fewer than PL_LOOK_SCARCE_X4 / 4 per workgroup still planning: the tail of a batch larger than the chip, or a batch
+// of mostly long searches -- the blanket posting of the first PL_LOOK_TOP heap slots only lengthens the queue the urgent jobs wait in: the records
+// all come late (768 problems: 1.7 % record pops at 106 k jobs, 36 ms against 34 without the lookahead). Then an owner posts the first
+// PL_LOOK_TOP_BUSY slots while more than PL_LOOK_BACKLOG jobs wait, and nothing while more than PL_LOOK_BACKLOG2 do (768 problems: 36 % record
+// pops, 26.5 ms; scripts/look_scale.py, profiles/NOTEBOOK.md). With that no gate on the helpers : owners ratio is needed (PL_LOOK_RATIO_X4 = 0;
+// 2 .. 12 measured before the narrowing existed: 4 was the best then).
+#ifndef PL_LOOK_SCARCE_X4
+#define PL_LOOK_SCARCE_X4 8          // "scarce": 4 x helpers < this x the workgroups that are no helpers yet
+#endif
+#ifndef PL_LOOK_B2_DIV
+#define PL_LOOK_B2_DIV 0             // (> 0: PL_LOOK_BACKLOG2 = helpers / this, at least 8 -- measured, no better than the fixed 32)
+#endif
+#ifndef PL_LOOK_TOP_BUSY
+#define PL_LOOK_TOP_BUSY 8
+#endif
+#ifndef PL_LOOK_BACKLOG2
+#define PL_LOOK_BACKLOG2 32
+#endif
+#ifndef PL_LOOK_TOP_BUSY2
+#define PL_LOOK_TOP_BUSY2 0
+#endif
 #ifndef PL_LOOK_RATIO_X4
-#define PL_LOOK_RATIO_X4 4           // the owners use the lookahead once 4 x helpers >= this x the workgroups that are no helpers yet (0: from the first helper on; 2 / 4 / 8 / 12 measured, scripts/look_scale.py)
+#define PL_LOOK_RATIO_X4 0           // the owners use the lookahead once 4 x helpers >= this x the workgroups that are no helpers yet (0: from the first helper on)
 #endif
 #ifndef PL_LOOK_ENT_LOG2
 #define PL_LOOK_ENT_LOG2 18            // 262 144 records x 704 B = 184 MB (config[1] keeps ~3 000 alive; a launch zeroes the 2 MB of state words)
@@ -2202,7 +2223,6 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     if (lane < 5) c = pl_ld64(look.ctrl + (lane == 0 ? 48 : lane == 1 ? 0 : lane == 2 ? 16 : lane == 3 ? 64 : 80));
     const int d = lane - 32 - PL_LOOK_KSPAN, sc = (int)cn.steer_i + d;
     bool kid = kids && lane >= 32 && lane < 32 + PL_LOOK_KIDS && cn.steer_i >= 0 && sc >= 0 && sc < p.n_steer;
-    const bool cand = lane < 32 && node != 0xffffffffu;
     const unsigned long long helpers_all = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
     // (too few helpers for the searches still running -- a large batch before its tail: their records would all come late, and the
     //  bookkeeping of a pop that finds none costs more than it gains: as if there were none yet. The count of helpers only grows.)
@@ -2214,6 +2234,11 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     // reading of the counters, so the margin is several times owners x jobs (512 x 21 = 10 752) -- an unread entry is never overwritten
     if (helpers == 0 || backlog > PL_JCAP - 16384) return;
     if (backlog > PL_LOOK_BACKLOG) kid = false;
+    // (helpers behind: only the first PL_LOOK_TOP_BUSY heap slots are worth a job -- the nodes popped next; the rest of the list would
+    //  only lengthen the queue the urgent jobs wait in)
+    const bool scarce = 4ll * (long long)helpers_all < (long long)PL_LOOK_SCARCE_X4 * owners_left;      // fewer helpers per running search than the blanket posting needs
+    const long long backlog2 = PL_LOOK_B2_DIV > 0 ? max(8ll, (long long)helpers_all / max(PL_LOOK_B2_DIV, 1)) : (long long)PL_LOOK_BACKLOG2;
+    const bool cand = lane < 32 && node != 0xffffffffu && (!scarce || ((backlog <= PL_LOOK_BACKLOG || lane < PL_LOOK_TOP_BUSY) && (backlog <= backlog2 || lane < PL_LOOK_TOP_BUSY2)));
     // the pose names the record: a node's own, or the child's the children stage will compute (hybrid_a_star.py:134-151)
     double x = 0.0, y = 0.0, th = 0.0;
     int gear = 1;

@@ -521,7 +521,7 @@ def extra_without_lookahead(b, g0, wcfg, cap, recs, outs):
 
 def extra_lookahead_batch_sizes(b):
     """The lookahead on batches LARGER than the chip (workgroup form, config[1]'s sampler, pop cap 1000): helpers exist only in the
-    batch's tail, and the owners use them once they outnumber the workgroups still planning (PL_LOOK_RATIO_X4). Per size: ms with and
+    batch's tail, and while they are scarce the owners post only the nodes they pop next (PL_LOOK_TOP_BUSY / PL_LOOK_BACKLOG2). Per size: ms with and
     without, identical results."""
     from automatedvaletparking_amd import workloads
     out = {"workload": "Case1 map, n random start/goal pairs (config[1]'s sampler), pop cap %d, one workgroup per problem" % POP_CAP, "sizes": {}}

@@ -274,8 +274,8 @@ int32_t avp_plan_group(int32_t mode);       /* problems per workgroup of the ker
  * (tests/test_gpu_lookahead.py: bit-identical records, paths and traces with and without).
  * avp_plan_look_bytes: bytes of the lookahead workspace (the same for every n and max_nodes; 0 = the library would not use one: a batch it
  * plans in a group form -- 11 problems per CU or more --, more than 16 children). A batch of more problems than CUs has no helpers until
- * its tail: a workgroup serves once the problem counter has run dry, and the owners use the lookahead from the moment the helpers outnumber
- * the workgroups still planning (rounds 2 - 5: at most two problems per CU). The helpers occupy every CU their launch leaves free until its last problem is done:
+ * its tail: a workgroup serves once the problem counter has run dry, and while helpers are scarce the owners post only the nodes they pop
+ * next (rounds 2 - 5: at most two problems per CU). The helpers occupy every CU their launch leaves free until its last problem is done:
  * meant for a launch that has the device to itself, not for several concurrent launches on different streams.
  *
  * Problem order. The persistent workgroups (waves) take problems off a counter; when the batch is larger than the chip the

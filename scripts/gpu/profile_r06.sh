@@ -39,7 +39,7 @@ for v in default look_atomics look_fault5; do
 done
 # the PRODUCT library with a record store of 1 024 entries (avp_plan_set_look_entries): tags collide, entries change hands all the time
 timeout -k 10 300 python scripts/look_soak.py --entries-log2 10 --launches 300 > $O/soak_look_small.json 2> $O/soak_look_small.err
-# a batch of six problems per CU: helpers only in its tail, behind the helpers : owners gate (300 launches, digest of all 1 536 problems)
+# a batch of six problems per CU: helpers only in its tail, owners posting fewer nodes while they are scarce (300 launches, digest of all 1 536 problems)
 timeout -k 10 400 python scripts/look_soak.py --n 1536 --launches 300 > $O/soak_look_n1536.json 2> $O/soak_look_n1536.err
 timeout -k 10 300 python scripts/look_scale.py 256 384 512 640 768 1024 1280 1536 2048 2560 3000 > $O/lookahead_batch_sizes.jsonl 2> $O/lookahead_batch_sizes.err
 timeout -k 10 500 python scripts/large_map_bench.py > $O/large_maps.json 2> $O/large_maps.err

@@ -2,9 +2,10 @@
 # lookahead vs batch size, variants of the helpers : owners gate (scripts/look_scale.py); VARS="look16 ratio4 ..." NS="256 512 ..."
 mkdir -p gpurun_out/r06f
 : > gpurun_out/r06f/scale.log
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for v in ${VARS:-look16 ratio2 ratio4 ratio8 ratio12}; do
-    AVP_HIP_LIB=automatedvaletparking_amd/variants/libavp_hip_$v.so python scripts/look_scale.py ${NS:-256 512 768 1024 1536 2048 3000} 2>/dev/null >> gpurun_out/r06f/scale.log
+    L=automatedvaletparking_amd/variants/libavp_hip_$v.so; [ $v = default ] && L=automatedvaletparking_amd/libavp_hip.so
+    AVP_HIP_LIB=$L python scripts/look_scale.py ${NS:-256 512 768 1024 1536 2048 3000} 2>/dev/null >> gpurun_out/r06f/scale.log
   done
 done
 python - <<'PY'

@@ -19,7 +19,7 @@ def _pairs(m, dm, n, seed):
     return free[0:2 * n:2], free[1:2 * n:2]
 
 
-@pytest.mark.parametrize("n", [1, 5, 40, 256, 300, 512, 900, 1600])          # (900, 1 600: helpers only in the batch's tail, behind the helpers : owners gate)
+@pytest.mark.parametrize("n", [1, 5, 40, 256, 300, 512, 900, 1600])          # (900, 1 600: helpers only in the batch's tail, scarce: the owners post fewer nodes)
 def test_lookahead_changes_no_result(vehicle, cfg, n):
     from automatedvaletparking_amd import _native, path_planner
     m = case_map_from_gold(1)

@@ -49,11 +49,12 @@ def test_committed_bench_line_keeps_the_contract():
         assert k in d, k
     # round 6: every entry says whether the expansion lookahead ran, and its record store (fixed size) no longer drops out at a large pop cap
     assert d["c3"]["lookahead"] is False and isinstance(d["c5"]["lookahead"], bool) and "lookahead_note" in d["c3"]
-    # ... and it runs on batches larger than the chip (helpers only in the tail, behind the helpers : owners gate): never slower, same results
+    # ... and it runs on batches larger than the chip (helpers only in the tail; the owners post fewer nodes while helpers are scarce): never slower, same results
     for n, e in d["lookahead_batch_sizes"]["sizes"].items():
         assert e["identical_results"] is True and e["lookahead_with"] is True and e["lookahead_without"] is False, n
         assert e["ms_with"] <= 1.03 * e["ms_without"], (n, e)
-    assert d["lookahead_batch_sizes"]["sizes"]["1536"]["ms_with"] <= 0.9 * d["lookahead_batch_sizes"]["sizes"]["1536"]["ms_without"]
+    lb = d["lookahead_batch_sizes"]["sizes"]
+    assert lb["512"]["ms_with"] <= 0.75 * lb["512"]["ms_without"] and lb["1024"]["ms_with"] <= 0.93 * lb["1024"]["ms_without"] and lb["1536"]["ms_with"] <= 0.85 * lb["1536"]["ms_without"]
     for w in ("c2", "c5"):
         for cap_s, e in d["cap_sweep"][w].items():
             assert isinstance(e["lookahead"], bool) and e["us_per_pop_of_the_longest_search"] > 0, (w, cap_s)
