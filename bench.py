@@ -40,6 +40,13 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# config[2] is 20 launches on 20 HIP streams. The ROCm runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+# launches that share a queue run one after the other: with 4, four launches are in flight, each down to its ~40 capped searches after a
+# millisecond (164 of 256 CUs busy) until the slowest is done -- 77 ms; with a queue per stream every launch's workgroups are resident as CUs
+# fall free -- 51 ms (8 queues: 55, 16: 54). A setting of the HIP runtime of THIS process, read when it initialises (before torch is imported);
+# single-process runs only (the multi-rank runs have no multi-stream extra and keep the runtime's default beside RCCL's own streams).
+if os.environ.get("WORLD_SIZE", "1") == "1" and os.environ.get("AVP_BENCH_FORCE_DIST") != "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 sys.path.insert(0, ROOT)
 
 POP_CAP = 1000
@@ -558,6 +565,7 @@ def extra_workload(b, name):
     xs["kernel_form"] = FORM_NAMES.get(xg[0].mode)
     xs["lookahead"] = any(bool(g.bp.last_lookahead) for g in xg)
     if len(xg) > 1:
+        xs["hip_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")
         xs["lookahead_note"] = "%d launches on %d streams share the device: each one's helpers would hold compute units the others' problems wait for (measured 133 vs 83 ms), so the lookahead is off here" % (len(xg), len(xg))
     return xs
 
