@@ -2226,7 +2226,7 @@ __device__ __forceinline__ void pl_look_post(const PlLook& look, const PlanWs& w
     const unsigned long long helpers_all = __shfl(c, 0, 64), ta = __shfl(c, 1, 64), ha = __shfl(c, 2, 64), tb = __shfl(c, 3, 64), hb = __shfl(c, 4, 64);
     // (too few helpers for the searches still running -- a large batch before its tail: their records would all come late, and the
     //  bookkeeping of a pop that finds none costs more than it gains: as if there were none yet. The count of helpers only grows.)
-    const long long owners_left = (long long)look.main_blocks - (long long)helpers_all;
+    const long long owners_left = (long long)gridDim.x - (long long)helpers_all;      // (every workgroup of the launch that is no helper now: the helper-only workgroups of a launch smaller than the chip are helpers from the start)
     const unsigned long long helpers = 4ll * (long long)helpers_all >= (long long)PL_LOOK_RATIO_X4 * owners_left ? helpers_all : 0ull;
     const long long backlog = max((long long)(ta - ha), (long long)(tb - hb));
     if (lane == 0) { s.look_calm = (helpers != 0 && backlog <= PL_LOOK_BACKLOG) ? 1 : 0; s.look_live = helpers != 0 ? 1 : 0; }   // (calm: the helpers keep up, a pending record is worth a short wait)
@@ -2456,7 +2456,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_kernel(DevMap m, avp_params p
         const int64_t pid = s.pid;
         // no problem left: done -- or, with LOOK, serve the owners of the unfinished problems until all are finished
         const bool helper = LOOK && pid >= n;
-        const int hk = (int)(blockIdx.x & 1u);              // a helper serves one kind of job: 0 = children halves, 1 = shot halves
+        const int hk = (int)(blockIdx.x & 1u);              // a helper serves one kind of job: 0 = children halves, 1 = shot halves (an even split is the optimum: 3 / 8, 5 / 8, 6 / 8 measured, NOTEBOOK round 6)
         const bool hC = helper && hk == 0, hS = helper && hk == 1;
         if (pid >= n && !helper) break;
         // second launch behind plan_wave_kernel: only the problems it handed back (status 100 = AVP_PLAN_RETRY)

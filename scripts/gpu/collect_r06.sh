@@ -36,3 +36,4 @@ cp $O/pmc_icache.json $P/r06_pmc_icache.json
 cp $O/config_sweep.jsonl $P/r06_config_sweep.jsonl
 cp $O/cap_growth.jsonl $P/r06_cap_growth.jsonl
 cp $O/lookahead_batch_sizes.jsonl $P/r06_lookahead_batch_sizes.jsonl
+cp $O/lookahead_capped_sets.jsonl $P/r06_lookahead_capped_sets.jsonl

@@ -42,6 +42,7 @@ timeout -k 10 300 python scripts/look_soak.py --entries-log2 10 --launches 300 >
 # a batch of six problems per CU: helpers only in its tail, owners posting fewer nodes while they are scarce (300 launches, digest of all 1 536 problems)
 timeout -k 10 400 python scripts/look_soak.py --n 1536 --launches 300 > $O/soak_look_n1536.json 2> $O/soak_look_n1536.err
 timeout -k 10 300 python scripts/look_scale.py 256 384 512 640 768 1024 1280 1536 2048 2560 3000 > $O/lookahead_batch_sizes.jsonl 2> $O/lookahead_batch_sizes.err
+timeout -k 10 300 python scripts/look_capped.py 32 64 100 128 160 200 256 400 2>/dev/null | grep '^{' > $O/lookahead_capped_sets.jsonl
 timeout -k 10 500 python scripts/large_map_bench.py > $O/large_maps.json 2> $O/large_maps.err
 for sl in off on; do for cfgs in "16384 3" "32768 2"; do set -- $cfgs
   timeout -k 10 300 python scripts/variant_bench.py --no-profile --big $1 --big-mode $2 --steps 1 --slice $sl > $O/slice_$1_m$2_$sl.json 2>/dev/null
